@@ -1,0 +1,180 @@
+"""ctypes front-end of the CPU ORACLE (test infrastructure only -- see fgs_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (fresnel_amd) never does.
+
+Reference followed: scripts/models/differentiable_renderer.py (TileBasedRenderer,
+DR:412-686; compute_2d_covariance DR:123-195).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libfgs_oracle.so")
+
+
+class OrCamera(ctypes.Structure):
+    _fields_ = [("view", ctypes.c_float * 16), ("fx", ctypes.c_float), ("fy", ctypes.c_float),
+                ("cx", ctypes.c_float), ("cy", ctypes.c_float), ("width", ctypes.c_int32),
+                ("height", ctypes.c_int32), ("near_", ctypes.c_float), ("far_", ctypes.c_float)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "fgs_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.fgs_or_count_pairs.restype = ctypes.c_int64
+        _lib.fgs_or_tile_lists.restype = ctypes.c_int64
+        _lib.fgs_or_render_fwd_bwd.restype = ctypes.c_int64
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def make_camera(view, fx, fy, cx, cy, width, height, near=0.01, far=100.0):
+    cam = OrCamera()
+    v = _f32(view).reshape(16)
+    for i in range(16):
+        cam.view[i] = float(v[i])
+    cam.fx, cam.fy, cam.cx, cam.cy = float(fx), float(fy), float(cx), float(cy)
+    cam.width, cam.height = int(width), int(height)
+    cam.near_, cam.far_ = float(near), float(far)
+    return cam
+
+
+def project(pos, scale, quat, cam, max_radius=64.0):
+    pos, scale, quat = _f32(pos), _f32(scale), _f32(quat)
+    N = pos.shape[0]
+    out = dict(cov2d=np.zeros((N, 4), np.float32), mean2d=np.zeros((N, 2), np.float32),
+               depth=np.zeros(N, np.float32), radius=np.zeros(N, np.float32),
+               visible=np.zeros(N, np.uint8), bbox=np.zeros((N, 4), np.int32),
+               conic=np.zeros((N, 3), np.float32))
+    lib().fgs_or_project(ctypes.c_int32(N), _p(pos), _p(scale), _p(quat), ctypes.byref(cam),
+                         ctypes.c_float(max_radius), _p(out["cov2d"]), _p(out["mean2d"]),
+                         _p(out["depth"]), _p(out["radius"]), _p(out["visible"]), _p(out["bbox"]),
+                         _p(out["conic"]))
+    return out
+
+
+def depth_order(depth, visible):
+    N = depth.shape[0]
+    order = np.zeros(N, np.int32)
+    vs = np.zeros(N, np.int32)
+    V = ctypes.c_int32(0)
+    lib().fgs_or_depth_order(ctypes.c_int32(N), _p(_f32(depth)), _p(np.ascontiguousarray(visible, np.uint8)),
+                             _p(order), _p(vs), ctypes.byref(V))
+    return order, vs[:V.value].copy()
+
+
+def count_pairs(vis_sorted, bbox):
+    return int(lib().fgs_or_count_pairs(ctypes.c_int32(len(vis_sorted)),
+                                        _p(np.ascontiguousarray(vis_sorted, np.int32)),
+                                        _p(np.ascontiguousarray(bbox, np.int32))))
+
+
+def tile_lists(vis_sorted, bbox, W, H, ts=16):
+    vs = np.ascontiguousarray(vis_sorted, np.int32)
+    bb = np.ascontiguousarray(bbox, np.int32)
+    T = ((W + ts - 1) // ts) * ((H + ts - 1) // ts)
+    ranges = np.zeros(T + 1, np.int64)
+    D = lib().fgs_or_tile_lists(ctypes.c_int32(len(vs)), _p(vs), _p(bb), ctypes.c_int32(W),
+                                ctypes.c_int32(H), ctypes.c_int32(ts), _p(ranges), None)
+    ids = np.zeros(max(int(D), 1), np.int32)
+    lib().fgs_or_tile_lists(ctypes.c_int32(len(vs)), _p(vs), _p(bb), ctypes.c_int32(W),
+                            ctypes.c_int32(H), ctypes.c_int32(ts), _p(ranges), _p(ids))
+    return ranges, ids[:int(D)]
+
+
+class Rendered:
+    """Everything the oracle's forward produced (kept for its backward)."""
+
+
+def render(pos, scale, quat, color, opacity, cam, bg=(0.0, 0.0, 0.0), max_radius=64.0,
+           phases=None, phase_amp=0.25, keep_pairs=True):
+    """Oracle forward for ONE image: returns Rendered with .image (3,H,W), .depth (H,W)."""
+    r = Rendered()
+    r.pos, r.scale, r.quat = _f32(pos), _f32(scale), _f32(quat)
+    r.color, r.opacity = _f32(color), _f32(opacity)
+    r.cam, r.bg, r.max_radius = cam, _f32(bg), float(max_radius)
+    r.phases = None if phases is None else _f32(phases)
+    r.phase_amp = float(phase_amp)
+    W, H = cam.width, cam.height
+    r.proj = project(r.pos, r.scale, r.quat, cam, max_radius)
+    r.order, r.vis_sorted = depth_order(r.proj["depth"], r.proj["visible"])
+    r.P = count_pairs(r.vis_sorted, r.proj["bbox"])
+    r.image = np.zeros((3, H, W), np.float32)
+    r.depth = np.zeros((H, W), np.float32)
+    r.state = np.zeros((5, H, W), np.float32)
+    r.pair_T = np.zeros(max(r.P, 1), np.float32) if keep_pairs else None
+    r.pair_phi = np.zeros(max(r.P, 1), np.float32) if (keep_pairs and phases is not None) else None
+    lib().fgs_or_composite_fwd(
+        ctypes.c_int32(len(r.vis_sorted)), _p(r.vis_sorted), _p(r.proj["mean2d"]), _p(r.proj["conic"]),
+        _p(r.color), _p(r.opacity), _p(r.proj["depth"]), _p(r.proj["bbox"]), _p(r.phases),
+        ctypes.c_float(r.phase_amp), ctypes.c_int32(W), ctypes.c_int32(H), _p(r.bg), _p(r.image),
+        _p(r.depth), _p(r.state), _p(r.pair_T), _p(r.pair_phi))
+    return r
+
+
+def render_backward(r, gI, gD):
+    """Oracle backward for the image produced by render(); returns dict of grads."""
+    gI, gD = _f32(gI), _f32(gD)
+    N = r.pos.shape[0]
+    W, H = r.cam.width, r.cam.height
+    g_mean = np.zeros((N, 2), np.float32)
+    g_conic = np.zeros((N, 3), np.float32)
+    g_color = np.zeros((N, 3), np.float32)
+    g_op = np.zeros(N, np.float32)
+    g_dep = np.zeros(N, np.float32)
+    g_ph = np.zeros(N, np.float32) if r.phases is not None else None
+    lib().fgs_or_composite_bwd(
+        ctypes.c_int32(len(r.vis_sorted)), _p(r.vis_sorted), _p(r.proj["mean2d"]), _p(r.proj["conic"]),
+        _p(r.color), _p(r.opacity), _p(r.proj["depth"]), _p(r.proj["bbox"]), _p(r.phases),
+        ctypes.c_float(r.phase_amp), ctypes.c_int32(W), ctypes.c_int32(H), _p(r.bg), _p(r.state),
+        _p(r.pair_T), _p(r.pair_phi), _p(gI), _p(gD), _p(g_mean), _p(g_conic), _p(g_color), _p(g_op),
+        _p(g_dep), _p(g_ph))
+    g_pos = np.zeros((N, 3), np.float32)
+    g_scale = np.zeros((N, 3), np.float32)
+    g_quat = np.zeros((N, 4), np.float32)
+    lib().fgs_or_project_bwd(ctypes.c_int32(N), _p(r.pos), _p(r.scale), _p(r.quat), ctypes.byref(r.cam),
+                             _p(r.proj["visible"]), _p(g_mean), _p(g_conic), _p(g_dep), _p(g_pos),
+                             _p(g_scale), _p(g_quat))
+    out = dict(positions=g_pos, scales=g_scale, rotations=g_quat, colors=g_color, opacities=g_op,
+               mean2d=g_mean, conic=g_conic, depth=g_dep)
+    if g_ph is not None:
+        out["phases"] = g_ph
+    return out
+
+
+def render_fwd_bwd_timed(pos, scale, quat, color, opacity, cam, gI, gD, bg=(0.0, 0.0, 0.0),
+                         max_radius=64.0):
+    """One fused forward+backward inside C (bench.py cpu_baseline leg). Returns pairs P."""
+    pos, scale, quat, color, opacity = map(_f32, (pos, scale, quat, color, opacity))
+    N = pos.shape[0]
+    W, H = cam.width, cam.height
+    img = np.zeros((3, H, W), np.float32)
+    dep = np.zeros((H, W), np.float32)
+    gp, gs, gq = np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32)
+    gc, go = np.zeros((N, 3), np.float32), np.zeros(N, np.float32)
+    P = lib().fgs_or_render_fwd_bwd(ctypes.c_int32(N), _p(pos), _p(scale), _p(quat), _p(color), _p(opacity),
+                                    ctypes.byref(cam), ctypes.c_float(max_radius), _p(_f32(bg)), _p(_f32(gI)),
+                                    _p(_f32(gD)), _p(img), _p(dep), _p(gp), _p(gs), _p(gq), _p(gc), _p(go))
+    return int(P), img, dep

@@ -1,0 +1,363 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, never on the GPU box).
+
+Imports the reference's Python renderer from /root/reference/scripts (read-only),
+runs it on small seeded inputs and writes inputs + reference outputs as .npz
+fixtures next to this file.  Nothing from the reference is copied: the fixtures
+hold data only (inputs, expected outputs, gradients, generating-stack metadata).
+
+Cases:
+  G1 dummy-SAAG N=256 @128x128                (config-1 shape)
+  G2 anisotropic, opacity up to 1.3 (0.99 clamp active), bg != 0, N=300 @96x96
+  G3 all Gaussians behind the camera -> background, zero grads
+  G4 huge scales -> radius cap 64 active, @160x160
+  G5 zone-quantised depths (8 values), argsort patched to stable=True in THIS harness
+  G6 G1 + scalar phases, use_phase_blending=True (reference forward + colour-only grad;
+     full grads from an out-of-place restatement that reproduces the forward exactly)
+  G7 off-axis view matrix (orbit camera el=20deg az=135deg)
+  G8 AngularSpectrumPropagator 64x64 known answers
+  G9 ASMWaveFieldRenderer N=256 @128x128, scalar and (N,3) phases, grads incl. wavelengths
+
+Upstream gradients gI ~ N(0,1), gD ~ N(0,0.01) come from numpy's frozen legacy
+RandomState(seed) so tests can regenerate them bit-exactly; they are stored too.
+"""
+import os
+import sys
+
+REF = "/root/reference/scripts"
+if not os.path.isdir(REF):
+    sys.exit("make_goldens.py: /root/reference is absent; goldens can only be generated "
+             "in the build container")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+from models.differentiable_renderer import (  # noqa: E402  (the reference, read-only)
+    Camera, TileBasedRenderer, compute_2d_covariance,
+    AngularSpectrumPropagator, ASMWaveFieldRenderer,
+)
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+META = dict(torch=torch.__version__, numpy=np.__version__, device="cpu")
+
+
+def upstream(seed, H, W):
+    rs = np.random.RandomState(seed)
+    gI = rs.standard_normal((3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)  # var 0.01
+    return gI, gD
+
+
+def frontal_camera(R):
+    return Camera(fx=0.8 * R, fy=0.8 * R, cx=R / 2, cy=R / 2, width=R, height=R)
+
+
+def orbit_view(el_deg, az_deg, distance=2.0):
+    """View matrix of the reference's orbit camera (formula at
+    scripts/training/train_gaussian_decoder.py:706-744), evaluated here in numpy."""
+    el, az = np.deg2rad(el_deg), np.deg2rad(az_deg)
+    cam = np.array([distance * np.cos(el) * np.sin(az), distance * np.sin(el),
+                    distance * np.cos(el) * np.cos(az)])
+    fwd = -cam / np.linalg.norm(cam)
+    right = np.cross(fwd, np.array([0.0, 1.0, 0.0]))
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    Rm = np.array([right, up, -fwd])
+    t = -Rm @ cam
+    V = np.eye(4, dtype=np.float32)
+    V[:3, :3] = Rm.astype(np.float32)
+    V[:3, 3] = t.astype(np.float32)
+    return V
+
+
+def dummy_saag(N, seed):
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.randn(N, 3, generator=g) * 0.5
+    pos[:, 2] -= 2
+    scale = torch.ones(N, 3) * 0.05
+    rot = torch.zeros(N, 4)
+    rot[:, 0] = 1
+    col = torch.rand(N, 3, generator=g)
+    opa = torch.ones(N) * 0.8
+    return pos, scale, rot, col, opa
+
+
+def intermediates(renderer, pos, scale, rot, camera, stable):
+    """Re-evaluate the reference's integer stages with its own helper functions."""
+    with torch.no_grad():
+        cov, mean, depth = compute_2d_covariance(pos, scale, rot, camera)
+        radii = renderer._compute_radius(cov)
+        order = torch.argsort(depth, stable=stable)
+        order_unstable = torch.argsort(depth)
+        W, H = renderer.width, renderer.height
+        vis = (depth > camera.near) & (depth < camera.far)
+        vis &= (mean[:, 0] + radii > 0) & (mean[:, 0] - radii < W)
+        vis &= (mean[:, 1] + radii > 0) & (mean[:, 1] - radii < H)
+        bbox = np.zeros((pos.shape[0], 4), dtype=np.int32)
+        for i in range(pos.shape[0]):
+            if not bool(vis[i]):
+                continue
+            r = radii[i].item()
+            x0 = max(0, int(mean[i, 0].item() - r))
+            x1 = min(W, int(mean[i, 0].item() + r) + 1)
+            y0 = max(0, int(mean[i, 1].item() - r))
+            y1 = min(H, int(mean[i, 1].item() + r) + 1)
+            bbox[i] = (x0, x1, y0, y1)
+        cov_reg = cov + 1e-4 * torch.eye(2).unsqueeze(0)
+        inv = torch.linalg.pinv(cov_reg)
+    return dict(cov_2d=cov.numpy(), means_2d=mean.numpy(), depths=depth.numpy(),
+                radii=radii.numpy(), depth_order=order.numpy().astype(np.int32),
+                depth_order_unstable=order_unstable.numpy().astype(np.int32),
+                visible=vis.numpy().astype(np.uint8), bbox=bbox, cov_inv=inv.numpy())
+
+
+def run_tbr(name, pos, scale, rot, col, opa, camera, H, W, bg=(0.0, 0.0, 0.0),
+            seed_up=0, phases=None, use_phase=False, amp=0.25, stable=False,
+            grad_inputs="all"):
+    renderer = TileBasedRenderer(W, H, background=bg, use_phase_blending=use_phase,
+                                 phase_amplitude=amp)
+    leaves = [t.clone().requires_grad_(grad_inputs == "all") for t in (pos, scale, rot, col, opa)]
+    if grad_inputs == "color":
+        leaves[3].requires_grad_(True)
+    ph = None
+    if phases is not None:
+        ph = phases.clone()
+    real_argsort = torch.argsort
+    if stable:
+        torch.argsort = lambda x, *a, **k: real_argsort(x, stable=True)
+    try:
+        img, dep = renderer(*leaves, camera, return_depth=True, phases=ph)
+    finally:
+        torch.argsort = real_argsort
+    gI, gD = upstream(seed_up, H, W)
+    loss = (img * torch.from_numpy(gI)).sum() + (dep * torch.from_numpy(gD)).sum()
+    loss.backward()
+    rec = dict(
+        name=name, positions=pos.numpy(), scales=scale.numpy(), rotations=rot.numpy(),
+        colors=col.numpy(), opacities=opa.numpy(),
+        view=camera.view_matrix.numpy().astype(np.float32),
+        intr=np.array([camera.fx, camera.fy, camera.cx, camera.cy, camera.near, camera.far],
+                      dtype=np.float64),
+        size=np.array([W, H], dtype=np.int32), background=np.array(bg, dtype=np.float32),
+        seed_up=np.int32(seed_up), gI=gI, gD=gD,
+        image=img.detach().numpy(), depth=dep.detach().numpy(),
+        use_phase=np.uint8(use_phase), phase_amplitude=np.float32(amp), stable=np.uint8(stable),
+    )
+    names = ["positions", "scales", "rotations", "colors", "opacities"]
+    for n, t in zip(names, leaves):
+        if t.grad is not None:
+            rec["grad_" + n] = t.grad.numpy()
+        elif t.requires_grad:
+            rec["grad_" + n] = np.zeros_like(t.detach().numpy())
+    if phases is not None:
+        rec["phases"] = phases.numpy()
+    rec.update(intermediates(renderer, pos, scale, rot, camera, stable))
+    for k, v in META.items():
+        rec["meta_" + k] = np.array(v)
+    return rec
+
+
+def save(rec, fname):
+    path = os.path.join(OUT, fname)
+    np.savez_compressed(path, **rec)
+    print(f"{fname}: {os.path.getsize(path) / 1024:.0f} KB")
+
+
+# ----------------------------------------------------------------------------------
+# G6 helper: an out-of-place restatement of the phase-blending recurrence (our code,
+# written for this harness) whose autograd supplies the full gradients the reference
+# cannot produce.  It must reproduce the reference forward exactly.
+# ----------------------------------------------------------------------------------
+def phase_restatement(pos, scale, rot, col, opa, phases, camera, H, W, bg, amp, inter):
+    cov, mean, depth = compute_2d_covariance(pos, scale, rot, camera)
+    order = torch.from_numpy(inter["depth_order"].astype(np.int64))
+    vis = torch.from_numpy(inter["visible"].astype(bool))
+    bbox = inter["bbox"]
+    cov_reg = cov + 1e-4 * torch.eye(2).unsqueeze(0)
+    inv = torch.linalg.pinv(cov_reg)
+    C = torch.zeros(H, W, 3)
+    A = torch.zeros(H, W)
+    D = torch.zeros(H, W)
+    P = torch.zeros(H, W)
+    for i in order.tolist():
+        if not bool(vis[i]):
+            continue
+        x0, x1, y0, y1 = [int(t) for t in bbox[i]]
+        if x0 >= x1 or y0 >= y1:
+            continue
+        ly, lx = torch.meshgrid(torch.arange(y0, y1, dtype=torch.float32),
+                                torch.arange(x0, x1, dtype=torch.float32), indexing="ij")
+        dx = lx - mean[i, 0]
+        dy = ly - mean[i, 1]
+        a, b, c, d = inv[i, 0, 0], inv[i, 0, 1], inv[i, 1, 0], inv[i, 1, 1]
+        mahal = a * dx * dx + (b + c) * dx * dy + d * dy * dy
+        alpha = torch.exp(-0.5 * mahal) * opa[i]
+        prev = P[y0:y1, x0:x1]
+        pd = torch.abs(phases[i] - prev)
+        pd = torch.min(pd, 1.0 - pd)
+        alpha = alpha * ((1.0 - amp) + amp * torch.cos(pd * 2 * 3.14159))
+        alpha = torch.clamp(alpha, 0, 0.99)
+        T = 1.0 - A[y0:y1, x0:x1]
+        w = alpha * T
+        mask = torch.zeros(H, W, dtype=torch.bool)
+        mask[y0:y1, x0:x1] = True
+        wfull = torch.zeros(H, W).masked_scatter(mask, w)
+        C = C + wfull.unsqueeze(-1) * col[i].view(1, 1, 3)
+        D = D + wfull * depth[i]
+        A = A + wfull
+        pc = wfull / A.clamp(min=1e-6)
+        Pn = P * (1 - pc) + phases[i] * pc
+        P = torch.where(mask, Pn, P)
+    C = C + (1.0 - A).unsqueeze(-1) * torch.tensor(bg).view(1, 1, 3)
+    return torch.clamp(C.permute(2, 0, 1), 0, 1), D
+
+
+def main():
+    # G1 ---------------------------------------------------------------------------
+    R = 128
+    pos, scale, rot, col, opa = dummy_saag(256, 0)
+    g1 = run_tbr("G1", pos, scale, rot, col, opa, frontal_camera(R), R, R, seed_up=101)
+    save(g1, "G1_saag256_128.npz")
+
+    # G2 ---------------------------------------------------------------------------
+    R = 96
+    g = torch.Generator().manual_seed(2)
+    N = 300
+    pos2 = torch.randn(N, 3, generator=g) * 0.5
+    pos2[:, 2] -= 2
+    scale2 = torch.rand(N, 3, generator=g) * 0.12 + 0.01
+    rot2 = torch.randn(N, 4, generator=g)
+    col2 = torch.rand(N, 3, generator=g)
+    opa2 = torch.rand(N, generator=g) * 1.3
+    g2 = run_tbr("G2", pos2, scale2, rot2, col2, opa2, frontal_camera(R), R, R,
+                 bg=(0.1, 0.2, 0.3), seed_up=102)
+    save(g2, "G2_aniso300_96.npz")
+
+    # G3 ---------------------------------------------------------------------------
+    R = 64
+    pos3, scale3, rot3, col3, opa3 = dummy_saag(64, 3)
+    pos3 = pos3.clone()
+    pos3[:, 2] += 4  # z ~ +2: behind the camera (camera looks down -Z)
+    g3 = run_tbr("G3", pos3, scale3, rot3, col3, opa3, frontal_camera(R), R, R,
+                 bg=(0.25, 0.5, 0.75), seed_up=103)
+    save(g3, "G3_behind64_64.npz")
+
+    # G4 ---------------------------------------------------------------------------
+    R = 160
+    g = torch.Generator().manual_seed(4)
+    N = 96
+    pos4 = torch.randn(N, 3, generator=g) * 0.6
+    pos4[:, 2] -= 2
+    scale4 = torch.rand(N, 3, generator=g) * 0.6 + 0.2
+    rot4 = torch.randn(N, 4, generator=g)
+    col4 = torch.rand(N, 3, generator=g)
+    opa4 = torch.rand(N, generator=g) * 0.5
+    g4 = run_tbr("G4", pos4, scale4, rot4, col4, opa4, frontal_camera(R), R, R, seed_up=104)
+    save(g4, "G4_radcap96_160.npz")
+
+    # G5 ---------------------------------------------------------------------------
+    R = 96
+    g = torch.Generator().manual_seed(5)
+    N = 400
+    pos5 = torch.randn(N, 3, generator=g) * 0.5
+    zone = torch.randint(0, 8, (N,), generator=g).float()
+    pos5[:, 2] = -2.0 - 2.0 * (zone + 0.5) / 8.0
+    scale5 = torch.rand(N, 3, generator=g) * 0.06 + 0.03
+    rot5 = torch.randn(N, 4, generator=g)
+    col5 = torch.rand(N, 3, generator=g)
+    opa5 = torch.rand(N, generator=g) * 0.9 + 0.05
+    g5 = run_tbr("G5", pos5, scale5, rot5, col5, opa5, frontal_camera(R), R, R,
+                 seed_up=105, stable=True)
+    save(g5, "G5_zones400_96.npz")
+
+    # G6 ---------------------------------------------------------------------------
+    R = 128
+    pos6, scale6, rot6, col6, opa6 = dummy_saag(256, 0)
+    g = torch.Generator().manual_seed(6)
+    ph6 = torch.rand(256, generator=g)
+    cam6 = frontal_camera(R)
+    g6 = run_tbr("G6", pos6, scale6, rot6, col6, opa6, cam6, R, R, seed_up=106,
+                 phases=ph6, use_phase=True, amp=0.25, grad_inputs="color")
+    leaves = [t.clone().requires_grad_(True) for t in (pos6, scale6, rot6, col6, opa6, ph6)]
+    img_r, dep_r = phase_restatement(*leaves, cam6, R, R, (0.0, 0.0, 0.0), 0.25, g6)
+    fwd_diff = max(float((img_r.detach() - torch.from_numpy(g6["image"])).abs().max()),
+                   float((dep_r.detach() - torch.from_numpy(g6["depth"])).abs().max()))
+    print("G6 restatement vs reference forward: max abs diff =", fwd_diff)
+    assert fwd_diff == 0.0, "out-of-place restatement must reproduce the reference forward"
+    loss = (img_r * torch.from_numpy(g6["gI"])).sum() + (dep_r * torch.from_numpy(g6["gD"])).sum()
+    loss.backward()
+    col_diff = float((leaves[3].grad - torch.from_numpy(g6["grad_colors"])).abs().max())
+    print("G6 restatement colour-grad vs reference colour-grad: max abs diff =", col_diff)
+    g6["ref_grad_colors"] = g6.pop("grad_colors")
+    for n, t in zip(["positions", "scales", "rotations", "colors", "opacities", "phases"], leaves):
+        g6["restated_grad_" + n] = t.grad.numpy()
+    g6["restated_fwd_maxdiff"] = np.float64(fwd_diff)
+    save(g6, "G6_phase256_128.npz")
+
+    # G7 ---------------------------------------------------------------------------
+    R = 96
+    g = torch.Generator().manual_seed(7)
+    N = 256
+    pos7 = torch.randn(N, 3, generator=g) * 0.35
+    scale7 = torch.rand(N, 3, generator=g) * 0.08 + 0.02
+    rot7 = torch.randn(N, 4, generator=g)
+    col7 = torch.rand(N, 3, generator=g)
+    opa7 = torch.rand(N, generator=g)
+    cam7 = frontal_camera(R)
+    cam7.set_view(torch.from_numpy(orbit_view(20.0, 135.0)))
+    g7 = run_tbr("G7", pos7, scale7, rot7, col7, opa7, cam7, R, R, bg=(0.05, 0.05, 0.05),
+                 seed_up=107)
+    save(g7, "G7_orbit256_96.npz")
+
+    # G8 ---------------------------------------------------------------------------
+    S = 64
+    prop = AngularSpectrumPropagator(S, S, pixel_pitch=1.0 / 256.0, wavelength=0.05)
+    rs = np.random.RandomState(8)
+    f = (rs.standard_normal((S, S)) + 1j * rs.standard_normal((S, S))).astype(np.complex64)
+    ft = torch.from_numpy(f)
+    with torch.no_grad():
+        out0 = prop.propagate(ft, torch.tensor(0.0))
+        out1 = prop.propagate(ft, torch.tensor(0.3), torch.tensor(0.05))
+        out2 = prop.propagate(ft, torch.tensor(-0.7), torch.tensor(0.0635))
+        H1 = prop._compute_transfer_function(torch.tensor(0.3), torch.tensor(0.05))
+    g8 = dict(field=f, out_z0=out0.numpy(), out_z03_l005=out1.numpy(),
+              out_zm07_l00635=out2.numpy(), H_z03_l005=H1.numpy(),
+              FX=prop.FX.numpy(), FY=prop.FY.numpy(), pixel_pitch=np.float64(1.0 / 256.0))
+    for k, v in META.items():
+        g8["meta_" + k] = np.array(v)
+    save(g8, "G8_asm_propagator_64.npz")
+
+    # G9 ---------------------------------------------------------------------------
+    R = 128
+    pos9, scale9, rot9, col9, opa9 = dummy_saag(256, 9)
+    # ASM depth planes span 0.1..2.0; the SAAG cloud sits at depth ~2 +- 0.5 so several
+    # planes are populated and the rest exercise the empty-plane skip.
+    g = torch.Generator().manual_seed(9)
+    ph_s = torch.rand(256, generator=g) * 2 * np.pi
+    ph_v = torch.rand(256, 3, generator=g) * 2 * np.pi
+    cam9 = frontal_camera(R)
+    for tag, ph in (("scalar", ph_s), ("rgb", ph_v)):
+        ren = ASMWaveFieldRenderer(R, R, background=(0.1, 0.1, 0.1))
+        leaves = [t.clone().requires_grad_(True) for t in (pos9, scale9, rot9, col9, opa9, ph)]
+        wl = torch.tensor([0.0635, 0.05, 0.041], requires_grad=True)
+        img = ren(*leaves[:5], cam9, phases=leaves[5], wavelengths_rgb=wl)
+        gI, _ = upstream(109, R, R)
+        (img * torch.from_numpy(gI)).sum().backward()
+        rec = dict(positions=pos9.numpy(), scales=scale9.numpy(), rotations=rot9.numpy(),
+                   colors=col9.numpy(), opacities=opa9.numpy(), phases=ph.numpy(),
+                   wavelengths=wl.detach().numpy(), background=np.array([0.1, 0.1, 0.1], np.float32),
+                   view=cam9.view_matrix.numpy(), size=np.array([R, R], np.int32),
+                   intr=np.array([cam9.fx, cam9.fy, cam9.cx, cam9.cy, cam9.near, cam9.far]),
+                   gI=gI, seed_up=np.int32(109), image=img.detach().numpy(),
+                   grad_wavelengths=wl.grad.numpy())
+        for n, t in zip(["positions", "scales", "rotations", "colors", "opacities", "phases"], leaves):
+            rec["grad_" + n] = t.grad.numpy()
+        for k, v in META.items():
+            rec["meta_" + k] = np.array(v)
+        save(rec, f"G9_asm256_128_{tag}.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,56 @@
+"""Shared test helpers: golden loading, oracle camera construction, tolerances."""
+import glob
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+TBR_CASES = ["G1_saag256_128", "G2_aniso300_96", "G3_behind64_64", "G4_radcap96_160",
+             "G5_zones400_96", "G6_phase256_128", "G7_orbit256_96"]
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def rel_to_max(a, b):
+    """max|a-b| / max|b|  (the tolerance form of SURVEY §8c: <= 1e-4 per tensor)."""
+    b = np.asarray(b)
+    if b.size == 0:
+        return 0.0
+    m = float(np.abs(b).max())
+    return float(np.abs(np.asarray(a) - b).max() / (m if m > 0 else 1.0))
+
+
+def oracle_camera(g):
+    from oracle import fgs_oracle as orc
+    W, H = [int(v) for v in g["size"]]
+    fx, fy, cx, cy, near, far = [float(v) for v in g["intr"]]
+    return orc.make_camera(g["view"], fx, fy, cx, cy, W, H, near, far)
+
+
+def synth_saag(N, seed):
+    """create_dummy_saag distribution (reference scripts/training/train_gaussian_decoder.py:760-778),
+    drawn with numpy so it is reproducible on any box."""
+    rs = np.random.RandomState(seed)
+    pos = (rs.standard_normal((N, 3)) * 0.5).astype(np.float32)
+    pos[:, 2] -= 2
+    scale = np.full((N, 3), 0.05, np.float32)
+    quat = np.zeros((N, 4), np.float32)
+    quat[:, 0] = 1
+    color = rs.random_sample((N, 3)).astype(np.float32)
+    opacity = np.full(N, 0.8, np.float32)
+    return pos, scale, quat, color, opacity
+
+
+def synth_aniso(N, seed, opacity_max=1.0, spread=0.5, zmean=-2.0, smin=0.01, smax=0.13):
+    rs = np.random.RandomState(seed)
+    pos = (rs.standard_normal((N, 3)) * spread).astype(np.float32)
+    pos[:, 2] += zmean
+    scale = (rs.random_sample((N, 3)) * (smax - smin) + smin).astype(np.float32)
+    quat = rs.standard_normal((N, 4)).astype(np.float32)
+    color = rs.random_sample((N, 3)).astype(np.float32)
+    opacity = (rs.random_sample(N) * opacity_max).astype(np.float32)
+    return pos, scale, quat, color, opacity
