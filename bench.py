@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the HIP rasterizer hot path on synthetic N-Gaussian x HxW batches.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward + backward pass of the rasterizer (project, depth sort, tile binning,
+composite, composite backward, projection backward) over one batch of synthetic images that is
+already resident in HBM, plus -- for N > 1 -- the RCCL all-reduce of the decoder-gradient
+bucket that the image-wise data-parallel training step performs.
+
+Workload = BASELINE.json configs[2] per GPU (the configuration the metric "512^2 render,
+1/2/4/8 MI355X" is quoted on): 32 768 Gaussians, 512x512, 8 images per GPU (64 over 8 GPUs),
+create_dummy_saag distribution (reference scripts/training/train_gaussian_decoder.py:760-778).
+Weak scaling: per-GPU work is fixed as N grows.
+
+Prints ONE JSON line (rank 0).  value = composited Gaussian-pixels per second, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+DECODER_GRAD_FLOATS = 673_537  # DirectPatchDecoder gradient bucket (measured)
+
+WORKLOADS = {
+    # name: (N gaussians, resolution, images per GPU)
+    "config3": (32768, 512, 8),
+    "config2": (8192, 256, 16),
+}
+
+
+def synth_batch(n_img, N, seed0, device):
+    """create_dummy_saag (TGD:760-778): pos~N(0,0.5^2), z-=2, scale .05, identity quat,
+    colour~U(0,1), opacity .8; generator seeded per image."""
+    pos, col = [], []
+    for i in range(n_img):
+        g = torch.Generator().manual_seed(seed0 + i)
+        p = torch.randn(N, 3, generator=g) * 0.5
+        p[:, 2] -= 2
+        pos.append(p)
+        col.append(torch.rand(N, 3, generator=g))
+    pos = torch.stack(pos).to(device)
+    col = torch.stack(col).to(device)
+    scale = torch.full((n_img, N, 3), 0.05, device=device)
+    quat = torch.zeros(n_img, N, 4, device=device)
+    quat[..., 0] = 1
+    opa = torch.full((n_img, N), 0.8, device=device)
+    return pos, scale, quat, col, opa
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--images-per-gpu", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)  # nccl IS RCCL on ROCm
+
+    from fresnel_amd import _binding as B
+    from fresnel_amd import renderer as R
+
+    N, S, per_gpu = WORKLOADS[args.workload]
+    if args.images_per_gpu:
+        per_gpu = args.images_per_gpu
+    cfg_id = 3 if args.workload == "config3" else 2
+    # image-wise shard: rank r owns images [r*per_gpu, (r+1)*per_gpu)
+    pos, scale, quat, col, opa = synth_batch(per_gpu, N, 1000 * cfg_id + rank * per_gpu, device)
+    leaves = [t.requires_grad_(True) for t in (pos, scale, quat, col, opa)]
+    cam = R.Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+    cam_t = R.pack_cameras(cam, device)
+    cfg = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, False, 0.25)
+    g = torch.Generator().manual_seed(4242 + rank)
+    gI = torch.randn(per_gpu, 3, S, S, generator=g).to(device)
+    gD = (torch.randn(per_gpu, S, S, generator=g) * 0.1).to(device)
+    bucket = torch.zeros(DECODER_GRAD_FLOATS, device=device) if world > 1 else None
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        img, dep = R.GaussianRenderer.apply(*leaves, None, cam_t, cfg)
+        torch.autograd.backward([img, dep], [gI, gD])
+        if bucket is not None:
+            dist.all_reduce(bucket)  # decoder-gradient bucket of the DP training step
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # unit of work: composited Gaussian-pixels of this rank's batch (device-side count)
+    _, _, saved, dims, _ = R.forward_raw(*[t.detach() for t in leaves], None, cam_t, cfg)
+    pairs_dev = torch.zeros(1, dtype=torch.int64, device=device)
+    import ctypes
+    B.check(B.load().fgs_count_pairs(ctypes.byref(dims), ctypes.c_void_p(saved.data_ptr()),
+                                     ctypes.c_void_p(pairs_dev.data_ptr()),
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "fgs_count_pairs")
+    st = R.inspect_saved(saved, dims)
+    D_local = int(st["counters"][0].item())
+    pairs_local = int(pairs_dev.item())
+    del saved, st
+
+    B.stage_timing_enable(True)
+    B.stage_timing_read()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stage = B.stage_timing_read()
+    B.stage_timing_enable(False)
+
+    tot = torch.tensor([elapsed, float(pairs_local)], dtype=torch.float64, device=device)
+    if dist is not None:
+        tmax = tot[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        psum = tot[1:].clone()
+        dist.all_reduce(psum, op=dist.ReduceOp.SUM)
+        elapsed, pairs_all = float(tmax.item()), float(psum.item())
+    else:
+        pairs_all = float(pairs_local)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = pairs_all / (elapsed / args.steps)
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (rank 0's launches, hipEvent-timed in the library
+        # on the stream the kernels run on, over the timed region) ----
+        HW = S * S
+        alg_bytes = {  # ALGORITHMIC bytes per launch (DESIGN.md "Kernels"), B images per launch
+            "composite_fwd": per_gpu * (40 * HW) + 52 * D_local,
+            "composite_bwd": per_gpu * (36 * HW) + (52 + 40) * D_local + per_gpu * N * 40,
+        }
+        alg_flops = {"composite_fwd": 23.0 * pairs_local, "composite_bwd": 60.0 * pairs_local}
+        avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in stage.items()}
+        dom = max(alg_bytes, key=lambda k: avg_ms.get(k, 0.0))
+        dur = avg_ms[dom] * 1e-3
+        achieved = alg_bytes[dom] / dur / 1e9 if dur > 0 else 0.0
+        roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(avg_ms[dom], 4), "algorithmic_bytes_per_launch": int(alg_bytes[dom]),
+                    "valu": {"achieved_tflops": round(alg_flops[dom] / dur / 1e12, 3) if dur > 0 else 0.0,
+                             "peak_tflops": FP32_VECTOR_PEAK_TF,
+                             "frac": round(alg_flops[dom] / dur / 1e12 / FP32_VECTOR_PEAK_TF, 5) if dur > 0 else 0.0,
+                             "note": "composite is VALU/transcendental-bound (SURVEY 8d); flop model 23/60 per pair"},
+                    "stage_avg_ms": {k: round(v, 4) for k, v in avg_ms.items()}}
+        cpu_baseline = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import fgs_oracle as orc
+            ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+            arrs = [t[0].detach().cpu().numpy() for t in leaves]
+            tc = time.perf_counter()
+            P1, _, _ = orc.render_fwd_bwd_timed(*arrs, ocam, gI[0].cpu().numpy(), gD[0].cpu().numpy())
+            tcpu = time.perf_counter() - tc
+            cpu_baseline = {"value": round(P1 / tcpu, 1), "unit": "Gaussian-pixels/s", "cores": 1, "kind": "port",
+                            "sample": f"image 0 of the batch ({N} Gaussians @ {S}x{S}, {P1} pairs), "
+                                      f"fwd+bwd in {tcpu:.2f} s, scalar C restatement (oracle/fgs_oracle.c)",
+                            "host_cpus": os.cpu_count()}
+        line = {
+            "metric": "composited Gaussian-pixels/sec + train-step ms, 512^2 render",
+            "value": value, "unit": "Gaussian-pixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE {args.workload}: {N} Gaussians, {S}x{S}, {per_gpu} images/GPU "
+                                   f"({per_gpu * world} global), create_dummy_saag distribution, rasterizer fwd+bwd"
+                                   + (", + RCCL all-reduce of the 2.7 MB decoder-grad bucket" if world > 1 else ""),
+                       "gaussians": N, "resolution": S, "images_per_gpu": per_gpu, "global_batch": per_gpu * world,
+                       "pairs_per_step": int(pairs_all), "tile_duplicates_rank0": D_local,
+                       "parallelism": f"image-wise dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""In-tree build of libfgs_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+
+    python -m fresnel_amd.build [--force] [--verbose]
+
+The shared library lands in fresnel_amd/_lib/ (git-ignored, shipped to the GPU box by gpurun).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "_lib")
+OBJ_DIR = os.path.join(HERE, "_lib", "obj")
+LIB = os.path.join(OUT_DIR, "libfgs_hip.so")
+
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+          "-fno-gpu-rdc"]
+# per-file extra flags.  fgs_project.hip carries the "canonical fp32" contract: no FMA
+# contraction, IEEE divide/sqrt, so integer decisions match the CPU oracle bit for bit.
+SOURCES = {
+    "fgs_api.hip": [],
+    "fgs_project.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
+    "fgs_sort.hip": [],
+    "fgs_bin.hip": [],
+    "fgs_composite.hip": ["-ffast-math", "-fno-finite-math-only"],
+    "fgs_asm.hip": [],
+}
+LINK_LIBS = ["-lhipfft"]
+
+
+def _newer(src, dst):
+    return not os.path.exists(dst) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "fgs.h"))
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    objs, rebuilt = [], False
+    for name, extra in SOURCES.items():
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(OBJ_DIR, name.replace(".hip", ".o"))
+        if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_time:
+            cmd = [hipcc] + COMMON + extra + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+        objs.append(obj)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + LINK_LIBS
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -1,0 +1,227 @@
+// C ABI of libfgs_hip.so (include/fgs.h): plan/layout computation and stage orchestration.
+// Nothing here allocates device memory or synchronises; every call enqueues on the caller's
+// stream (graph-capturable, Guideline 9 of the CDNA HIP guide).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "fgs_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void fgs_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- per-stage event timers -------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct StageRec { int stage; hipEvent_t a, b; };
+std::mutex g_tm;
+bool g_timing = false;
+std::vector<StageRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_open[FGS_NUM_STAGES];
+hipEvent_t take_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+void fgs_stage_begin(int stage, hipStream_t st) {
+    if (!g_timing) return;
+    std::lock_guard<std::mutex> lk(g_tm);
+    hipEvent_t e = take_event();
+    if (!e) return;
+    (void)hipEventRecord(e, st);
+    g_open[stage] = e;
+}
+
+void fgs_stage_end(int stage, hipStream_t st) {
+    if (!g_timing) return;
+    std::lock_guard<std::mutex> lk(g_tm);
+    if (!g_open[stage]) return;
+    hipEvent_t e = take_event();
+    if (!e) return;
+    (void)hipEventRecord(e, st);
+    g_recs.push_back({stage, g_open[stage], e});
+    g_open[stage] = nullptr;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int fgs_make_plan(const FgsDims *d, FgsPlan *p) {
+    if (!d || !p) { fgs_set_error("null dims"); return FGS_EINVAL; }
+    if (d->batch < 1 || d->num_gaussians < 1 || d->width < 1 || d->height < 1 || d->width > 32768 ||
+        d->height > 32768 || !(d->max_radius > 0.0f) || (d->num_cameras != 1 && d->num_cameras != d->batch)) {
+        fgs_set_error("invalid dims: B=%d N=%d W=%d H=%d max_radius=%g num_cameras=%d", d->batch,
+                      d->num_gaussians, d->width, d->height, (double)d->max_radius, d->num_cameras);
+        return FGS_EINVAL;
+    }
+    const size_t B = d->batch, N = d->num_gaussians;
+    if (B * N >= (1ull << 31)) { fgs_set_error("B*N too large"); return FGS_EINVAL; }
+    memset(p, 0, sizeof(*p));
+    p->d = *d;
+    const int tx = (d->width + FGS_TILE - 1) / FGS_TILE, ty = (d->height + FGS_TILE - 1) / FGS_TILE;
+    p->tiles = tx * ty;
+    // bbox width <= floor(2r)+2 pixels -> spans at most floor((2r+1)/16)+2 tile columns
+    int span = (int)((2.0 * (double)d->max_radius + 1.0) / FGS_TILE) + 2;
+    if (span > tx) span = tx;
+    int spany = (int)((2.0 * (double)d->max_radius + 1.0) / FGS_TILE) + 2;
+    if (spany > ty) spany = ty;
+    p->tiles_per_gauss = span * spany;
+    const size_t dcap = B * N * (size_t)p->tiles_per_gauss;
+    if (dcap >= (1ull << 32) - 256) { fgs_set_error("duplicate capacity exceeds 2^32"); return FGS_EINVAL; }
+    uint32_t bits = 0;
+    while ((1ull << bits) < B * (size_t)p->tiles) ++bits;
+    p->tile_key_bits = bits;
+
+    FgsSavedLayout &L = p->L;
+    size_t o = 0;
+    L.rec = o; o = align256(o + B * N * FGS_REC_FLOATS * 4);
+    L.depth_key = o; o = align256(o + B * N * 4);
+    L.tile_count = o; o = align256(o + B * N * 4);
+    L.order = o; o = align256(o + B * N * 4);
+    L.counters = o; o = align256(o + 16 * 4);
+    L.ranges = o; o = align256(o + B * p->tiles * 2 * 4);
+    L.dup_ids = o; o = align256(o + dcap * 4);
+    L.pix_state = o; o = align256(o + B * 6 * (size_t)d->width * d->height * 4);
+    L.total_bytes = o;
+    L.dup_capacity = dcap;
+    L.tiles_x = tx; L.tiles_y = ty;
+
+    const size_t nsort = dcap > B * N ? dcap : B * N;
+    const size_t nblk = (B * N + 255) / 256;
+    size_t hist = fgs_radix_hist_bytes((uint32_t)N, (uint32_t)B);
+    const size_t hist2 = fgs_radix_hist_bytes((uint32_t)dcap, 1);
+    if (hist2 > hist) hist = hist2;
+    o = 0;
+    p->s_keys0 = o; o = align256(o + nsort * 4);
+    p->s_keys1 = o; o = align256(o + nsort * 4);
+    p->s_vals0 = o; o = align256(o + nsort * 4);
+    p->s_vals1 = o; o = align256(o + nsort * 4);
+    p->s_hist = o; o = align256(o + hist);
+    p->s_bsum = o; o = align256(o + nblk * 4);
+    p->s_gconic = o; o = align256(o + B * N * 3 * 4);
+    p->s_gmean = o; o = align256(o + B * N * 2 * 4);
+    p->s_gdepth = o; o = align256(o + B * N * 4);
+    p->s_total = o;
+    return FGS_OK;
+}
+
+extern "C" {
+
+const char *fgs_last_error(void) { return g_err; }
+
+int fgs_stage_timing_enable(int enable) {
+    std::lock_guard<std::mutex> lk(g_tm);
+    g_timing = enable != 0;
+    return FGS_OK;
+}
+
+int fgs_stage_timing_read(float *ms, int32_t *count) {
+    std::lock_guard<std::mutex> lk(g_tm);
+    for (const StageRec &r : g_recs) {
+        float t = 0.0f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            if (ms) ms[r.stage] += t;
+            if (count) count[r.stage] += 1;
+        }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return FGS_OK;
+}
+const char *fgs_version(void) { return "fgs-hip 0.1 (gfx950)"; }
+
+int fgs_workspace_bytes(const FgsDims *dims, size_t *saved_bytes, size_t *scratch_bytes) {
+    FgsPlan p;
+    const int rc = fgs_make_plan(dims, &p);
+    if (rc) return rc;
+    if (saved_bytes) *saved_bytes = p.L.total_bytes;
+    if (scratch_bytes) *scratch_bytes = p.s_total;
+    return FGS_OK;
+}
+
+int fgs_saved_layout(const FgsDims *dims, FgsSavedLayout *layout) {
+    FgsPlan p;
+    const int rc = fgs_make_plan(dims, &p);
+    if (rc) return rc;
+    if (!layout) { fgs_set_error("null layout"); return FGS_EINVAL; }
+    *layout = p.L;
+    return FGS_OK;
+}
+
+int fgs_forward(const FgsDims *dims, const float *cameras, const float *pos, const float *scale,
+                const float *quat, const float *color, const float *opacity, const float *phase,
+                float *out_rgb, float *out_depth, void *saved, void *scratch, void *stream) {
+    FgsPlan p;
+    int rc = fgs_make_plan(dims, &p);
+    if (rc) return rc;
+    if (!cameras || !pos || !scale || !quat || !color || !opacity || !out_rgb || !out_depth || !saved || !scratch) {
+        fgs_set_error("fgs_forward: null pointer argument");
+        return FGS_EINVAL;
+    }
+    if (p.d.use_phase && !phase) { fgs_set_error("fgs_forward: use_phase set but phase is NULL"); return FGS_EINVAL; }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char *sv = reinterpret_cast<char *>(saved), *sc = reinterpret_cast<char *>(scratch);
+    fgs_stage_begin(ST_PROJECT, st);
+    if ((rc = fgs_launch_project(p, cameras, pos, scale, quat, color, opacity, sv, st))) return rc;
+    fgs_stage_end(ST_PROJECT, st);
+    if ((rc = fgs_launch_binning(p, sv, sc, st))) return rc;
+    fgs_stage_begin(ST_COMPOSITE_FWD, st);
+    if ((rc = fgs_launch_composite_fwd(p, phase, sv, out_rgb, out_depth, st))) return rc;
+    fgs_stage_end(ST_COMPOSITE_FWD, st);
+    return FGS_OK;
+}
+
+int fgs_backward(const FgsDims *dims, const float *cameras, const float *pos, const float *scale,
+                 const float *quat, const float *color, const float *opacity, const float *phase,
+                 const void *saved, void *scratch, const float *g_rgb, const float *g_depth,
+                 float *g_pos, float *g_scale, float *g_quat, float *g_color, float *g_opacity,
+                 float *g_phase, void *stream) {
+    FgsPlan p;
+    int rc = fgs_make_plan(dims, &p);
+    if (rc) return rc;
+    if (!cameras || !pos || !scale || !quat || !color || !opacity || !saved || !scratch || !g_rgb || !g_depth ||
+        !g_pos || !g_scale || !g_quat || !g_color || !g_opacity) {
+        fgs_set_error("fgs_backward: null pointer argument");
+        return FGS_EINVAL;
+    }
+    if (p.d.use_phase && (!phase || !g_phase)) {
+        fgs_set_error("fgs_backward: use_phase set but phase/g_phase is NULL");
+        return FGS_EINVAL;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const char *sv = reinterpret_cast<const char *>(saved);
+    char *sc = reinterpret_cast<char *>(scratch);
+    fgs_stage_begin(ST_COMPOSITE_BWD, st);
+    if ((rc = fgs_launch_composite_bwd(p, color, phase, sv, sc, g_rgb, g_depth, g_color, g_opacity, g_phase, st)))
+        return rc;
+    fgs_stage_end(ST_COMPOSITE_BWD, st);
+    fgs_stage_begin(ST_PROJECT_BWD, st);
+    if ((rc = fgs_launch_project_bwd(p, cameras, pos, scale, quat, sv,
+                                     reinterpret_cast<const float *>(sc + p.s_gmean),
+                                     reinterpret_cast<const float *>(sc + p.s_gconic),
+                                     reinterpret_cast<const float *>(sc + p.s_gdepth), g_pos, g_scale, g_quat, st)))
+        return rc;
+    fgs_stage_end(ST_PROJECT_BWD, st);
+    return FGS_OK;
+}
+
+int fgs_count_pairs(const FgsDims *dims, const void *saved, uint64_t *out_pairs, void *stream) {
+    FgsPlan p;
+    const int rc = fgs_make_plan(dims, &p);
+    if (rc) return rc;
+    if (!saved || !out_pairs) { fgs_set_error("fgs_count_pairs: null pointer"); return FGS_EINVAL; }
+    return fgs_launch_count_pairs(p, reinterpret_cast<const char *>(saved), out_pairs,
+                                  reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

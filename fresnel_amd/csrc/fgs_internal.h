@@ -1,0 +1,84 @@
+// Internal declarations shared by the HIP translation units of libfgs_hip.so.
+// gfx950 (MI355X, CDNA4) only: wave64, 160 KiB LDS/CU, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fgs.h"
+
+#define FGS_REC_FLOATS 12
+#define FGS_WAVE 64
+
+// record field indices (saved.rec)
+enum { R_U = 0, R_V, R_CA, R_CBC, R_CD, R_OP, R_CR, R_CG, R_CB, R_DEPTH, R_BBX, R_BBY };
+
+struct FgsPlan {
+    FgsDims d;
+    FgsSavedLayout L;
+    int32_t tiles;            // tiles per image
+    int32_t tiles_per_gauss;  // worst-case tiles touched by one Gaussian
+    uint32_t tile_key_bits;   // bits of (image*T + tile)
+    // scratch layout (bytes)
+    size_t s_total;
+    size_t s_keys0, s_keys1;  // uint32 [max(B*N, Dcap)] radix ping/pong keys
+    size_t s_vals0, s_vals1;  // uint32 [max(B*N, Dcap)] radix ping/pong payloads (vals of the final pass land in saved.dup_ids)
+    size_t s_hist;            // uint32 radix histograms
+    size_t s_bsum;            // uint32 block sums for the duplicate-offset scan
+    size_t s_gconic;          // float [B][N][3] composite -> projection gradient hand-off
+    size_t s_gmean;           // float [B][N][2]
+    size_t s_gdepth;          // float [B][N]
+};
+
+int fgs_make_plan(const FgsDims *dims, FgsPlan *plan);
+void fgs_set_error(const char *fmt, ...);
+
+#define FGS_LAUNCH_CHECK(what)                                              \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            fgs_set_error("%s: %s", what, hipGetErrorString(e__));          \
+            return FGS_ELAUNCH;                                             \
+        }                                                                   \
+    } while (0)
+
+enum FgsStage { ST_PROJECT = 0, ST_DEPTH_SORT, ST_DUP_EMIT, ST_TILE_SORT, ST_TILE_RANGES, ST_COMPOSITE_FWD,
+                ST_COMPOSITE_BWD, ST_PROJECT_BWD };
+void fgs_stage_begin(int stage, hipStream_t st);  // no-ops unless fgs_stage_timing_enable(1)
+void fgs_stage_end(int stage, hipStream_t st);
+
+// ---- stage launchers (each enqueues on `st`, returns FGS_OK / FGS_ELAUNCH) ----
+int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
+                       const float *quat, const float *color, const float *opacity, char *saved,
+                       hipStream_t st);
+int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
+                           const float *quat, const char *saved, const float *g_mean, const float *g_conic,
+                           const float *g_depth, float *g_pos, float *g_scale, float *g_quat, hipStream_t st);
+
+// Stable LSD radix sort of (key,val) uint32 pairs over `num_segs` independent segments.
+// Segment s covers elements [s*seg_stride, s*seg_stride + len) with len = seg_len (host) or
+// *seg_len_dev (device, single segment).  Sorts bits [0, key_bits).  The sorted result is
+// left in (keys_out, vals_out); in/alt buffers are clobbered.
+int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt,
+                          uint32_t *vals_final /*nullable: where the last pass writes vals*/,
+                          uint32_t **keys_sorted /*out: which buffer holds sorted keys*/,
+                          uint32_t **vals_sorted, uint32_t seg_len, const uint32_t *seg_len_dev,
+                          uint32_t seg_capacity, uint32_t seg_stride, uint32_t num_segs, uint32_t key_bits,
+                          uint32_t *hist, hipStream_t st);
+size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs);
+
+int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t st);
+int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, float *out_rgb,
+                             float *out_depth, hipStream_t st);
+int fgs_launch_composite_bwd(const FgsPlan &p, const float *color, const float *phase, const char *saved,
+                             char *scratch, const float *g_rgb, const float *g_depth, float *g_color,
+                             float *g_opacity, float *g_phase, hipStream_t st);
+int fgs_launch_count_pairs(const FgsPlan &p, const char *saved, uint64_t *out, hipStream_t st);
+
+// ---- small device helpers ----
+__device__ __forceinline__ uint32_t fgs_lane() { return threadIdx.x & 63u; }
+
+// order-preserving map float -> uint32 (ascending), -0.0 folded into +0.0
+__device__ __forceinline__ uint32_t fgs_float_key(float f) {
+    f = f + 0.0f;
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}

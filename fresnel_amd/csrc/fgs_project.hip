@@ -1,0 +1,288 @@
+// Stage 1: 3D -> 2D projection, 2D covariance, radius, visibility, fp64 bbox, conic.
+// Replaces DR:98-120, DR:123-195, DR:452-487, DR:541-543, DR:578-579, DR:594-597 of the
+// reference (scripts/models/differentiable_renderer.py) for a whole batch in one launch.
+//
+// HBM-bound streaming kernel: one thread per Gaussian, 56 B in (pos/scale/quat/color/opacity
+// as the reference's AoS tensors -- consecutive lanes read consecutive 12/16-B rows, so each
+// wave's loads are fully coalesced), 56 B out (48-B record + depth key + tile count).
+//
+// "Canonical fp32": every operation below that feeds an INTEGER decision (visibility,
+// bbox, depth key) is individually rounded, in the association order documented in
+// DESIGN.md -- this file is compiled with -ffp-contract=off and uses IEEE division/sqrt,
+// so those decisions are bit-identical to the CPU oracle's.
+#include "fgs_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float clamp_min(float x, float lo) { return x < lo ? lo : x; }  // NaN-propagating
+__device__ __forceinline__ float clamp_max(float x, float hi) { return x > hi ? hi : x; }
+__device__ __forceinline__ float sgnf(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+
+struct Proj {
+    float xc, yc, zc, dep;
+    float w, x, y, z, nrm;   // normalised quaternion + raw norm
+    float Rc[3][3];          // view_rot @ R
+    float M[3][3];           // Rc * diag(s)
+    float S[3][3];           // cov3d
+    float zs, z2, J00, J02, J11, J12;
+    float T0[3], T1[3];
+    float a, b, c, d, u, v;
+};
+
+__device__ __forceinline__ void project_one(const float *__restrict__ V, float fx, float fy, float cx,
+                                            float cy, const float p[3], const float s[3],
+                                            const float q[4], Proj &o) {
+    o.xc = ((V[0] * p[0] + V[1] * p[1]) + V[2] * p[2]) + V[3];
+    o.yc = ((V[4] * p[0] + V[5] * p[1]) + V[6] * p[2]) + V[7];
+    o.zc = ((V[8] * p[0] + V[9] * p[1]) + V[10] * p[2]) + V[11];
+    o.dep = -o.zc;
+    float nrm = __fsqrt_rn(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    o.nrm = nrm;
+    if (nrm < 1e-12f) nrm = 1e-12f;
+    const float w = __fdiv_rn(q[0], nrm), x = __fdiv_rn(q[1], nrm), y = __fdiv_rn(q[2], nrm),
+                z = __fdiv_rn(q[3], nrm);
+    o.w = w; o.x = x; o.y = y; o.z = z;
+    float R[3][3];
+    R[0][0] = (1.0f - (2.0f * y) * y) - (2.0f * z) * z;
+    R[0][1] = (2.0f * x) * y - (2.0f * w) * z;
+    R[0][2] = (2.0f * x) * z + (2.0f * w) * y;
+    R[1][0] = (2.0f * x) * y + (2.0f * w) * z;
+    R[1][1] = (1.0f - (2.0f * x) * x) - (2.0f * z) * z;
+    R[1][2] = (2.0f * y) * z - (2.0f * w) * x;
+    R[2][0] = (2.0f * x) * z - (2.0f * w) * y;
+    R[2][1] = (2.0f * y) * z + (2.0f * w) * x;
+    R[2][2] = (1.0f - (2.0f * x) * x) - (2.0f * y) * y;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            o.Rc[i][j] = (V[4 * i] * R[0][j] + V[4 * i + 1] * R[1][j]) + V[4 * i + 2] * R[2][j];
+            o.M[i][j] = o.Rc[i][j] * s[j];
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            o.S[i][j] = (o.M[i][0] * o.M[j][0] + o.M[i][1] * o.M[j][1]) + o.M[i][2] * o.M[j][2];
+    o.zs = clamp_min(fabsf(o.zc), 0.01f) * sgnf(o.zc + 1e-8f);
+    o.z2 = o.zs * o.zs;
+    o.J00 = __fdiv_rn(fx, -o.zs);
+    o.J02 = __fdiv_rn(fx * o.xc, o.z2);
+    o.J11 = __fdiv_rn(fy, o.zs);
+    o.J12 = __fdiv_rn(fy * o.yc, o.z2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        o.T0[j] = o.J00 * o.S[0][j] + o.J02 * o.S[2][j];
+        o.T1[j] = o.J11 * o.S[1][j] + o.J12 * o.S[2][j];
+    }
+    o.a = o.T0[0] * o.J00 + o.T0[2] * o.J02;
+    o.b = o.T0[1] * o.J11 + o.T0[2] * o.J12;
+    o.c = o.T1[0] * o.J00 + o.T1[2] * o.J02;
+    o.d = o.T1[1] * o.J11 + o.T1[2] * o.J12;
+    o.u = __fdiv_rn(fx * o.xc, -o.zs) + cx;
+    o.v = __fdiv_rn(fy * (-o.yc), -o.zs) + cy;
+}
+
+__global__ __launch_bounds__(256) void k_project(
+    int32_t total, int32_t N, int32_t W, int32_t H, int32_t num_cameras, float max_radius,
+    const float *__restrict__ cams, const float *__restrict__ pos, const float *__restrict__ scale,
+    const float *__restrict__ quat, const float *__restrict__ color, const float *__restrict__ opacity,
+    float *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ tile_count) {
+    const int32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int32_t b = idx / N;
+    const float *__restrict__ cam = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
+    const float p[3] = {pos[3 * idx], pos[3 * idx + 1], pos[3 * idx + 2]};
+    const float s[3] = {scale[3 * idx], scale[3 * idx + 1], scale[3 * idx + 2]};
+    const float4 q4 = reinterpret_cast<const float4 *>(quat)[idx];
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    const float fx = cam[16], fy = cam[17], cx = cam[18], cy = cam[19], nearp = cam[20], farp = cam[21];
+    Proj o;
+    project_one(cam, fx, fy, cx, cy, p, s, q, o);
+
+    // radius, DR:471-485
+    const float tr = o.a + o.d;
+    float det = o.a * o.d - o.b * o.c;
+    det = clamp_min(det, 1e-6f);
+    const float disc = clamp_min(tr * tr - 4.0f * det, 0.0f);
+    const float lam = __fdiv_rn(tr + __fsqrt_rn(disc), 2.0f);
+    float r = 3.0f * __fsqrt_rn(clamp_min(lam, 1e-6f));
+    r = clamp_max(r, max_radius);
+    // visibility, DR:541-543
+    const bool vis = (o.dep > nearp) && (o.dep < farp) && (o.u + r > 0.0f) && (o.u - r < (float)W) &&
+                     (o.v + r > 0.0f) && (o.v - r < (float)H);
+    // bbox in fp64, DR:594-597
+    int32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    if (vis) {
+        const double ud = (double)o.u, vd = (double)o.v, rd = (double)r;
+        double e;
+        e = trunc(ud - rd); x0 = e < 0.0 ? 0 : (e > (double)W ? W : (int32_t)e);
+        e = trunc(ud + rd) + 1.0; x1 = e > (double)W ? W : (e < 0.0 ? 0 : (int32_t)e);
+        e = trunc(vd - rd); y0 = e < 0.0 ? 0 : (e > (double)H ? H : (int32_t)e);
+        e = trunc(vd + rd) + 1.0; y1 = e > (double)H ? H : (e < 0.0 ? 0 : (int32_t)e);
+    }
+    uint32_t ntiles = 0;
+    if (vis && x0 < x1 && y0 < y1)
+        ntiles = (uint32_t)(((x1 - 1) / FGS_TILE - x0 / FGS_TILE + 1) * ((y1 - 1) / FGS_TILE - y0 / FGS_TILE + 1));
+    // inverse of cov + 1e-4 I, DR:578-579 (closed form)
+    const float ar = o.a + 1e-4f, dr = o.d + 1e-4f;
+    const float detr = ar * dr - o.b * o.c;
+    const float ia = __fdiv_rn(dr, detr);
+    const float ibc = __fdiv_rn(-o.b, detr) + __fdiv_rn(-o.c, detr);
+    const float id = __fdiv_rn(ar, detr);
+
+    float4 *out = reinterpret_cast<float4 *>(rec + (size_t)idx * FGS_REC_FLOATS);
+    out[0] = make_float4(o.u, o.v, ia, ibc);
+    out[1] = make_float4(id, opacity[idx], color[3 * idx], color[3 * idx + 1]);
+    out[2] = make_float4(color[3 * idx + 2], o.dep, __uint_as_float((uint32_t)x0 | ((uint32_t)x1 << 16)),
+                         __uint_as_float((uint32_t)y0 | ((uint32_t)y1 << 16)));
+    depth_key[idx] = vis ? fgs_float_key(o.dep) : 0xFFFFFFFFu;
+    tile_count[idx] = ntiles;
+}
+
+// Projection backward (autograd of DR:98-195 + DR:578-579).  One thread per Gaussian;
+// recomputes the forward intermediates from the inputs (cheaper than saving 60 floats).
+__global__ __launch_bounds__(256) void k_project_bwd(
+    int32_t total, int32_t N, int32_t num_cameras, const float *__restrict__ cams,
+    const float *__restrict__ pos, const float *__restrict__ scale, const float *__restrict__ quat,
+    const uint32_t *__restrict__ depth_key, const float *__restrict__ g_mean,
+    const float *__restrict__ g_conic, const float *__restrict__ g_depth, float *__restrict__ g_pos,
+    float *__restrict__ g_scale, float *__restrict__ g_quat) {
+    const int32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    float gp[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0};
+    if (depth_key[idx] != 0xFFFFFFFFu) {
+        const int32_t b = idx / N;
+        const float *__restrict__ V = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
+        const float p[3] = {pos[3 * idx], pos[3 * idx + 1], pos[3 * idx + 2]};
+        const float s[3] = {scale[3 * idx], scale[3 * idx + 1], scale[3 * idx + 2]};
+        const float4 q4 = reinterpret_cast<const float4 *>(quat)[idx];
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float fx = V[16], fy = V[17];
+        Proj o;
+        project_one(V, fx, fy, V[18], V[19], p, s, q, o);
+        const float ar = o.a + 1e-4f, dr = o.d + 1e-4f;
+        const float rdet = 1.0f / (ar * dr - o.b * o.c);
+        const float Y[2][2] = {{dr * rdet, -o.b * rdet}, {-o.c * rdet, ar * rdet}};
+        const float GY[2][2] = {{g_conic[3 * idx], g_conic[3 * idx + 1]}, {g_conic[3 * idx + 1], g_conic[3 * idx + 2]}};
+        float tmp[2][2], G2[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tmp[i][j] = Y[0][i] * GY[0][j] + Y[1][i] * GY[1][j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) G2[i][j] = -(tmp[i][0] * Y[j][0] + tmp[i][1] * Y[j][1]);
+        const float J[2][3] = {{o.J00, 0.0f, o.J02}, {0.0f, o.J11, o.J12}};
+        // dL/dSigma = J^T G2 J
+        float GS[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) acc += J[a2][i] * G2[a2][b2] * J[b2][j];
+                GS[i][j] = acc;
+            }
+        // dL/dJ = G2 (J S^T) + G2^T (J S)
+        float JS[2][3], JSt[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                JS[i][j] = J[i][0] * o.S[0][j] + J[i][1] * o.S[1][j] + J[i][2] * o.S[2][j];
+                JSt[i][j] = J[i][0] * o.S[j][0] + J[i][1] * o.S[j][1] + J[i][2] * o.S[j][2];
+            }
+        float GJ[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                GJ[i][j] = (G2[i][0] * JSt[0][j] + G2[i][1] * JSt[1][j]) + (G2[0][i] * JS[0][j] + G2[1][i] * JS[1][j]);
+        const float gu = g_mean[2 * idx], gv = g_mean[2 * idx + 1];
+        const float zs = o.zs, z2 = o.z2, z3 = o.z2 * o.zs;
+        const float gxc = GJ[0][2] * fx / z2 + gu * (-fx / zs);
+        const float gyc = GJ[1][2] * fy / z2 + gv * (fy / zs);
+        const float gzs = GJ[0][0] * fx / z2 + GJ[0][2] * (-2.0f * fx * o.xc / z3) + GJ[1][1] * (-fy / z2) +
+                          GJ[1][2] * (-2.0f * fy * o.yc / z3) + gu * (fx * o.xc / z2) + gv * (-fy * o.yc / z2);
+        const float dzs = (fabsf(o.zc) >= 0.01f ? sgnf(o.zc) : 0.0f) * sgnf(o.zc + 1e-8f);
+        const float gpc[3] = {gxc, gyc, gzs * dzs - g_depth[idx]};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gp[j] = V[j] * gpc[0] + V[4 + j] * gpc[1] + V[8 + j] * gpc[2];
+        // Sigma = M M^T -> dM = (GS + GS^T) M ; M = Rc diag(s)
+        float GRc[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float gm = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) gm += (GS[i][k] + GS[k][i]) * o.M[k][j];
+                acc += gm * o.Rc[i][j];
+                GRc[i][j] = gm * s[j];
+            }
+            gs[j] = acc;
+        }
+        float GR[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) GR[i][j] = V[i] * GRc[0][j] + V[4 + i] * GRc[1][j] + V[8 + i] * GRc[2][j];
+        const float w = o.w, x = o.x, y = o.y, z = o.z;
+        float gh[4];
+        gh[0] = -2 * z * GR[0][1] + 2 * y * GR[0][2] + 2 * z * GR[1][0] - 2 * x * GR[1][2] - 2 * y * GR[2][0] + 2 * x * GR[2][1];
+        gh[1] = 2 * y * GR[0][1] + 2 * z * GR[0][2] + 2 * y * GR[1][0] - 4 * x * GR[1][1] - 2 * w * GR[1][2] + 2 * z * GR[2][0] + 2 * w * GR[2][1] - 4 * x * GR[2][2];
+        gh[2] = -4 * y * GR[0][0] + 2 * x * GR[0][1] + 2 * w * GR[0][2] + 2 * x * GR[1][0] + 2 * z * GR[1][2] - 2 * w * GR[2][0] + 2 * z * GR[2][1] - 4 * y * GR[2][2];
+        gh[3] = -4 * z * GR[0][0] - 2 * w * GR[0][1] + 2 * x * GR[0][2] + 2 * w * GR[1][0] - 4 * z * GR[1][1] + 2 * y * GR[1][2] + 2 * x * GR[2][0] + 2 * y * GR[2][1];
+        const float qh[4] = {w, x, y, z};
+        if (o.nrm >= 1e-12f) {
+            const float dot = qh[0] * gh[0] + qh[1] * gh[1] + qh[2] * gh[2] + qh[3] * gh[3];
+            const float rn = 1.0f / o.nrm;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gq[i] = (gh[i] - qh[i] * dot) * rn;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gq[i] = gh[i] * 1e12f;
+        }
+    }
+    g_pos[3 * idx] = gp[0]; g_pos[3 * idx + 1] = gp[1]; g_pos[3 * idx + 2] = gp[2];
+    g_scale[3 * idx] = gs[0]; g_scale[3 * idx + 1] = gs[1]; g_scale[3 * idx + 2] = gs[2];
+    reinterpret_cast<float4 *>(g_quat)[idx] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+}
+
+}  // namespace
+
+int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
+                       const float *quat, const float *color, const float *opacity, char *saved,
+                       hipStream_t st) {
+    const int32_t total = p.d.batch * p.d.num_gaussians;
+    const int grid = (total + 255) / 256;
+    hipLaunchKernelGGL(k_project, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians, p.d.width,
+                       p.d.height, p.d.num_cameras, p.d.max_radius, cams, pos, scale, quat, color, opacity,
+                       reinterpret_cast<float *>(saved + p.L.rec),
+                       reinterpret_cast<uint32_t *>(saved + p.L.depth_key),
+                       reinterpret_cast<uint32_t *>(saved + p.L.tile_count));
+    FGS_LAUNCH_CHECK("k_project");
+    return FGS_OK;
+}
+
+int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
+                           const float *quat, const char *saved, const float *g_mean, const float *g_conic,
+                           const float *g_depth, float *g_pos, float *g_scale, float *g_quat,
+                           hipStream_t st) {
+    const int32_t total = p.d.batch * p.d.num_gaussians;
+    const int grid = (total + 255) / 256;
+    hipLaunchKernelGGL(k_project_bwd, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
+                       p.d.num_cameras, cams, pos, scale, quat,
+                       reinterpret_cast<const uint32_t *>(saved + p.L.depth_key), g_mean, g_conic, g_depth,
+                       g_pos, g_scale, g_quat);
+    FGS_LAUNCH_CHECK("k_project_bwd");
+    return FGS_OK;
+}

@@ -1,0 +1,201 @@
+// Stable LSD radix sort (8-bit digits) of uint32 (key, payload) pairs -- the build's own
+// design; the reference has no per-tile sort and its Vulkan GPURadixSort
+// (src/core/compute/radix_sort.cpp:172-242) scatters through atomicAdd and is NOT stable.
+//
+// Used twice per forward:
+//   (1) depth order: B independent segments of N keys = order-preserving depth bits
+//       (replaces torch.argsort(depths), DR:527, with the canonical stable order of
+//       depth ascending, ties by original index);
+//   (2) tile binning: ONE segment of D duplicates (D known only on the device), key =
+//       image*T + tile.  Duplicates are emitted in depth order, so stability alone keeps
+//       every tile's list depth-sorted and only ceil(log2(B*T)/8) passes are needed.
+//
+// Per pass: upsweep (per-block digit histogram) -> per-digit wave scan -> downsweep (each
+// block re-walks its contiguous range in rounds of 256 keys; a key's rank inside the round
+// comes from wave64 ballots: 8 ballots give the mask of lanes holding the same digit,
+// popcount below the lane gives the stable rank -- no atomics, no order dependence).
+// HBM-bound: 8 B read in upsweep+downsweep and 8 B written per element per pass.
+#include "fgs_internal.h"
+
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / 64;
+
+struct SegInfo {
+    uint32_t begin, end;  // this block's element range (absolute indices)
+};
+
+__device__ __forceinline__ SegInfo block_range(uint32_t seg_len, const uint32_t *seg_len_dev,
+                                               uint32_t seg_capacity, uint32_t seg_stride) {
+    uint32_t len = seg_len_dev ? *seg_len_dev : seg_len;
+    if (len > seg_capacity) len = seg_capacity;
+    const uint32_t bps = gridDim.x;
+    uint32_t per = (len + bps - 1) / bps;
+    per = (per + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
+    const uint32_t seg0 = blockIdx.y * seg_stride;
+    uint32_t b = blockIdx.x * per, e = b + per;
+    if (b > len) b = len;
+    if (e > len) e = len;
+    return {seg0 + b, seg0 + e};
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(
+    const uint32_t *__restrict__ keys, uint32_t seg_len, const uint32_t *__restrict__ seg_len_dev,
+    uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const SegInfo r = block_range(seg_len, seg_len_dev, seg_capacity, seg_stride);
+    for (uint32_t i = r.begin + threadIdx.x; i < r.end; i += RS_THREADS)
+        atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    // layout: hist[(seg*256 + digit) * bps + blk]
+    hist[((size_t)blockIdx.y * 256 + threadIdx.x) * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// One wave per (segment, digit): exclusive scan along the block axis, digit total to dtot.
+__global__ __launch_bounds__(256) void k_radix_scan(uint32_t *__restrict__ hist, uint32_t *__restrict__ dtot,
+                                                    uint32_t bps, uint32_t num_rows) {
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);  // seg*256 + digit
+    if (row >= num_rows) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *p = hist + (size_t)row * bps;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < bps; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t v = i < bps ? p[i] : 0u;
+        uint32_t s = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(s, o, 64);
+            if ((int)lane >= o) s += t;
+        }
+        if (i < bps) p[i] = carry + s - v;
+        carry += __shfl(s, 63, 64);
+    }
+    if (lane == 0) dtot[row] = carry;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t seg_len,
+    const uint32_t *__restrict__ seg_len_dev, uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift,
+    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ dtot) {
+    __shared__ uint32_t run_off[256];
+    __shared__ uint32_t wcnt[RS_WAVES][256];
+    __shared__ uint32_t scan_tmp[256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const SegInfo r = block_range(seg_len, seg_len_dev, seg_capacity, seg_stride);
+    // exclusive scan of the 256 digit totals of this segment (Hillis-Steele in LDS)
+    {
+        const uint32_t t = dtot[blockIdx.y * 256 + tid];
+        scan_tmp[tid] = t;
+        __syncthreads();
+        uint32_t s = t;
+        for (int o = 1; o < 256; o <<= 1) {
+            const uint32_t add = tid >= (uint32_t)o ? scan_tmp[tid - o] : 0u;
+            __syncthreads();
+            s += add;
+            scan_tmp[tid] = s;
+            __syncthreads();
+        }
+        const uint32_t seg0 = blockIdx.y * seg_stride;
+        run_off[tid] = seg0 + (s - t) + hist[((size_t)blockIdx.y * 256 + tid) * gridDim.x + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) wcnt[w][tid] = 0;
+    }
+    __syncthreads();
+    for (uint32_t base = r.begin; base < r.end; base += RS_THREADS) {
+        const uint32_t i = base + tid;
+        const bool valid = i < r.end;
+        const uint32_t key = valid ? keys_in[i] : 0u;
+        const uint32_t val = valid ? vals_in[i] : 0u;
+        const uint32_t digit = (key >> shift) & 255u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool bset = (digit >> bit) & 1u;
+            const unsigned long long bm = __ballot(valid && bset);
+            m &= bset ? bm : ~bm;
+        }
+        const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wcnt[wave][digit] = __popcll(m);
+        __syncthreads();
+        if (valid) {
+            uint32_t pre = 0;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) pre += (w < (int)wave) ? wcnt[w][digit] : 0u;
+            const uint32_t dst = run_off[digit] + pre + rank;
+            keys_out[dst] = key;
+            vals_out[dst] = val;
+        }
+        __syncthreads();
+        {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) { tot += wcnt[w][tid]; wcnt[w][tid] = 0; }
+            run_off[tid] += tot;
+        }
+        __syncthreads();
+    }
+}
+
+uint32_t blocks_per_seg(uint32_t seg_capacity, uint32_t num_segs) {
+    // aim at >= 4 blocks per CU over the chip, <= 1024 per segment, >= 1024 keys per block
+    uint32_t bps = (seg_capacity + 1023) / 1024;
+    uint32_t cap = 1024;
+    if (num_segs > 1) cap = 64;
+    if (bps > cap) bps = cap;
+    if (bps < 1) bps = 1;
+    return bps;
+}
+
+}  // namespace
+
+size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs) {
+    const size_t bps = blocks_per_seg(seg_capacity, num_segs);
+    return ((size_t)num_segs * 256 * bps + (size_t)num_segs * 256) * sizeof(uint32_t);
+}
+
+int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt,
+                          uint32_t *vals_final, uint32_t **keys_sorted, uint32_t **vals_sorted,
+                          uint32_t seg_len, const uint32_t *seg_len_dev, uint32_t seg_capacity,
+                          uint32_t seg_stride, uint32_t num_segs, uint32_t key_bits, uint32_t *hist,
+                          hipStream_t st) {
+    const uint32_t bps = blocks_per_seg(seg_capacity, num_segs);
+    uint32_t *dtot = hist + (size_t)num_segs * 256 * bps;
+    const uint32_t passes = (key_bits + 7) / 8;
+    uint32_t *kin = keys_in, *vin = vals_in, *kout = keys_alt, *vout = vals_alt;
+    if (passes == 0) {
+        if (vals_final && vals_final != vals_in) {
+            // single possible key: already sorted; move the payload where the caller wants it
+            hipError_t e = hipMemcpyAsync(vals_final, vals_in, (size_t)seg_stride * (num_segs - 1) * 4 + (size_t)seg_capacity * 4,
+                                          hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) { fgs_set_error("radix copy: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
+            vin = vals_final;
+        }
+        *keys_sorted = kin; *vals_sorted = vin;
+        return FGS_OK;
+    }
+    (void)vout;
+    for (uint32_t p = 0; p < passes; ++p) {
+        uint32_t *vdst = (p == passes - 1 && vals_final) ? vals_final : (vin == vals_in ? vals_alt : vals_in);
+        const dim3 grid(bps, num_segs);
+        hipLaunchKernelGGL(k_radix_upsweep, grid, dim3(RS_THREADS), 0, st, kin, seg_len, seg_len_dev,
+                           seg_capacity, seg_stride, p * 8, hist);
+        FGS_LAUNCH_CHECK("k_radix_upsweep");
+        const uint32_t rows = num_segs * 256;
+        hipLaunchKernelGGL(k_radix_scan, dim3((rows + 3) / 4), dim3(256), 0, st, hist, dtot, bps, rows);
+        FGS_LAUNCH_CHECK("k_radix_scan");
+        hipLaunchKernelGGL(k_radix_downsweep, grid, dim3(RS_THREADS), 0, st, kin, vin, kout, vdst, seg_len,
+                           seg_len_dev, seg_capacity, seg_stride, p * 8, hist, dtot);
+        FGS_LAUNCH_CHECK("k_radix_downsweep");
+        uint32_t *t;
+        t = kin; kin = kout; kout = t;
+        vin = vdst;
+    }
+    *keys_sorted = kin;
+    *vals_sorted = vin;
+    return FGS_OK;
+}

@@ -1,0 +1,243 @@
+"""Host-side mirror of the reference renderer interface, backed by hand-written HIP kernels.
+
+Same names, argument meaning and error behaviour as the reference's
+scripts/models/differentiable_renderer.py ("DR"):
+
+    Camera                                   DR:24-95
+    TileBasedRenderer(__init__ / forward)    DR:434-450, DR:489-499, DR:684-686
+
+plus the `GaussianRenderer` torch.autograd.Function that BASELINE.json's north_star names
+(the reference has no autograd.Function; its backward is whatever autograd derives from the
+per-Gaussian Python loop, DR:582-667).
+
+PyTorch is plumbing here (device memory, streams, autograd graph); all arithmetic runs in
+libfgs_hip.so through the C ABI of include/fgs.h.  There is NO CPU fallback: calling the
+renderer without CUDA tensors or without the built library raises.
+"""
+import ctypes
+from typing import Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import _binding as B
+
+
+class Camera:
+    """Simple pinhole camera model (same fields and defaults as DR:27-52)."""
+
+    def __init__(self, fx: float, fy: float, cx: float, cy: float, width: int, height: int,
+                 near: float = 0.01, far: float = 100.0):
+        self.fx = fx
+        self.fy = fy
+        self.cx = cx
+        self.cy = cy
+        self.width = width
+        self.height = height
+        self.near = near
+        self.far = far
+        # identity = camera at origin looking down -Z (DR:47-48)
+        self.view_matrix = torch.eye(4)
+
+    def set_view(self, view_matrix: torch.Tensor):
+        """Set view matrix (world-to-camera transform), DR:50-52."""
+        self.view_matrix = view_matrix
+
+    def project(self, points_3d: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Project (N,3) world points to pixel coordinates + depths (DR:54-86); torch ops."""
+        ones = torch.ones(points_3d.shape[0], 1, device=points_3d.device)
+        homo = torch.cat([points_3d, ones], dim=1)
+        view = self.view_matrix.to(points_3d.device)
+        pc = (view @ homo.T).T[:, :3]
+        x, y, z = pc[:, 0], pc[:, 1], pc[:, 2]
+        z = torch.clamp(z.abs(), min=self.near) * torch.sign(z + 1e-8)
+        u = self.fx * x / (-z) + self.cx
+        v = self.fy * (-y) / (-z) + self.cy
+        return torch.stack([u, v], dim=1), -z
+
+    def get_intrinsics(self) -> torch.Tensor:
+        return torch.tensor([[self.fx, 0, self.cx], [0, self.fy, self.cy], [0, 0, 1]], dtype=torch.float32)
+
+    def packed(self) -> list:
+        """The FGS_CAMERA_FLOATS-float device record of include/fgs.h."""
+        v = self.view_matrix.detach().to("cpu", torch.float32).reshape(16).tolist()
+        return v + [float(self.fx), float(self.fy), float(self.cx), float(self.cy),
+                    float(self.near), float(self.far), 0.0, 0.0]
+
+
+def pack_cameras(cameras: Union[Camera, Sequence[Camera]], device) -> torch.Tensor:
+    cams = [cameras] if isinstance(cameras, Camera) else list(cameras)
+    return torch.tensor([c.packed() for c in cams], dtype=torch.float32, device=device)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_handle():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Cfg:
+    """Static (non-tensor) configuration of one renderer call."""
+
+    def __init__(self, width, height, background, max_radius, use_phase, phase_amplitude):
+        self.width, self.height = int(width), int(height)
+        self.background = tuple(float(b) for b in background)
+        self.max_radius = float(max_radius)
+        self.use_phase = bool(use_phase)
+        self.phase_amplitude = float(phase_amplitude)
+
+
+def forward_raw(positions, scales, rotations, colors, opacities, phases, cam_tensor, cfg):
+    """fgs_forward without autograd: returns (out_rgb, out_depth, saved, dims, input tensors)."""
+    if not positions.is_cuda:
+        raise B.FgsError("GaussianRenderer (HIP) needs CUDA/ROCm tensors; there is no CPU fallback "
+                         "(the CPU oracle lives under oracle/ and is test infrastructure only)")
+    lib = B.load()
+    Bn, N = positions.shape[0], positions.shape[1]
+    dev = positions.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    pos = positions.detach().contiguous().float()
+    scl = scales.detach().contiguous().float()
+    rot = rotations.detach().contiguous().float()
+    col = colors.detach().contiguous().float()
+    opa = opacities.detach().contiguous().float()
+    ph = phases.detach().contiguous().float() if (cfg.use_phase and phases is not None) else None
+    cam_tensor = cam_tensor.contiguous().float()
+    dims = B.make_dims(Bn, N, cfg.width, cfg.height, cfg.max_radius, cfg.background,
+                       use_phase=ph is not None, phase_amplitude=cfg.phase_amplitude,
+                       num_cameras=cam_tensor.shape[0])
+    saved_bytes, scratch_bytes = B.workspace_bytes(dims)
+    with torch.cuda.device(dev):
+        saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+        out_rgb = torch.empty(Bn, 3, cfg.height, cfg.width, **f32)
+        out_depth = torch.empty(Bn, cfg.height, cfg.width, **f32)
+        B.check(lib.fgs_forward(ctypes.byref(dims), _ptr(cam_tensor), _ptr(pos), _ptr(scl), _ptr(rot),
+                                _ptr(col), _ptr(opa), _ptr(ph), _ptr(out_rgb), _ptr(out_depth),
+                                _ptr(saved), _ptr(scratch), _stream_handle()), "fgs_forward")
+    return out_rgb, out_depth, saved, dims, (pos, scl, rot, col, opa, ph)
+
+
+class GaussianRenderer(torch.autograd.Function):
+    """Batched differentiable rasterizer: (B,N,.) Gaussians + cameras -> (B,3,H,W), (B,H,W).
+
+    forward  -> fgs_forward   (project, depth sort, tile binning, composite)
+    backward -> fgs_backward  (composite backward, projection backward)
+    """
+
+    @staticmethod
+    def forward(ctx, positions, scales, rotations, colors, opacities, phases, cam_tensor, cfg: _Cfg):
+        out_rgb, out_depth, saved, dims, tensors = forward_raw(
+            positions, scales, rotations, colors, opacities, phases, cam_tensor, cfg)
+        pos, scl, rot, col, opa, ph = tensors
+        ctx.dims = dims
+        ctx.has_phase = ph is not None
+        ctx.save_for_backward(pos, scl, rot, col, opa, ph if ph is not None else pos.new_empty(0),
+                              cam_tensor, saved)
+        return out_rgb, out_depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth):
+        lib = B.load()
+        pos, scl, rot, col, opa, ph, cam_tensor, saved = ctx.saved_tensors
+        dims = ctx.dims
+        dev = pos.device
+        ph = ph if ctx.has_phase else None
+        g_rgb = (g_rgb if g_rgb is not None else torch.zeros(dims.batch, 3, dims.height, dims.width, device=dev))
+        g_depth = (g_depth if g_depth is not None else torch.zeros(dims.batch, dims.height, dims.width, device=dev))
+        g_rgb = g_rgb.contiguous().float()
+        g_depth = g_depth.contiguous().float()
+        _, scratch_bytes = B.workspace_bytes(dims)
+        with torch.cuda.device(dev):
+            scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+            g_pos, g_scl, g_rot = torch.empty_like(pos), torch.empty_like(scl), torch.empty_like(rot)
+            g_col, g_opa = torch.empty_like(col), torch.empty_like(opa)
+            g_ph = torch.empty_like(ph) if ph is not None else None
+            B.check(lib.fgs_backward(ctypes.byref(dims), _ptr(cam_tensor), _ptr(pos), _ptr(scl), _ptr(rot),
+                                     _ptr(col), _ptr(opa), _ptr(ph), _ptr(saved), _ptr(scratch), _ptr(g_rgb),
+                                     _ptr(g_depth), _ptr(g_pos), _ptr(g_scl), _ptr(g_rot), _ptr(g_col),
+                                     _ptr(g_opa), _ptr(g_ph), _stream_handle()), "fgs_backward")
+        return g_pos, g_scl, g_rot, g_col, g_opa, g_ph, None, None
+
+
+def render_batch(positions, scales, rotations, colors, opacities, cameras, width, height,
+                 background=(0.0, 0.0, 0.0), max_radius=64, phases=None, use_phase_blending=False,
+                 phase_amplitude=0.25, cam_tensor=None):
+    """Functional batched entry point: tensors are (B,N,.); cameras is one Camera (shared by
+    the batch, as in the reference's training loop TGD:1209-1223) or a list of B Cameras."""
+    if cam_tensor is None:
+        cam_tensor = pack_cameras(cameras, positions.device)
+    cfg = _Cfg(width, height, background, max_radius, use_phase_blending and phases is not None,
+               phase_amplitude)
+    return GaussianRenderer.apply(positions, scales, rotations, colors, opacities, phases, cam_tensor, cfg)
+
+
+class TileBasedRenderer(nn.Module):
+    """Drop-in for the reference's TileBasedRenderer (DR:412-686), HIP-backed.
+
+    forward(positions (N,3), scales (N,3), rotations (N,4), colors (N,3), opacities (N,),
+            camera, return_depth=False, phases=None) -> (3,H,W) or ((3,H,W), (H,W))
+
+    Extension: the same call with a leading batch dimension (B,N,.) renders B images in one
+    launch sequence and returns (B,3,H,W) [, (B,H,W)]; `camera` may then be a list of B.
+    """
+
+    def __init__(self, image_width: int, image_height: int,
+                 background: Tuple[float, float, float] = (0.0, 0.0, 0.0), max_radius: int = 64,
+                 use_phase_blending: bool = False, phase_amplitude: float = 0.25):
+        super().__init__()
+        self.width = image_width
+        self.height = image_height
+        self.background = torch.tensor(background)  # plain tensor, as in DR:447
+        self.max_radius = max_radius
+        self.use_phase_blending = use_phase_blending
+        self.phase_amplitude = phase_amplitude
+
+    def forward(self, positions: torch.Tensor, scales: torch.Tensor, rotations: torch.Tensor,
+                colors: torch.Tensor, opacities: torch.Tensor, camera, return_depth: bool = False,
+                phases: Optional[torch.Tensor] = None):
+        batched = positions.dim() == 3
+        if not batched:
+            positions, scales, rotations = positions[None], scales[None], rotations[None]
+            colors, opacities = colors[None], opacities[None]
+            if phases is not None:
+                phases = phases[None]
+        use_phase = self.use_phase_blending and phases is not None
+        if use_phase and phases.dim() != 2:
+            # the reference's phase path takes a scalar phase per Gaussian in [0,1] (DR:498,
+            # DR:636-637); (N,3) phases make `phase - prev_phase` fail to broadcast there
+            raise RuntimeError(
+                f"TileBasedRenderer phase blending expects phases of shape (N,), got {tuple(phases.shape[1:])}")
+        bg = tuple(float(b) for b in self.background.tolist())
+        img, depth = render_batch(positions, scales, rotations, colors, opacities, camera, self.width,
+                                  self.height, bg, self.max_radius, phases if use_phase else None,
+                                  use_phase, self.phase_amplitude)
+        if not batched:
+            img, depth = img[0], depth[0]
+        if return_depth:
+            return img, depth
+        return img
+
+
+def inspect_saved(saved: torch.Tensor, dims) -> dict:
+    """Typed views of the integer stages inside a `saved` workspace (parity tests)."""
+    L = B.saved_layout(dims)
+    Bn, N, T = dims.batch, dims.num_gaussians, L.tiles_x * L.tiles_y
+
+    def view(off, count, dtype):
+        nbytes = count * torch.empty(0, dtype=dtype).element_size()
+        return saved[off:off + nbytes].view(dtype)
+
+    out = dict(layout=L)
+    out["rec"] = view(L.rec, Bn * N * 12, torch.float32).view(Bn, N, 12)
+    out["depth_key"] = view(L.depth_key, Bn * N, torch.int32).view(Bn, N)
+    out["tile_count"] = view(L.tile_count, Bn * N, torch.int32).view(Bn, N)
+    out["order"] = view(L.order, Bn * N, torch.int32).view(Bn, N)
+    out["counters"] = view(L.counters, 16, torch.int32)
+    out["ranges"] = view(L.ranges, Bn * T * 2, torch.int32).view(Bn, T, 2)
+    out["dup_ids"] = view(L.dup_ids, L.dup_capacity, torch.int32)
+    out["pix_state"] = view(L.pix_state, Bn * 6 * dims.height * dims.width, torch.float32).view(
+        Bn, 6, dims.height, dims.width)
+    return out

@@ -1,0 +1,115 @@
+/*
+ * fgs.h -- C ABI of the MI355X-native Gaussian-splatting rasterizer (libfgs_hip.so).
+ *
+ * The reference (CalebisGross/fresnel) has no FFI for this path: its boundary is the
+ * Python call surface of scripts/models/differentiable_renderer.py ("DR"):
+ *     TileBasedRenderer.__init__   DR:434-450
+ *     TileBasedRenderer.forward    DR:489-499 -> (3,H,W) [, (H,W)]   DR:684-686
+ *     Camera                       DR:24-52
+ *     ASMWaveFieldRenderer.forward DR:1150-1161
+ * This header is what a binding for that surface calls (see INTEGRATION.md for the
+ * ctypes stub).  Conventions:
+ *   - plain pointers and sizes only; every data pointer is DEVICE memory (HBM) unless
+ *     marked host; all tensors contiguous fp32 in the reference's layouts, with a leading
+ *     batch dimension B (one reference call == B = 1);
+ *   - functions enqueue work on `stream` and return; they never allocate, never
+ *     synchronise and are re-entrant per (stream, workspace);
+ *   - return 0 on success, negative FGS_E* on error; fgs_last_error() gives the text.
+ */
+#ifndef FGS_H
+#define FGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGS_OK 0
+#define FGS_EINVAL (-1)    /* bad dims / null pointer */
+#define FGS_ELAUNCH (-2)   /* HIP launch error */
+#define FGS_EUNSUPPORTED (-3)
+
+#define FGS_TILE 16        /* tile edge in pixels */
+#define FGS_CAMERA_FLOATS 24
+
+/* Problem shape.  Mirrors TileBasedRenderer.__init__ (DR:434-450). */
+typedef struct FgsDims {
+    int32_t batch;          /* B images rendered by one call                       */
+    int32_t num_gaussians;  /* N Gaussians per image                               */
+    int32_t width, height;  /* image_width, image_height                 DR:445-446 */
+    float max_radius;       /* radius cap in pixels (default 64)         DR:439,485 */
+    float background[3];    /*                                            DR:447    */
+    int32_t use_phase;      /* use_phase_blending && phases given        DR:629     */
+    float phase_amplitude;  /*                                            DR:442    */
+    int32_t num_cameras;    /* 1 (shared, TGD:1209-1223) or B                       */
+    int32_t reserved;
+} FgsDims;
+
+/* Camera record on the DEVICE: FGS_CAMERA_FLOATS floats per camera (Camera, DR:27-52):
+ *   [0..15] view matrix row-major (world->camera), [16] fx, [17] fy, [18] cx, [19] cy,
+ *   [20] near, [21] far, [22..23] unused. */
+
+/* Byte offsets of the sections of the `saved` buffer (forward -> backward state and
+ * the integer stages the parity tests inspect).  All sections 256-byte aligned. */
+typedef struct FgsSavedLayout {
+    size_t total_bytes;
+    size_t rec;        /* float  [B][N][12]: u,v, conic(a, b+c, d), opacity, r,g,b, depth,
+                                              bits(x0|x1<<16), bits(y0|y1<<16)            */
+    size_t depth_key;  /* uint32 [B][N]: order-preserving depth bits, 0xFFFFFFFF = culled */
+    size_t tile_count; /* uint32 [B][N]: tiles touched (0 = culled or empty bbox)         */
+    size_t order;      /* uint32 [B][N]: Gaussian ids in canonical depth order (DR:527)   */
+    size_t counters;   /* uint32 [16]: [0] total duplicates D, [1] overflow flag          */
+    size_t ranges;     /* uint32 [B*T][2]: [start,end) into dup_ids per (image,tile)      */
+    size_t dup_ids;    /* uint32 [Dcap]: b*N+n per duplicate, sorted by (image,tile), depth
+                                         order inside a tile                              */
+    size_t pix_state;  /* float  [B][6][H][W]: C_r,C_g,C_b (pre-bg, pre-clamp), A, D, Phi */
+    size_t dup_capacity; /* Dcap (elements, not bytes)                                    */
+    int32_t tiles_x, tiles_y;
+} FgsSavedLayout;
+
+/* Sizes of the two caller-provided device buffers.  `saved` must stay untouched between
+ * fgs_forward and the matching fgs_backward; `scratch` may be reused immediately. */
+int fgs_workspace_bytes(const FgsDims *dims, size_t *saved_bytes, size_t *scratch_bytes);
+int fgs_saved_layout(const FgsDims *dims, FgsSavedLayout *layout);
+
+/* Replaces TileBasedRenderer.forward (DR:489-686) for B images at once.
+ *   pos (B,N,3)  scale (B,N,3)  quat (B,N,4 wxyz, unnormalised ok)  color (B,N,3)
+ *   opacity (B,N)  phase (B,N) or NULL
+ *   out_rgb (B,3,H,W) clamped to [0,1]; out_depth (B,H,W). */
+int fgs_forward(const FgsDims *dims, const float *cameras, const float *pos, const float *scale,
+                const float *quat, const float *color, const float *opacity, const float *phase,
+                float *out_rgb, float *out_depth, void *saved, void *scratch, void *stream);
+
+/* Replaces autograd through DR:519-686: gradients of sum(out_rgb*g_rgb)+sum(out_depth*g_depth).
+ * g_* outputs are fully overwritten (zeros for culled Gaussians).  g_phase may be NULL
+ * when dims->use_phase == 0. */
+int fgs_backward(const FgsDims *dims, const float *cameras, const float *pos, const float *scale,
+                 const float *quat, const float *color, const float *opacity, const float *phase,
+                 const void *saved, void *scratch, const float *g_rgb, const float *g_depth,
+                 float *g_pos, float *g_scale, float *g_quat, float *g_color, float *g_opacity,
+                 float *g_phase, void *stream);
+
+/* Number of composited Gaussian-pixels of the last forward on this `saved` buffer
+ * (SURVEY §8d unit of work): enqueues a reduction that writes one uint64 to
+ * `out_pairs` (device). */
+int fgs_count_pairs(const FgsDims *dims, const void *saved, uint64_t *out_pairs, void *stream);
+
+/* Per-stage hipEvent timers (profiling aid; SURVEY §5 "tracing").  When enabled, every stage
+ * launched by fgs_forward/fgs_backward is bracketed by an event pair on the caller's stream.
+ * fgs_stage_timing_read synchronises on the recorded events, ADDS the elapsed milliseconds per
+ * stage to ms[FGS_NUM_STAGES] and the number of launches to count[FGS_NUM_STAGES], and clears
+ * the record.  Stage order: project, depth_sort, dup_emit, tile_sort, tile_ranges,
+ * composite_fwd, composite_bwd, project_bwd. */
+#define FGS_NUM_STAGES 8
+int fgs_stage_timing_enable(int enable);
+int fgs_stage_timing_read(float *ms, int32_t *count);
+
+const char *fgs_last_error(void);
+const char *fgs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGS_H */

@@ -1,0 +1,73 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and
+exports every symbol include/*.h declares; plan/layout arithmetic (no GPU compute calls)."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+
+from helpers import ROOT
+
+
+def declared_symbols():
+    names = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        txt = open(h).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names += re.findall(r"\b(fgs_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from fresnel_amd import build
+    path = build.build()
+    return ctypes.CDLL(path)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_symbols()
+    assert "fgs_forward" in names and "fgs_backward" in names
+    for n in names:
+        assert hasattr(lib, n), f"libfgs_hip.so does not export {n}"
+
+
+def test_binding_symbol_list_matches_header():
+    from fresnel_amd import _binding
+    assert sorted(_binding.EXPORTED_SYMBOLS) == declared_symbols()
+
+
+def test_workspace_and_layout():
+    from fresnel_amd import _binding as B
+    d = B.make_dims(2, 1000, 100, 72)
+    saved, scratch = B.workspace_bytes(d)
+    L = B.saved_layout(d)
+    assert L.tiles_x == 7 and L.tiles_y == 5
+    # 64-px radius cap: bbox spans <= 10 tile columns, clipped to the 7x5 tile grid
+    assert L.dup_capacity == 2 * 1000 * 7 * 5
+    assert L.total_bytes == saved and saved > 0 and scratch > 0
+    offs = [L.rec, L.depth_key, L.tile_count, L.order, L.counters, L.ranges, L.dup_ids, L.pix_state]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    d2 = B.make_dims(8, 32768, 512, 512)
+    L2 = B.saved_layout(d2)
+    assert L2.dup_capacity == 8 * 32768 * 100
+
+
+def test_invalid_dims_are_rejected():
+    from fresnel_amd import _binding as B
+    with pytest.raises(B.FgsError):
+        B.workspace_bytes(B.make_dims(0, 10, 16, 16))
+    with pytest.raises(B.FgsError):
+        B.workspace_bytes(B.make_dims(2, 10, 16, 16, num_cameras=3))
+
+
+def test_renderer_refuses_cpu_tensors():
+    """The product path has no CPU fallback: it must fail loudly, not route to the oracle."""
+    import torch
+    from fresnel_amd import _binding as B
+    from fresnel_amd.renderer import Camera, TileBasedRenderer
+    r = TileBasedRenderer(32, 32)
+    cam = Camera(25.6, 25.6, 16, 16, 32, 32)
+    with pytest.raises(B.FgsError):
+        r(torch.zeros(4, 3), torch.ones(4, 3), torch.ones(4, 4), torch.ones(4, 3), torch.ones(4), cam)
