@@ -87,8 +87,10 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p) {
     L.depth_key = o; o = align256(o + B * N * 4);
     L.tile_count = o; o = align256(o + B * N * 4);
     L.order = o; o = align256(o + B * N * 4);
+    L.dup_off = o; o = align256(o + B * N * 4);
     L.counters = o; o = align256(o + 16 * 4);
     L.ranges = o; o = align256(o + B * p->tiles * 2 * 4);
+    L.tile_order = o; o = align256(o + B * p->tiles * 4);
     L.dup_ids = o; o = align256(o + dcap * 4);
     L.pix_state = o; o = align256(o + B * 6 * (size_t)d->width * d->height * 4);
     L.total_bytes = o;
@@ -107,9 +109,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p) {
     p->s_vals1 = o; o = align256(o + nsort * 4);
     p->s_hist = o; o = align256(o + hist);
     p->s_bsum = o; o = align256(o + nblk * 4);
-    p->s_gconic = o; o = align256(o + B * N * 3 * 4);
-    p->s_gmean = o; o = align256(o + B * N * 2 * 4);
-    p->s_gdepth = o; o = align256(o + B * N * 4);
+    p->s_grows = o; o = align256(o + dcap * FGS_GROW_FLOATS * 4);
     p->s_total = o;
     return FGS_OK;
 }
@@ -202,14 +202,12 @@ int fgs_backward(const FgsDims *dims, const float *cameras, const float *pos, co
     const char *sv = reinterpret_cast<const char *>(saved);
     char *sc = reinterpret_cast<char *>(scratch);
     fgs_stage_begin(ST_COMPOSITE_BWD, st);
-    if ((rc = fgs_launch_composite_bwd(p, color, phase, sv, sc, g_rgb, g_depth, g_color, g_opacity, g_phase, st)))
-        return rc;
+    if ((rc = fgs_launch_composite_bwd(p, phase, sv, sc, g_rgb, g_depth, g_phase, st))) return rc;
     fgs_stage_end(ST_COMPOSITE_BWD, st);
     fgs_stage_begin(ST_PROJECT_BWD, st);
     if ((rc = fgs_launch_project_bwd(p, cameras, pos, scale, quat, sv,
-                                     reinterpret_cast<const float *>(sc + p.s_gmean),
-                                     reinterpret_cast<const float *>(sc + p.s_gconic),
-                                     reinterpret_cast<const float *>(sc + p.s_gdepth), g_pos, g_scale, g_quat, st)))
+                                     reinterpret_cast<const float *>(sc + p.s_grows), g_pos, g_scale, g_quat,
+                                     g_color, g_opacity, st)))
         return rc;
     fgs_stage_end(ST_PROJECT_BWD, st);
     return FGS_OK;

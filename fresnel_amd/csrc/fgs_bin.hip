@@ -88,11 +88,13 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
                                                   const uint32_t *__restrict__ tile_count,
                                                   const float *__restrict__ rec,
                                                   const uint32_t *__restrict__ bsum,
+                                                  uint32_t *__restrict__ dup_off,
                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t gid, tot;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t c = sorted_count(i, total, N, order, tile_count, &gid);
     uint32_t off = bsum[blockIdx.x] + block_exclusive_scan_256(c, &tot);
+    if (i < total) dup_off[gid] = off;
     if (c == 0) return;
     const uint32_t bbx = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBX]);
     const uint32_t bby = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBY]);
@@ -117,6 +119,37 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t *__restrict_
         const uint32_t k = keys[i];
         if (i == 0 || keys[i - 1] != k) ranges[2 * k] = i;
         if (i == D - 1 || keys[i + 1] != k) ranges[2 * k + 1] = i + 1;
+    }
+}
+
+// Launch order of the composite kernels: tiles with the longest lists first (LPT scheduling:
+// the hardware dispatcher hands workgroups to CUs in blockIdx order, so heavy tiles start
+// early and light ones fill the tail).  Single-block counting sort into 64 length buckets;
+// the order inside a bucket is arbitrary -- it affects scheduling only, never results.
+__global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, const uint32_t *__restrict__ ranges,
+                                                     uint32_t *__restrict__ tile_order) {
+    __shared__ uint32_t hist[64];
+    __shared__ uint32_t maxc;
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) maxc = 1;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) atomicMax(&maxc, ranges[2 * t + 1] - ranges[2 * t]);
+    __syncthreads();
+    const uint32_t mx = maxc;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
+        const uint32_t cnt = ranges[2 * t + 1] - ranges[2 * t];
+        atomicAdd(&hist[63u - (uint32_t)(((unsigned long long)cnt * 63ull) / mx)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 64; ++i) { const uint32_t h = hist[i]; hist[i] = run; run += h; }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
+        const uint32_t cnt = ranges[2 * t + 1] - ranges[2 * t];
+        const uint32_t pos = atomicAdd(&hist[63u - (uint32_t)(((unsigned long long)cnt * 63ull) / mx)], 1u);
+        tile_order[pos] = t;
     }
 }
 
@@ -171,7 +204,8 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     FGS_LAUNCH_CHECK("k_dup_scan_bsum");
     // (3) emit (tile key, gaussian id) in depth order
     hipLaunchKernelGGL(k_dup_emit, dim3(nblk), dim3(256), 0, st, total, N, (uint32_t)p.tiles,
-                       (uint32_t)p.L.tiles_x, dcap, order, tile_count, rec, bsum, keys0, vals0);
+                       (uint32_t)p.L.tiles_x, dcap, order, tile_count, rec, bsum,
+                       reinterpret_cast<uint32_t *>(saved + p.L.dup_off), keys0, vals0);
     FGS_LAUNCH_CHECK("k_dup_emit");
     fgs_stage_end(ST_DUP_EMIT, st);
     fgs_stage_begin(ST_TILE_SORT, st);
@@ -188,6 +222,9 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     if (rgrid > 2048) rgrid = 2048;
     hipLaunchKernelGGL(k_tile_ranges, dim3(rgrid), dim3(256), 0, st, counters, ks, ranges);
     FGS_LAUNCH_CHECK("k_tile_ranges");
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, B * (uint32_t)p.tiles, ranges,
+                       reinterpret_cast<uint32_t *>(saved + p.L.tile_order));
+    FGS_LAUNCH_CHECK("k_tile_order");
     fgs_stage_end(ST_TILE_RANGES, st);
     return FGS_OK;
 }

@@ -1,114 +1,147 @@
 // Stage 3: front-to-back per-pixel alpha compositing, forward and backward.
 // Replaces the reference's per-Gaussian Python loop (DR:582-667) and its autograd replay.
 //
-// One workgroup = one 16x16 tile of one image; one lane = one pixel.  The tile's depth-sorted
-// Gaussian list is staged through LDS in chunks of 256 twelve-float records (three b128 rows
-// per record, read back as wave-uniform broadcasts), and every lane blends the chunk in
-// order.  Reference semantics kept exactly: rectangular bbox support (DR:594-600), integer
-// pixel coordinates (DR:603-607), alpha clamp [0, 0.99] (DR:647), additive accumulated alpha
-// with T = 1 - A (DR:650-658), no early termination.
+// Work decomposition (CDNA4, wave64): ONE WAVE owns one 16x16 tile of one image.  The tile is
+// cut into four 8x8 sub-tiles; lane l owns pixel (l&7, l>>3) of EACH sub-tile, so a wave
+// instruction covers exactly one sub-tile.  For every Gaussian of the tile's depth-sorted list
+// the wave tests the Gaussian's integer bbox against the four sub-tile rectangles with scalar
+// code and runs the per-pixel blend only for the sub-tiles it touches (wave-uniform branches:
+// no divergence, 8x8 work granularity).  The list is staged through LDS 64 records at a time
+// (lane j fetches record j with three 16-byte loads; the loop reads each record back once as
+// three wave-uniform ds_read_b128 broadcasts and keeps it in registers across the sub-tiles).
 //
-// VALU/transcendental-bound (about 25 VALU + 1 v_exp_f32 per Gaussian-pixel forward, ~70
-// backward); HBM traffic is the 48-B record gather per duplicate plus the per-pixel state.
+// Reference semantics kept exactly: rectangular bbox support (DR:594-600), integer pixel
+// coordinates (DR:603-607), alpha clamp [0, 0.99] (DR:647), additive accumulated alpha with
+// T = 1 - A (DR:650-658), no early termination.
+//
+// Bound: VALU + transcendental (about 25 VALU + 1 v_exp_f32 per Gaussian-pixel forward, ~60
+// backward); HBM traffic is the 52-byte id+record gather per duplicate plus per-pixel state.
 #include "fgs_internal.h"
 
 namespace {
 
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;  // exp(-m/2) = exp2(m * this)
 constexpr float PHASE_KAPPA = 2.0f * 3.14159f;              // DR:642 uses the literal 3.14159
+constexpr int CH = 64;                                      // records per LDS chunk (one per lane)
 
 struct TileCtx {
-    uint32_t tile, b, px, py, start, end;
-    bool inside;
+    uint32_t tile, b, tx, ty, X0, Y0, start, end;
 };
 
-__device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H,
+__device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x,
+                                            const uint32_t *__restrict__ tile_order,
                                             const uint32_t *__restrict__ ranges) {
     TileCtx c;
-    c.tile = blockIdx.x;
+    c.tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
     c.b = c.tile / tiles;
     const uint32_t t = c.tile - c.b * tiles;
-    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
-    c.px = tx * FGS_TILE + (threadIdx.x & 15u);
-    c.py = ty * FGS_TILE + (threadIdx.x >> 4);
-    c.inside = c.px < W && c.py < H;
+    c.ty = t / tiles_x;
+    c.tx = t - c.ty * tiles_x;
+    c.X0 = c.tx * FGS_TILE;
+    c.Y0 = c.ty * FGS_TILE;
     c.start = ranges[2 * c.tile];
     c.end = ranges[2 * c.tile + 1];
     return c;
 }
 
-// sum over the 64 lanes of the wave; the total is valid in lane 63 (DPP row shifts + broadcasts)
-__device__ __forceinline__ float wave_sum_lane63(float x) {
-#define FGS_DPP_ADD(ctrl, rmask)                                                                     \
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, false))
-    FGS_DPP_ADD(0x111, 0xf);  // row_shr:1
-    FGS_DPP_ADD(0x112, 0xf);  // row_shr:2
-    FGS_DPP_ADD(0x114, 0xf);  // row_shr:4
-    FGS_DPP_ADD(0x118, 0xf);  // row_shr:8
-    FGS_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1,3
-    FGS_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2,3
-#undef FGS_DPP_ADD
-    return x;
+// Wave-wide sums of ten values; totals are valid in lane 63.  Hand-written fused
+// v_add_f32_dpp (hipcc emits v_mov_dpp + v_pk_add pairs for the builtin form: 2.5x the
+// instructions).  The ten chains are interleaved so that dependent DPP reads are ten
+// instructions apart (>= the 2 wait states a VALU write -> DPP read needs); the leading s_nop
+// covers the producers of the inputs.  row_shr 1,2,4,8 sum each 16-lane row into its lane 15;
+// row_bcast:15 / row_bcast:31 carry the row totals to lane 63.
+__device__ __forceinline__ void wave_sum10_lane63(float &a0, float &a1, float &a2, float &a3, float &a4,
+                                                  float &a5, float &a6, float &a7, float &a8, float &a9) {
+#define FGS_STEP(ctrl)                                                                                     \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n v_add_f32_dpp %1, %1, %1 " ctrl "\n v_add_f32_dpp %2, %2, %2 " ctrl  \
+    "\n v_add_f32_dpp %3, %3, %3 " ctrl "\n v_add_f32_dpp %4, %4, %4 " ctrl "\n v_add_f32_dpp %5, %5, %5 " ctrl \
+    "\n v_add_f32_dpp %6, %6, %6 " ctrl "\n v_add_f32_dpp %7, %7, %7 " ctrl "\n v_add_f32_dpp %8, %8, %8 " ctrl \
+    "\n v_add_f32_dpp %9, %9, %9 " ctrl "\n"
+    asm volatile("s_nop 1\n" FGS_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 FGS_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 FGS_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 FGS_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 FGS_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 FGS_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
+                   "+v"(a9));
+#undef FGS_STEP
 }
 
 template <bool PHASE>
-__global__ __launch_bounds__(256) void k_composite_fwd(
+__global__ __launch_bounds__(64) void k_composite_fwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
-    const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec,
-    const float *__restrict__ phase, float *__restrict__ pix_state, float *__restrict__ out_rgb,
-    float *__restrict__ out_depth) {
-    __shared__ float4 sh0[256], sh1[256], sh2[256];
-    __shared__ float shp[256];
-    const TileCtx c = tile_ctx(tiles, tiles_x, W, H, ranges);
-    const float fx = (float)c.px, fy = (float)c.py;
-    float A = 0.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, Dm = 0.0f, Ph = 0.0f;
-    for (uint32_t base = c.start; base < c.end; base += 256) {
-        const uint32_t n = min(256u, c.end - base);
-        if (threadIdx.x < n) {
-            const uint32_t gid = dup_ids[base + threadIdx.x];
+    const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
+    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
+    float *__restrict__ pix_state, float *__restrict__ out_rgb, float *__restrict__ out_depth) {
+    __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
+    __shared__ float shp[CH];
+    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    float A[4], Cr[4], Cg[4], Cb[4], Dm[4], Ph[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { A[s] = 0; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; Ph[s] = 0; }
+    for (uint32_t base = c.start; base < c.end; base += CH) {
+        const uint32_t n = min((uint32_t)CH, c.end - base);
+        if (lane < n) {
+            const uint32_t gid = dup_ids[base + lane];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
             float4 q0 = r[0], q1 = r[1];
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
-            sh0[threadIdx.x] = q0; sh1[threadIdx.x] = q1; sh2[threadIdx.x] = r[2];
-            if (PHASE) shp[threadIdx.x] = phase[gid];
+            sh0[lane] = q0; sh1[lane] = q1; sh2[lane] = r[2];
+            if (PHASE) shp[lane] = phase[gid];
         }
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
-            const bool in = c.px >= (bbx & 0xFFFFu) && c.px < (bbx >> 16) && c.py >= (bby & 0xFFFFu) &&
-                            c.py < (bby >> 16);
-            const float dx = fx - q0.x, dy = fy - q0.y;
-            const float m = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
-            float alpha = __builtin_amdgcn_exp2f(m) * q1.y;
-            if (PHASE) {
-                const float ph = shp[j];
-                float pd = fabsf(ph - Ph);
-                pd = fminf(pd, 1.0f - pd);
-                alpha *= (1.0f - amp) + amp * __cosf(pd * PHASE_KAPPA);
-            }
-            alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
-            alpha = in ? alpha : 0.0f;
-            const float w = alpha * (1.0f - A);
-            Cr += w * q1.z; Cg += w * q1.w; Cb += w * q2.x; Dm += w * q2.y;
-            A += w;
-            if (PHASE) {
-                const float pc = w / fmaxf(A, 1e-6f);
-                Ph = in ? (Ph * (1.0f - pc) + shp[j] * pc) : Ph;
+            const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+            const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
+            const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
+            const float ph = PHASE ? shp[j] : 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t sx = c.X0 + 8u * (s & 1), sy = c.Y0 + 8u * (s >> 1);
+                if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) continue;  // scalar branch
+                const uint32_t px = sx + lx, py = sy + ly;
+                const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
+                const float dx = (float)px - q0.x, dy = (float)py - q0.y;
+                const float m = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
+                float alpha = __builtin_amdgcn_exp2f(m) * q1.y;
+                if (PHASE) {
+                    float pd = fabsf(ph - Ph[s]);
+                    pd = fminf(pd, 1.0f - pd);
+                    alpha *= (1.0f - amp) + amp * __cosf(pd * PHASE_KAPPA);
+                }
+                alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
+                alpha = in ? alpha : 0.0f;
+                const float w = alpha * (1.0f - A[s]);
+                Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
+                A[s] += w;
+                if (PHASE) {
+                    const float pc = w / fmaxf(A[s], 1e-6f);
+                    Ph[s] = in ? (Ph[s] * (1.0f - pc) + ph * pc) : Ph[s];
+                }
             }
         }
         __syncthreads();
     }
-    if (c.inside) {
-        const size_t HW = (size_t)W * H, o = (size_t)c.py * W + c.px;
-        float *ps = pix_state + (size_t)c.b * 6 * HW + o;
-        ps[0] = Cr; ps[HW] = Cg; ps[2 * HW] = Cb; ps[3 * HW] = A; ps[4 * HW] = Dm; ps[5 * HW] = Ph;
-        const float T = 1.0f - A;
-        float *img = out_rgb + (size_t)c.b * 3 * HW + o;
-        img[0] = fminf(fmaxf(Cr + T * bg0, 0.0f), 1.0f);
-        img[HW] = fminf(fmaxf(Cg + T * bg1, 0.0f), 1.0f);
-        img[2 * HW] = fminf(fmaxf(Cb + T * bg2, 0.0f), 1.0f);
-        out_depth[(size_t)c.b * HW + o] = Dm;
+    const size_t HW = (size_t)W * H;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
+        if (px < W && py < H) {
+            const size_t o = (size_t)py * W + px;
+            float *ps = pix_state + (size_t)c.b * 6 * HW + o;
+            ps[0] = Cr[s]; ps[HW] = Cg[s]; ps[2 * HW] = Cb[s]; ps[3 * HW] = A[s]; ps[4 * HW] = Dm[s];
+            ps[5 * HW] = Ph[s];
+            const float T = 1.0f - A[s];
+            float *img = out_rgb + (size_t)c.b * 3 * HW + o;
+            img[0] = fminf(fmaxf(Cr[s] + T * bg0, 0.0f), 1.0f);
+            img[HW] = fminf(fmaxf(Cg[s] + T * bg1, 0.0f), 1.0f);
+            img[2 * HW] = fminf(fmaxf(Cb[s] + T * bg2, 0.0f), 1.0f);
+            out_depth[(size_t)c.b * HW + o] = Dm[s];
+        }
     }
 }
 
@@ -117,85 +150,102 @@ __global__ __launch_bounds__(256) void k_composite_fwd(
 //   S_i = T_fin (gI.bg) + sum_{j>i} w_j q_j = T_fin (gI.bg) + Total - sum_{j<=i} w_j q_j,
 // with Total = gI.C_acc + gD.D_acc known from the forward's saved per-pixel state, so the
 // sweep runs in the SAME order as the forward and T_i is recomputed exactly (no division-
-// based transmittance recovery).  Per-Gaussian sums are reduced over the wave with DPP and
-// committed with one fp32 atomic per value per wave.
-__global__ __launch_bounds__(256) void k_composite_bwd(
-    uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2,
-    const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec,
-    const float *__restrict__ pix_state,
-    const float *__restrict__ g_rgb, const float *__restrict__ g_depth, float *__restrict__ g_mean,
-    float *__restrict__ g_conic, float *__restrict__ g_dep, float *__restrict__ g_color,
-    float *__restrict__ g_opacity) {
-    __shared__ float4 sh0[256], sh1[256], sh2[256];
-    __shared__ uint32_t shid[256];
-    const TileCtx c = tile_ctx(tiles, tiles_x, W, H, ranges);
-    const float fx = (float)c.px, fy = (float)c.py;
-    const size_t HW = (size_t)W * H, o = (size_t)c.py * W + c.px;
-    float gr = 0.0f, gg = 0.0f, gb = 0.0f, gd = 0.0f, S0 = 0.0f;
-    if (c.inside) {
-        const float *ps = pix_state + (size_t)c.b * 6 * HW + o;
-        const float Cr = ps[0], Cg = ps[HW], Cb = ps[2 * HW], Af = ps[3 * HW];
-        const float Tf = 1.0f - Af;
-        const float pr = Cr + Tf * bg0, pg = Cg + Tf * bg1, pb = Cb + Tf * bg2;
-        const float *gi = g_rgb + (size_t)c.b * 3 * HW + o;
-        gr = (pr >= 0.0f && pr <= 1.0f) ? gi[0] : 0.0f;  // clamp backward, closed interval
-        gg = (pg >= 0.0f && pg <= 1.0f) ? gi[HW] : 0.0f;
-        gb = (pb >= 0.0f && pb <= 1.0f) ? gi[2 * HW] : 0.0f;
-        gd = g_depth[(size_t)c.b * HW + o];
-        S0 = Tf * (gr * bg0 + gg * bg1 + gb * bg2) + (gr * Cr + gg * Cg + gb * Cb) + gd * ps[4 * HW];
+// based transmittance recovery, no saved per-pair state).
+//
+// Gradient accumulation is atomic-free and deterministic: each lane sums its (up to four)
+// pixels' contributions to the ten per-Gaussian gradients, the wave reduces them with DPP, and
+// lane 63 stores ONE 48-byte row at the duplicate's emission slot (dup_off[gaussian] + index
+// of this tile inside the Gaussian's tile rectangle).  A Gaussian's rows are contiguous and
+// k_project_bwd sums them in a fixed order.
+__global__ __launch_bounds__(64) void k_composite_bwd(
+    uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, uint32_t dcap,
+    const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
+    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const uint32_t *__restrict__ dup_off,
+    const float *__restrict__ pix_state, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
+    float *__restrict__ grad_rows) {
+    __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
+    __shared__ uint32_t she[CH];
+    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const size_t HW = (size_t)W * H;
+    float gr[4], gg[4], gb[4], gd[4], S0[4], A[4], prefix[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
+        gr[s] = gg[s] = gb[s] = gd[s] = S0[s] = 0.0f;
+        A[s] = 0.0f; prefix[s] = 0.0f;
+        if (px < W && py < H) {
+            const size_t o = (size_t)py * W + px;
+            const float *ps = pix_state + (size_t)c.b * 6 * HW + o;
+            const float Cr = ps[0], Cg = ps[HW], Cb = ps[2 * HW], Af = ps[3 * HW];
+            const float Tf = 1.0f - Af;
+            const float pr = Cr + Tf * bg0, pg = Cg + Tf * bg1, pb = Cb + Tf * bg2;
+            const float *gi = g_rgb + (size_t)c.b * 3 * HW + o;
+            gr[s] = (pr >= 0.0f && pr <= 1.0f) ? gi[0] : 0.0f;  // clamp backward, closed interval
+            gg[s] = (pg >= 0.0f && pg <= 1.0f) ? gi[HW] : 0.0f;
+            gb[s] = (pb >= 0.0f && pb <= 1.0f) ? gi[2 * HW] : 0.0f;
+            gd[s] = g_depth[(size_t)c.b * HW + o];
+            S0[s] = Tf * (gr[s] * bg0 + gg[s] * bg1 + gb[s] * bg2) + (gr[s] * Cr + gg[s] * Cg + gb[s] * Cb) +
+                    gd[s] * ps[4 * HW];
+        }
     }
-    float A = 0.0f, prefix = 0.0f;
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base = c.start; base < c.end; base += 256) {
-        const uint32_t n = min(256u, c.end - base);
-        if (threadIdx.x < n) {
-            const uint32_t gid = dup_ids[base + threadIdx.x];
+    for (uint32_t base = c.start; base < c.end; base += CH) {
+        const uint32_t n = min((uint32_t)CH, c.end - base);
+        if (lane < n) {
+            const uint32_t gid = dup_ids[base + lane];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
-            sh0[threadIdx.x] = r[0]; sh1[threadIdx.x] = r[1]; sh2[threadIdx.x] = r[2];
-            shid[threadIdx.x] = gid;
+            const float4 q2 = r[2];
+            sh0[lane] = r[0]; sh1[lane] = r[1]; sh2[lane] = q2;
+            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
+            const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
+            const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE;
+            she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
         }
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
-            // wave-uniform reject: bbox rows vs this wave's 4 pixel rows, bbox cols vs tile cols
-            const bool in = c.px >= (bbx & 0xFFFFu) && c.px < (bbx >> 16) && c.py >= (bby & 0xFFFFu) &&
-                            c.py < (bby >> 16);
-            if (__ballot(in) == 0ull) continue;
+            const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+            const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
+            const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
             const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;
-            const float dx = fx - q0.x, dy = fy - q0.y;
-            const float m = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
-            const float G = __builtin_amdgcn_exp2f(m * NEG_HALF_LOG2E);
-            const float raw = G * op;
-            float alpha = fminf(fmaxf(raw, 0.0f), 0.99f);
-            alpha = in ? alpha : 0.0f;
-            const float T = 1.0f - A;
-            const float w = alpha * T;
-            const float q = gr * q1.z + gg * q1.w + gb * q2.x + gd * q2.y;
-            prefix += w * q;
-            const float S = S0 - prefix;
-            const float dalpha = T * q - S * __builtin_amdgcn_rcpf(1.0f - alpha);
-            const float draw = (in && raw >= 0.0f && raw <= 0.99f) ? dalpha : 0.0f;
-            A += w;
-            const float dm = -0.5f * draw * op * G;
-            float v_op = draw * G;
-            float v_ca = dm * dx * dx, v_cbc = dm * dx * dy, v_cd = dm * dy * dy;
-            float v_u = -dm * (2.0f * ca * dx + cbc * dy), v_v = -dm * (cbc * dx + 2.0f * cd * dy);
-            float v_r = w * gr, v_g = w * gg, v_b = w * gb, v_d = w * gd;
-            v_op = wave_sum_lane63(v_op);
-            v_ca = wave_sum_lane63(v_ca); v_cbc = wave_sum_lane63(v_cbc); v_cd = wave_sum_lane63(v_cd);
-            v_u = wave_sum_lane63(v_u); v_v = wave_sum_lane63(v_v);
-            v_r = wave_sum_lane63(v_r); v_g = wave_sum_lane63(v_g); v_b = wave_sum_lane63(v_b);
-            v_d = wave_sum_lane63(v_d);
+            float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t sx = c.X0 + 8u * (s & 1), sy = c.Y0 + 8u * (s >> 1);
+                if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) continue;  // scalar branch
+                const uint32_t px = sx + lx, py = sy + ly;
+                const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
+                const float dx = (float)px - q0.x, dy = (float)py - q0.y;
+                const float m = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
+                const float G = __builtin_amdgcn_exp2f(m * NEG_HALF_LOG2E);
+                const float raw = G * op;
+                float alpha = fminf(fmaxf(raw, 0.0f), 0.99f);
+                alpha = in ? alpha : 0.0f;
+                const float T = 1.0f - A[s];
+                const float w = alpha * T;
+                const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
+                prefix[s] += w * q;
+                const float S = S0[s] - prefix[s];
+                const float dalpha = T * q - S * __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float draw = (in && raw >= 0.0f && raw <= 0.99f) ? dalpha : 0.0f;
+                A[s] += w;
+                const float dm = -0.5f * draw * op * G;
+                v_op += draw * G;
+                v_ca += dm * dx * dx; v_cbc += dm * dx * dy; v_cd += dm * dy * dy;
+                v_u -= dm * (2.0f * ca * dx + cbc * dy);
+                v_v -= dm * (cbc * dx + 2.0f * cd * dy);
+                v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
+            }
+            wave_sum10_lane63(v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d);
             if (lane == 63) {
-                const uint32_t gid = shid[j];
-                atomicAdd(g_mean + 2 * (size_t)gid, v_u); atomicAdd(g_mean + 2 * (size_t)gid + 1, v_v);
-                atomicAdd(g_conic + 3 * (size_t)gid, v_ca); atomicAdd(g_conic + 3 * (size_t)gid + 1, v_cbc);
-                atomicAdd(g_conic + 3 * (size_t)gid + 2, v_cd);
-                atomicAdd(g_dep + gid, v_d);
-                atomicAdd(g_color + 3 * (size_t)gid, v_r); atomicAdd(g_color + 3 * (size_t)gid + 1, v_g);
-                atomicAdd(g_color + 3 * (size_t)gid + 2, v_b);
-                atomicAdd(g_opacity + gid, v_op);
+                const uint32_t e = she[j];
+                if (e < dcap) {
+                    float4 *dst = reinterpret_cast<float4 *>(grad_rows + (size_t)e * FGS_GROW_FLOATS);
+                    dst[0] = make_float4(v_u, v_v, v_ca, v_cbc);
+                    dst[1] = make_float4(v_cd, v_op, v_r, v_g);
+                    dst[2] = make_float4(v_b, v_d, 0.0f, 0.0f);
+                }
             }
         }
         __syncthreads();
@@ -209,49 +259,41 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
     const uint32_t *ranges = reinterpret_cast<const uint32_t *>(saved + p.L.ranges);
     const uint32_t *dup_ids = reinterpret_cast<const uint32_t *>(saved + p.L.dup_ids);
+    const uint32_t *tile_order = reinterpret_cast<const uint32_t *>(saved + p.L.tile_order);
     const float *rec = reinterpret_cast<const float *>(saved + p.L.rec);
     float *pix = reinterpret_cast<float *>(saved + p.L.pix_state);
     if (p.d.use_phase)
-        hipLaunchKernelGGL(k_composite_fwd<true>, dim3(grid), dim3(256), 0, st, (uint32_t)p.tiles,
+        hipLaunchKernelGGL(k_composite_fwd<true>, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles,
                            (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height,
                            p.d.background[0], p.d.background[1], p.d.background[2], p.d.phase_amplitude,
-                           ranges, dup_ids, rec, phase, pix, out_rgb, out_depth);
+                           tile_order, ranges, dup_ids, rec, phase, pix, out_rgb, out_depth);
     else
-        hipLaunchKernelGGL(k_composite_fwd<false>, dim3(grid), dim3(256), 0, st, (uint32_t)p.tiles,
+        hipLaunchKernelGGL(k_composite_fwd<false>, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles,
                            (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height,
                            p.d.background[0], p.d.background[1], p.d.background[2], p.d.phase_amplitude,
-                           ranges, dup_ids, rec, phase, pix, out_rgb, out_depth);
+                           tile_order, ranges, dup_ids, rec, phase, pix, out_rgb, out_depth);
     FGS_LAUNCH_CHECK("k_composite_fwd");
     return FGS_OK;
 }
 
-int fgs_launch_composite_bwd(const FgsPlan &p, const float *color, const float *phase, const char *saved,
-                             char *scratch, const float *g_rgb, const float *g_depth, float *g_color,
-                             float *g_opacity, float *g_phase, hipStream_t st) {
-    (void)color; (void)phase; (void)g_phase;
+int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *saved, char *scratch,
+                             const float *g_rgb, const float *g_depth, float *g_phase, hipStream_t st) {
+    (void)phase; (void)g_phase;
     if (p.d.use_phase) {
         fgs_set_error("phase-blending backward is not implemented in this build");
         return FGS_EUNSUPPORTED;
     }
     const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
-    const size_t BN = (size_t)p.d.batch * p.d.num_gaussians;
-    float *g_mean = reinterpret_cast<float *>(scratch + p.s_gmean);
-    float *g_conic = reinterpret_cast<float *>(scratch + p.s_gconic);
-    float *g_dep = reinterpret_cast<float *>(scratch + p.s_gdepth);
-    hipError_t e;
-    e = hipMemsetAsync(g_mean, 0, BN * 2 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(g_conic, 0, BN * 3 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(g_dep, 0, BN * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(g_color, 0, BN * 3 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(g_opacity, 0, BN * sizeof(float), st);
-    if (e != hipSuccess) { fgs_set_error("memset grads: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
-    const float *pix = reinterpret_cast<const float *>(saved + p.L.pix_state);
-    hipLaunchKernelGGL(k_composite_bwd, dim3(grid), dim3(256), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
+    hipLaunchKernelGGL(k_composite_bwd, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
                        (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0], p.d.background[1],
-                       p.d.background[2], reinterpret_cast<const uint32_t *>(saved + p.L.ranges),
+                       p.d.background[2], (uint32_t)p.L.dup_capacity,
+                       reinterpret_cast<const uint32_t *>(saved + p.L.tile_order),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.ranges),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_ids),
-                       reinterpret_cast<const float *>(saved + p.L.rec), pix, g_rgb, g_depth, g_mean, g_conic,
-                       g_dep, g_color, g_opacity);
+                       reinterpret_cast<const float *>(saved + p.L.rec),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
+                       reinterpret_cast<const float *>(saved + p.L.pix_state), g_rgb, g_depth,
+                       reinterpret_cast<float *>(scratch + p.s_grows));
     FGS_LAUNCH_CHECK("k_composite_bwd");
     return FGS_OK;
 }

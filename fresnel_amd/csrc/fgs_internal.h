@@ -9,6 +9,9 @@
 #define FGS_WAVE 64
 
 // record field indices (saved.rec)
+// gradient-row field indices (scratch.grows): one 12-float row per (tile, Gaussian) duplicate
+enum { G_U = 0, G_V, G_CA, G_CBC, G_CD, G_OP, G_CR, G_CG, G_CB, G_DEPTH, G_PAD0, G_PAD1 };
+#define FGS_GROW_FLOATS 12
 enum { R_U = 0, R_V, R_CA, R_CBC, R_CD, R_OP, R_CR, R_CG, R_CB, R_DEPTH, R_BBX, R_BBY };
 
 struct FgsPlan {
@@ -23,9 +26,7 @@ struct FgsPlan {
     size_t s_vals0, s_vals1;  // uint32 [max(B*N, Dcap)] radix ping/pong payloads (vals of the final pass land in saved.dup_ids)
     size_t s_hist;            // uint32 radix histograms
     size_t s_bsum;            // uint32 block sums for the duplicate-offset scan
-    size_t s_gconic;          // float [B][N][3] composite -> projection gradient hand-off
-    size_t s_gmean;           // float [B][N][2]
-    size_t s_gdepth;          // float [B][N]
+    size_t s_grows;           // float [Dcap][12]: per-duplicate gradient rows (composite bwd -> reduce)
 };
 
 int fgs_make_plan(const FgsDims *dims, FgsPlan *plan);
@@ -50,8 +51,8 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
                        const float *quat, const float *color, const float *opacity, char *saved,
                        hipStream_t st);
 int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
-                           const float *quat, const char *saved, const float *g_mean, const float *g_conic,
-                           const float *g_depth, float *g_pos, float *g_scale, float *g_quat, hipStream_t st);
+                           const float *quat, const char *saved, const float *grad_rows, float *g_pos,
+                           float *g_scale, float *g_quat, float *g_color, float *g_opacity, hipStream_t st);
 
 // Stable LSD radix sort of (key,val) uint32 pairs over `num_segs` independent segments.
 // Segment s covers elements [s*seg_stride, s*seg_stride + len) with len = seg_len (host) or
@@ -68,9 +69,8 @@ size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs);
 int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t st);
 int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, float *out_rgb,
                              float *out_depth, hipStream_t st);
-int fgs_launch_composite_bwd(const FgsPlan &p, const float *color, const float *phase, const char *saved,
-                             char *scratch, const float *g_rgb, const float *g_depth, float *g_color,
-                             float *g_opacity, float *g_phase, hipStream_t st);
+int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *saved, char *scratch,
+                             const float *g_rgb, const float *g_depth, float *g_phase, hipStream_t st);
 int fgs_launch_count_pairs(const FgsPlan &p, const char *saved, uint64_t *out, hipStream_t st);
 
 // ---- small device helpers ----

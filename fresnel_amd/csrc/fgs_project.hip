@@ -142,19 +142,41 @@ __global__ __launch_bounds__(256) void k_project(
     tile_count[idx] = ntiles;
 }
 
-// Projection backward (autograd of DR:98-195 + DR:578-579).  One thread per Gaussian;
-// recomputes the forward intermediates from the inputs (cheaper than saving 60 floats).
+// Gradient-row reduction + projection backward (autograd of DR:98-195 + DR:578-579).
+// One thread per Gaussian, walked in DEPTH-RANK order so that the rows read by neighbouring
+// lanes are neighbours in memory (rows are laid out in emission order).  Sums the Gaussian's
+// contiguous 48-byte gradient rows in a fixed order (deterministic), then chains
+// (dL/dmean2d, dL/dconic, dL/ddepth) to (dL/dpos, dL/dscale, dL/dquat), recomputing the forward
+// intermediates from the inputs (cheaper than saving ~60 floats per Gaussian).
 __global__ __launch_bounds__(256) void k_project_bwd(
-    int32_t total, int32_t N, int32_t num_cameras, const float *__restrict__ cams,
+    int32_t total, int32_t N, int32_t num_cameras, uint32_t dcap, const float *__restrict__ cams,
     const float *__restrict__ pos, const float *__restrict__ scale, const float *__restrict__ quat,
-    const uint32_t *__restrict__ depth_key, const float *__restrict__ g_mean,
-    const float *__restrict__ g_conic, const float *__restrict__ g_depth, float *__restrict__ g_pos,
-    float *__restrict__ g_scale, float *__restrict__ g_quat) {
-    const int32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ order,
+    const uint32_t *__restrict__ dup_off, const uint32_t *__restrict__ tile_count,
+    const float *__restrict__ grad_rows, float *__restrict__ g_pos, float *__restrict__ g_scale,
+    float *__restrict__ g_quat, float *__restrict__ g_color, float *__restrict__ g_opacity) {
+    const int32_t ri = blockIdx.x * 256 + threadIdx.x;
+    if (ri >= total) return;
+    const int32_t b = ri / N;
+    const int32_t idx = b * N + (int32_t)order[ri];
     float gp[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0};
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0;
+    {
+        const uint32_t cnt = tile_count[idx], off = dup_off[idx];
+        for (uint32_t k = 0; k < cnt && off + k < dcap; ++k) {
+            const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * FGS_GROW_FLOATS);
+            const float4 a = r[0], bq = r[1], cq = r[2];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += bq.x; s1.y += bq.y; s1.z += bq.z; s1.w += bq.w;
+            s2.x += cq.x; s2.y += cq.y;
+        }
+    }
+    const float g_mean[2] = {s0.x, s0.y};
+    const float g_conic[3] = {s0.z, s0.w, s1.x};
+    const float g_depth = s2.y;
+    g_opacity[idx] = s1.y;
+    g_color[3 * idx] = s1.z; g_color[3 * idx + 1] = s1.w; g_color[3 * idx + 2] = s2.x;
     if (depth_key[idx] != 0xFFFFFFFFu) {
-        const int32_t b = idx / N;
         const float *__restrict__ V = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
         const float p[3] = {pos[3 * idx], pos[3 * idx + 1], pos[3 * idx + 2]};
         const float s[3] = {scale[3 * idx], scale[3 * idx + 1], scale[3 * idx + 2]};
@@ -166,7 +188,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
         const float ar = o.a + 1e-4f, dr = o.d + 1e-4f;
         const float rdet = 1.0f / (ar * dr - o.b * o.c);
         const float Y[2][2] = {{dr * rdet, -o.b * rdet}, {-o.c * rdet, ar * rdet}};
-        const float GY[2][2] = {{g_conic[3 * idx], g_conic[3 * idx + 1]}, {g_conic[3 * idx + 1], g_conic[3 * idx + 2]}};
+        const float GY[2][2] = {{g_conic[0], g_conic[1]}, {g_conic[1], g_conic[2]}};
         float tmp[2][2], G2[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -205,14 +227,14 @@ __global__ __launch_bounds__(256) void k_project_bwd(
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 GJ[i][j] = (G2[i][0] * JSt[0][j] + G2[i][1] * JSt[1][j]) + (G2[0][i] * JS[0][j] + G2[1][i] * JS[1][j]);
-        const float gu = g_mean[2 * idx], gv = g_mean[2 * idx + 1];
+        const float gu = g_mean[0], gv = g_mean[1];
         const float zs = o.zs, z2 = o.z2, z3 = o.z2 * o.zs;
         const float gxc = GJ[0][2] * fx / z2 + gu * (-fx / zs);
         const float gyc = GJ[1][2] * fy / z2 + gv * (fy / zs);
         const float gzs = GJ[0][0] * fx / z2 + GJ[0][2] * (-2.0f * fx * o.xc / z3) + GJ[1][1] * (-fy / z2) +
                           GJ[1][2] * (-2.0f * fy * o.yc / z3) + gu * (fx * o.xc / z2) + gv * (-fy * o.yc / z2);
         const float dzs = (fabsf(o.zc) >= 0.01f ? sgnf(o.zc) : 0.0f) * sgnf(o.zc + 1e-8f);
-        const float gpc[3] = {gxc, gyc, gzs * dzs - g_depth[idx]};
+        const float gpc[3] = {gxc, gyc, gzs * dzs - g_depth};
 #pragma unroll
         for (int j = 0; j < 3; ++j) gp[j] = V[j] * gpc[0] + V[4 + j] * gpc[1] + V[8 + j] * gpc[2];
         // Sigma = M M^T -> dM = (GS + GS^T) M ; M = Rc diag(s)
@@ -274,15 +296,17 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
 }
 
 int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
-                           const float *quat, const char *saved, const float *g_mean, const float *g_conic,
-                           const float *g_depth, float *g_pos, float *g_scale, float *g_quat,
-                           hipStream_t st) {
+                           const float *quat, const char *saved, const float *grad_rows, float *g_pos,
+                           float *g_scale, float *g_quat, float *g_color, float *g_opacity, hipStream_t st) {
     const int32_t total = p.d.batch * p.d.num_gaussians;
     const int grid = (total + 255) / 256;
     hipLaunchKernelGGL(k_project_bwd, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
-                       p.d.num_cameras, cams, pos, scale, quat,
-                       reinterpret_cast<const uint32_t *>(saved + p.L.depth_key), g_mean, g_conic, g_depth,
-                       g_pos, g_scale, g_quat);
+                       p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat,
+                       reinterpret_cast<const uint32_t *>(saved + p.L.depth_key),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.order),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
+                       g_quat, g_color, g_opacity);
     FGS_LAUNCH_CHECK("k_project_bwd");
     return FGS_OK;
 }

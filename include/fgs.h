@@ -60,8 +60,12 @@ typedef struct FgsSavedLayout {
     size_t depth_key;  /* uint32 [B][N]: order-preserving depth bits, 0xFFFFFFFF = culled */
     size_t tile_count; /* uint32 [B][N]: tiles touched (0 = culled or empty bbox)         */
     size_t order;      /* uint32 [B][N]: Gaussian ids in canonical depth order (DR:527)   */
+    size_t dup_off;    /* uint32 [B][N]: first duplicate slot of each Gaussian (emission
+                                         order = image, depth rank, tile row, tile column)   */
     size_t counters;   /* uint32 [16]: [0] total duplicates D, [1] overflow flag          */
     size_t ranges;     /* uint32 [B*T][2]: [start,end) into dup_ids per (image,tile)      */
+    size_t tile_order; /* uint32 [B*T]: (image,tile) indices, longest lists first: the launch
+                                         order of the composite kernels (scheduling only)    */
     size_t dup_ids;    /* uint32 [Dcap]: b*N+n per duplicate, sorted by (image,tile), depth
                                          order inside a tile                              */
     size_t pix_state;  /* float  [B][6][H][W]: C_r,C_g,C_b (pre-bg, pre-clamp), A, D, Phi */
