@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Training harness around the HIP rasterizer: this repo's counterpart of the reference's
+scripts/training/train_gaussian_decoder.py ("TGD") for the path BASELINE.json names.
+
+Kept from TGD (same flag names / defaults / behaviour):
+  flags             --experiment --data_dir --output_dir --batch_size --epochs --lr --image_size
+                    --gaussians_per_patch --max_images --use_fresnel_zones --num_fresnel_zones
+                    --use_phase_blending --phase_amplitude --resume            TGD:1401-1545
+  renderer choice   TileBasedRenderer(res, res, use_phase_blending, phase_amplitude)   TGD:1898-1907
+  camera            fx = fy = 0.8*res, cx = cy = res/2, view = I                       TGD:1910-1917
+  step              decoder -> render -> stack -> L1 + normalised-depth L1 (SSIM / LPIPS only when
+                    those packages exist, as TGD:53-65) -> NaN/Inf skip -> backward ->
+                    clip_grad_norm_(1.0) -> AdamW(lr, weight_decay=1e-5) ; CosineAnnealingLR
+                                                                    TGD:890, 922-930, 1255-1266, 1970-1971
+  checkpoints       {epoch, model_state_dict, optimizer_state_dict, losses, config}    TGD:1304-1310
+Changed on purpose:
+  * the per-image Python loop TGD:1209-1223 becomes ONE batched renderer call;
+  * image-wise data parallelism: one process per GPU, the batch is sharded by image and the
+    decoder gradients are all-reduced once per step over RCCL (fresnel_amd/dist.py);
+  * no dataset tooling: without --data_dir caches the harness fabricates images/features like
+    TGD:1748-1758 / TGD:613-630 do when files are missing.
+
+    python -m fresnel_amd.train --experiment 2 --epochs 1                      # 1 GPU
+    python -m torch.distributed.run --nproc-per-node 8 -m fresnel_amd.train    # 8 GPUs, DP
+"""
+import argparse
+import math
+import os
+from dataclasses import asdict, dataclass
+from pathlib import Path
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch.optim import AdamW
+from torch.optim.lr_scheduler import CosineAnnealingLR
+
+from .decoder import PatchGaussianDecoder
+from .dist import DPContext
+
+try:  # optional perceptual losses, exactly like TGD:53-65
+    from pytorch_msssim import ssim as ssim_fn
+    SSIM_AVAILABLE = True
+except ImportError:
+    SSIM_AVAILABLE = False
+
+
+@dataclass
+class TrainingConfig:  # subset of TGD:97-162 that this path uses; same names and defaults
+    experiment: int = 2
+    data_dir: str = "images"
+    output_dir: str = "checkpoints"
+    batch_size: int = 4
+    epochs: int = 100
+    lr: float = 1e-4
+    weight_decay: float = 1e-5
+    image_size: int = 256
+    feature_size: int = 37
+    feature_dim: int = 384
+    rgb_weight: float = 1.0
+    depth_weight: float = 0.1
+    ssim_weight: float = 0.5
+    gaussians_per_patch: int = 4
+    max_images: Optional[int] = None
+    use_fresnel_zones: bool = False
+    num_fresnel_zones: int = 8
+    use_phase_blending: bool = False
+    phase_amplitude: float = 0.25
+    device: str = "cuda" if torch.cuda.is_available() else "cpu"
+    log_interval: int = 10
+    save_interval: int = 10
+    seed: int = 0
+    steps_per_epoch: int = 8  # synthetic-data mode only
+
+
+class SyntheticDataset:
+    """Stand-in for TGD's ImageDataset when no caches exist: random images, zero-mean random
+    features, smooth random depth (TGD:613-630 returns zero features/depth for missing caches;
+    TGD:1748-1758 fabricates random PNGs).  Deterministic in the GLOBAL sample index so every DP
+    configuration sees the same data."""
+
+    def __init__(self, n_items, cfg: TrainingConfig):
+        self.n, self.cfg = n_items, cfg
+
+    def get(self, idx):
+        g = torch.Generator().manual_seed(self.cfg.seed * 1_000_003 + idx)
+        S, Fs = self.cfg.image_size, self.cfg.feature_size
+        low = torch.rand(3, 8, 8, generator=g)
+        image = F.interpolate(low[None], size=(S, S), mode="bilinear", align_corners=False)[0]
+        feats = torch.randn(Fs, Fs, self.cfg.feature_dim, generator=g) * 0.5
+        dlow = torch.rand(1, 4, 4, generator=g)
+        depth = F.interpolate(dlow[None], size=(S, S), mode="bilinear", align_corners=False)[0]
+        return image, feats, depth
+
+    def batch(self, indices, device):
+        items = [self.get(i) for i in indices]
+        return tuple(torch.stack(t).to(device) for t in zip(*items))
+
+
+def compute_losses(rendered, target, rendered_depth, target_depth, cfg: TrainingConfig):
+    """L1 + (1-SSIM if available) + normalised depth L1 (TGD:890, 906-930)."""
+    d: Dict[str, float] = {}
+    rgb = F.l1_loss(rendered, target)
+    d["rgb"] = float(rgb.detach())
+    total = cfg.rgb_weight * rgb
+    if SSIM_AVAILABLE and cfg.ssim_weight > 0:
+        s = 1.0 - ssim_fn(torch.clamp(rendered, 0, 1), target, data_range=1.0, size_average=True)
+        d["ssim"] = float(s.detach())
+        total = total + cfg.ssim_weight * s
+    if rendered_depth is not None and target_depth is not None:
+        rd_std = torch.clamp(rendered_depth.std(), min=1e-4)
+        td_std = torch.clamp(target_depth.std(), min=1e-4)
+        dl = F.l1_loss((rendered_depth - rendered_depth.mean()) / rd_std,
+                       (target_depth - target_depth.mean()) / td_std)
+        d["depth"] = float(dl.detach())
+        total = total + cfg.depth_weight * dl
+    d["total"] = float(total.detach())
+    return total, d
+
+
+def default_renderer_factory(cfg: TrainingConfig, device):
+    """The product renderer: HIP TileBasedRenderer + the reference camera (TGD:1898-1917)."""
+    from .renderer import Camera, TileBasedRenderer
+    res = cfg.image_size
+    renderer = TileBasedRenderer(res, res, use_phase_blending=cfg.use_phase_blending,
+                                 phase_amplitude=cfg.phase_amplitude).to(device)
+    camera = Camera(fx=res * 0.8, fy=res * 0.8, cx=res / 2, cy=res / 2, width=res, height=res)
+    return renderer, camera
+
+
+def train_step(model, renderer, camera, batch, optimizer, cfg: TrainingConfig, dp: DPContext):
+    """One optimizer step on this rank's image shard.  Returns (loss_dict | None if skipped)."""
+    images, feats, depth = batch
+    out = model(feats, depth)
+    phases = out.get("phases") if cfg.use_phase_blending else None
+    # ONE batched call replaces the per-image loop of TGD:1209-1223
+    rendered, rdepth = renderer(out["positions"], out["scales"], out["rotations"], out["colors"],
+                                out["opacities"], camera, return_depth=True, phases=phases)
+    res = cfg.image_size
+    target = F.interpolate(images, size=(res, res), mode="bilinear", align_corners=False)
+    tdepth = F.interpolate(depth, size=(res, res), mode="bilinear", align_corners=False).squeeze(1)
+    loss, ld = compute_losses(rendered, target, rdepth, tdepth, cfg)
+    bad = bool(torch.isnan(loss) or torch.isinf(loss))
+    if dp.any_true(bad, loss.device):  # collective NaN/Inf skip (TGD:1255-1258)
+        optimizer.zero_grad()
+        return None
+    optimizer.zero_grad()
+    loss.backward()
+    dp.allreduce_gradients(list(model.parameters()))
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)  # TGD:1264
+    optimizer.step()
+    ld["total"] = dp.mean_scalar(ld["total"], loss.device)
+    return ld
+
+
+def save_checkpoint(model, optimizer, epoch, losses, cfg: TrainingConfig):
+    os.makedirs(cfg.output_dir, exist_ok=True)
+    ckpt = {"epoch": epoch, "model_state_dict": model.state_dict(),
+            "optimizer_state_dict": optimizer.state_dict(), "losses": losses, "config": asdict(cfg)}
+    path = Path(cfg.output_dir) / f"decoder_exp{cfg.experiment}_epoch{epoch}.pt"
+    torch.save(ckpt, path)
+    return path
+
+
+def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
+                 renderer_factory: Callable = default_renderer_factory, resume: Optional[str] = None,
+                 log=print):
+    device = torch.device(cfg.device)
+    dp = dp or DPContext(device=device if device.type == "cuda" else None)
+    torch.manual_seed(cfg.seed)
+    model = PatchGaussianDecoder(cfg.feature_dim, cfg.gaussians_per_patch, grid=cfg.feature_size,
+                                 use_fresnel_zones=cfg.use_fresnel_zones,
+                                 num_fresnel_zones=cfg.num_fresnel_zones,
+                                 use_phase_output=cfg.use_phase_blending).to(device)
+    dp.broadcast_parameters(model)
+    renderer, camera = renderer_factory(cfg, device)
+    optimizer = AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+    scheduler = CosineAnnealingLR(optimizer, T_max=cfg.epochs)
+    start_epoch = 0
+    if resume:
+        ck = torch.load(resume, map_location=device)
+        model.load_state_dict(ck["model_state_dict"])
+        optimizer.load_state_dict(ck["optimizer_state_dict"])
+        start_epoch = ck["epoch"] + 1
+    n_items = cfg.max_images or cfg.batch_size * cfg.steps_per_epoch
+    data = SyntheticDataset(n_items, cfg)
+    history = []
+    for epoch in range(start_epoch, cfg.epochs):
+        model.train()
+        sums, nb = {}, 0
+        for bi in range(0, n_items - cfg.batch_size + 1, cfg.batch_size):
+            lo, hi = dp.shard(cfg.batch_size)  # image-wise shard of the global batch
+            idx = list(range(bi + lo, bi + hi))
+            ld = train_step(model, renderer, camera, data.batch(idx, device), optimizer, cfg, dp)
+            if ld is None:
+                if dp.rank == 0:
+                    log(f"  Warning: NaN/Inf loss at batch {bi // cfg.batch_size}, skipping")
+                continue
+            for k, v in ld.items():
+                sums[k] = sums.get(k, 0.0) + v
+            nb += 1
+            if dp.rank == 0 and (bi // cfg.batch_size) % cfg.log_interval == 0:
+                log(f"  Batch {bi // cfg.batch_size} | Loss: {ld['total']:.4f} | RGB: {ld['rgb']:.4f}")
+        scheduler.step()
+        losses = {k: v / max(nb, 1) for k, v in sums.items()}
+        history.append(losses)
+        if dp.rank == 0:
+            log(f"Epoch {epoch + 1}/{cfg.epochs} | " + " ".join(f"{k}={v:.4f}" for k, v in losses.items()))
+            if (epoch + 1) % cfg.save_interval == 0 or epoch + 1 == cfg.epochs:
+                save_checkpoint(model, optimizer, epoch, losses, cfg)
+    return model, history
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Train the Gaussian decoder through the HIP rasterizer")
+    c = TrainingConfig()
+    ap.add_argument("--experiment", type=int, default=c.experiment)
+    ap.add_argument("--data_dir", default=c.data_dir)
+    ap.add_argument("--output_dir", default=c.output_dir)
+    ap.add_argument("--batch_size", type=int, default=c.batch_size)
+    ap.add_argument("--epochs", type=int, default=c.epochs)
+    ap.add_argument("--lr", type=float, default=c.lr)
+    ap.add_argument("--image_size", type=int, default=c.image_size)
+    ap.add_argument("--gaussians_per_patch", type=int, default=c.gaussians_per_patch)
+    ap.add_argument("--max_images", type=int, default=None)
+    ap.add_argument("--use_fresnel_zones", type=int, nargs="?", const=8, default=0,
+                    help="quantise depth into N zones (TGD flag; bare flag = 8)")
+    ap.add_argument("--num_fresnel_zones", type=int, default=c.num_fresnel_zones)
+    ap.add_argument("--use_phase_blending", action="store_true")
+    ap.add_argument("--phase_amplitude", type=float, default=c.phase_amplitude)
+    ap.add_argument("--resume", default=None)
+    ap.add_argument("--renderer", default="hip", choices=["hip"],
+                    help="only the HIP rasterizer ships; there is no CPU fallback")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.experiment != 2:
+        raise SystemExit("only --experiment 2 (direct patch decoder) is on this repo's hot path")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("fresnel_amd.train needs a GPU: the HIP rasterizer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    cfg = TrainingConfig(experiment=a.experiment, data_dir=a.data_dir, output_dir=a.output_dir,
+                         batch_size=a.batch_size, epochs=a.epochs, lr=a.lr, image_size=a.image_size,
+                         gaussians_per_patch=a.gaussians_per_patch, max_images=a.max_images,
+                         use_fresnel_zones=bool(a.use_fresnel_zones),
+                         num_fresnel_zones=a.use_fresnel_zones or a.num_fresnel_zones,
+                         use_phase_blending=a.use_phase_blending, phase_amplitude=a.phase_amplitude,
+                         device=f"cuda:{local_rank}", seed=a.seed)
+    dp = DPContext(device=torch.device(cfg.device))
+    try:
+        run_training(cfg, dp, resume=a.resume)
+    finally:
+        dp.shutdown()
+
+
+if __name__ == "__main__":
+    main()
