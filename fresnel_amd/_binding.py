@@ -35,7 +35,8 @@ class FgsSavedLayout(ctypes.Structure):
                 ("depth_key", ctypes.c_size_t), ("tile_count", ctypes.c_size_t),
                 ("order", ctypes.c_size_t), ("dup_off", ctypes.c_size_t), ("counters", ctypes.c_size_t),
                 ("ranges", ctypes.c_size_t), ("tile_order", ctypes.c_size_t), ("dup_ids", ctypes.c_size_t),
-                ("pix_state", ctypes.c_size_t), ("dup_capacity", ctypes.c_size_t),
+                ("pix_state", ctypes.c_size_t), ("phase_ckpt", ctypes.c_size_t),
+                ("dup_capacity", ctypes.c_size_t),
                 ("tiles_x", ctypes.c_int32), ("tiles_y", ctypes.c_int32)]
 
 

@@ -93,6 +93,8 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p) {
     L.tile_order = o; o = align256(o + B * p->tiles * 4);
     L.dup_ids = o; o = align256(o + dcap * 4);
     L.pix_state = o; o = align256(o + B * 6 * (size_t)d->width * d->height * 4);
+    L.phase_ckpt = o;
+    if (d->use_phase) o = align256(o + (dcap / FGS_PHASE_CKPT + B * p->tiles + 2) * 8 * 64 * 4);
     L.total_bytes = o;
     L.dup_capacity = dcap;
     L.tiles_x = tx; L.tiles_y = ty;
@@ -207,7 +209,7 @@ int fgs_backward(const FgsDims *dims, const float *cameras, const float *pos, co
     fgs_stage_begin(ST_PROJECT_BWD, st);
     if ((rc = fgs_launch_project_bwd(p, cameras, pos, scale, quat, sv,
                                      reinterpret_cast<const float *>(sc + p.s_grows), g_pos, g_scale, g_quat,
-                                     g_color, g_opacity, st)))
+                                     g_color, g_opacity, p.d.use_phase ? g_phase : nullptr, st)))
         return rc;
     fgs_stage_end(ST_PROJECT_BWD, st);
     return FGS_OK;

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(64) void k_composite_fwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
-    float *__restrict__ pix_state, float *__restrict__ out_rgb, float *__restrict__ out_depth) {
+    float *__restrict__ pix_state, float *__restrict__ phase_ckpt, float *__restrict__ out_rgb,
+    float *__restrict__ out_depth) {
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ float shp[CH];
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
@@ -94,6 +95,13 @@ __global__ __launch_bounds__(64) void k_composite_fwd(
         }
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
+            if (PHASE && (j % FGS_PHASE_CKPT) == 0) {
+                // (A, Phi) before list entry (base - start + j): the backward restarts from here
+                const size_t slot = (size_t)(c.start / FGS_PHASE_CKPT) + (base - c.start + j) / FGS_PHASE_CKPT + c.tile;
+                float *ck = phase_ckpt + slot * 512 + lane;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { ck[s * 64] = A[s]; ck[(4 + s) * 64] = Ph[s]; }
+            }
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
             const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
             const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
@@ -252,6 +260,203 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     }
 }
 
+// eleven-value variant (adds dL/dphase) for the phase path
+__device__ __forceinline__ void wave_sum11_lane63(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
+                                                  float &a6, float &a7, float &a8, float &a9, float &a10) {
+#define FGS_STEP(ctrl)                                                                                     \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n v_add_f32_dpp %1, %1, %1 " ctrl "\n v_add_f32_dpp %2, %2, %2 " ctrl  \
+    "\n v_add_f32_dpp %3, %3, %3 " ctrl "\n v_add_f32_dpp %4, %4, %4 " ctrl "\n v_add_f32_dpp %5, %5, %5 " ctrl \
+    "\n v_add_f32_dpp %6, %6, %6 " ctrl "\n v_add_f32_dpp %7, %7, %7 " ctrl "\n v_add_f32_dpp %8, %8, %8 " ctrl \
+    "\n v_add_f32_dpp %9, %9, %9 " ctrl "\n v_add_f32_dpp %10, %10, %10 " ctrl "\n"
+    asm volatile("s_nop 1\n" FGS_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 FGS_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 FGS_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 FGS_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 FGS_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 FGS_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
+                   "+v"(a9), "+v"(a10));
+#undef FGS_STEP
+}
+
+// Phase-blending backward (the reference cannot backprop this path at
+// all, §0.6 -- the contract is the exact adjoint of the forward recurrence DR:629-667).
+// alpha_i depends on the running weighted-mean phase Phi_{i-1}, so the recurrence cannot be
+// inverted back-to-front: the forward stores (A, Phi) per pixel every FGS_PHASE_CKPT list
+// entries; this kernel walks the list in REVERSE sub-chunks, re-runs the forward inside each
+// sub-chunk from its checkpoint (parking (A_{i-1}, Phi_{i-1}) per entry in LDS), then sweeps
+// the sub-chunk back-to-front with the per-pixel adjoints Abar (init -gI.bg) and Phibar.
+__global__ __launch_bounds__(64) void k_composite_bwd_phase(
+    uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
+    uint32_t dcap, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
+    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
+    const uint32_t *__restrict__ dup_off, const float *__restrict__ pix_state,
+    const float *__restrict__ phase_ckpt, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
+    float *__restrict__ grad_rows) {
+    constexpr int PCK = FGS_PHASE_CKPT;
+    __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
+    __shared__ float shp[CH];
+    __shared__ uint32_t she[CH];
+    __shared__ float2 st[PCK][4][64];
+    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const size_t HW = (size_t)W * H;
+    float gr[4], gg[4], gb[4], gd[4], Abar[4], Pbar[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
+        gr[s] = gg[s] = gb[s] = gd[s] = 0.0f;
+        Abar[s] = 0.0f; Pbar[s] = 0.0f;
+        if (px < W && py < H) {
+            const size_t o = (size_t)py * W + px;
+            const float *ps = pix_state + (size_t)c.b * 6 * HW + o;
+            const float Tf = 1.0f - ps[3 * HW];
+            const float pr = ps[0] + Tf * bg0, pg = ps[HW] + Tf * bg1, pb = ps[2 * HW] + Tf * bg2;
+            const float *gi = g_rgb + (size_t)c.b * 3 * HW + o;
+            gr[s] = (pr >= 0.0f && pr <= 1.0f) ? gi[0] : 0.0f;
+            gg[s] = (pg >= 0.0f && pg <= 1.0f) ? gi[HW] : 0.0f;
+            gb[s] = (pb >= 0.0f && pb <= 1.0f) ? gi[2 * HW] : 0.0f;
+            gd[s] = g_depth[(size_t)c.b * HW + o];
+            Abar[s] = -(gr[s] * bg0 + gg[s] * bg1 + gb[s] * bg2);  // d/dA of (1 - A) * bg
+        }
+    }
+    const uint32_t total = c.end - c.start;
+    const uint32_t nchunks = (total + CH - 1) / CH;
+    for (uint32_t ci = nchunks; ci-- > 0;) {
+        const uint32_t base = c.start + ci * CH;
+        const uint32_t n = min((uint32_t)CH, c.end - base);
+        if (lane < n) {
+            const uint32_t gid = dup_ids[base + lane];
+            const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
+            const float4 q2 = r[2];
+            sh0[lane] = r[0]; sh1[lane] = r[1]; sh2[lane] = q2;
+            shp[lane] = phase[gid];
+            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
+            const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
+            const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE;
+            she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
+        }
+        __syncthreads();
+        const uint32_t nsub = (n + PCK - 1) / PCK;
+        for (uint32_t si = nsub; si-- > 0;) {
+            const uint32_t j0 = si * PCK;
+            const uint32_t m = min((uint32_t)PCK, n - j0);
+            const size_t slot = (size_t)(c.start / PCK) + (ci * CH + j0) / PCK + c.tile;
+            const float *ck = phase_ckpt + slot * 512 + lane;
+            float Af[4], Pf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { Af[s] = ck[s * 64]; Pf[s] = ck[(4 + s) * 64]; }
+            // ---- forward re-run of the sub-chunk: park (A_{i-1}, Phi_{i-1}) ----
+            for (uint32_t k = 0; k < m; ++k) {
+                const uint32_t j = j0 + k;
+                const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
+                const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+                const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
+                const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
+                const float ph = shp[j];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t sx = c.X0 + 8u * (s & 1), sy = c.Y0 + 8u * (s >> 1);
+                    if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) continue;
+                    st[k][s][lane] = make_float2(Af[s], Pf[s]);
+                    const uint32_t px = sx + lx, py = sy + ly;
+                    const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
+                    const float dx = (float)px - q0.x, dy = (float)py - q0.y;
+                    const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
+                    float alpha = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E) * q1.y;
+                    float pd = fabsf(ph - Pf[s]);
+                    pd = fminf(pd, 1.0f - pd);
+                    alpha *= (1.0f - amp) + amp * __cosf(pd * PHASE_KAPPA);
+                    alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
+                    alpha = in ? alpha : 0.0f;
+                    const float w = alpha * (1.0f - Af[s]);
+                    Af[s] += w;
+                    const float pc = w / fmaxf(Af[s], 1e-6f);
+                    Pf[s] = in ? (Pf[s] * (1.0f - pc) + ph * pc) : Pf[s];
+                }
+            }
+            // ---- reverse sweep of the sub-chunk ----
+            for (uint32_t k = m; k-- > 0;) {
+                const uint32_t j = j0 + k;
+                const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
+                const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
+                const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
+                const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
+                const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;
+                const float ph = shp[j];
+                float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0,
+                      v_ph = 0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t sx = c.X0 + 8u * (s & 1), sy = c.Y0 + 8u * (s >> 1);
+                    if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) continue;
+                    const float2 sv = st[k][s][lane];
+                    const float Aprev = sv.x, Pprev = sv.y;
+                    const uint32_t px = sx + lx, py = sy + ly;
+                    const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
+                    const float dx = (float)px - q0.x, dy = (float)py - q0.y;
+                    const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
+                    const float G = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E);
+                    const float dphi = ph - Pprev;
+                    const float pd0 = fabsf(dphi);
+                    const float pd = fminf(pd0, 1.0f - pd0);
+                    const float inter = (1.0f - amp) + amp * __cosf(pd * PHASE_KAPPA);
+                    const float raw = (G * op) * inter;
+                    const float alpha = in ? fminf(fmaxf(raw, 0.0f), 0.99f) : 0.0f;
+                    const float T = 1.0f - Aprev;
+                    const float w = alpha * T;
+                    const float Ai = Aprev + w;
+                    const float Aic = fmaxf(Ai, 1e-6f);
+                    const float rA = __builtin_amdgcn_rcpf(Aic);
+                    const float pc = w * rA;
+                    const float Pb = in ? Pbar[s] : 0.0f;
+                    v_ph += Pb * pc;
+                    const float pcbar = Pb * dphi;
+                    // d pc/d w, direct (1/A_i) plus through A_i (-w/A_i^2), equals A_{i-1}/A_i^2: kept in that
+                    // cancellation-free form (the two parts cancel to ~0 for a pixel's first contribution)
+                    float Ab = Abar[s];
+                    float wbar = Ab + (gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y);
+                    if (Ai >= 1e-6f) {
+                        wbar += pcbar * Aprev * rA * rA;
+                        Ab -= pcbar * w * rA * rA;
+                    } else {
+                        wbar += pcbar * rA;
+                    }
+                    v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
+                    const float abar = wbar * T;
+                    Ab -= wbar * alpha;
+                    const float rbar = (in && raw >= 0.0f && raw <= 0.99f) ? abar : 0.0f;
+                    v_op += rbar * G * inter;
+                    const float pdbar = -(rbar * G * op) * amp * PHASE_KAPPA * __sinf(PHASE_KAPPA * pd);
+                    const float pd0bar = (pd0 < 1.0f - pd0) ? pdbar : ((pd0 > 1.0f - pd0) ? -pdbar : 0.0f);
+                    const float sg = (dphi > 0.0f) ? 1.0f : ((dphi < 0.0f) ? -1.0f : 0.0f);
+                    v_ph += pd0bar * sg;
+                    if (in) {
+                        Pbar[s] = Pb * (1.0f - pc) - pd0bar * sg;
+                        Abar[s] = Ab;
+                    }
+                    const float dm = -0.5f * (rbar * op * inter) * G;
+                    v_ca += dm * dx * dx; v_cbc += dm * dx * dy; v_cd += dm * dy * dy;
+                    v_u -= dm * (2.0f * ca * dx + cbc * dy);
+                    v_v -= dm * (cbc * dx + 2.0f * cd * dy);
+                }
+                wave_sum11_lane63(v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d, v_ph);
+                if (lane == 63) {
+                    const uint32_t e = she[j];
+                    if (e < dcap) {
+                        float4 *dst = reinterpret_cast<float4 *>(grad_rows + (size_t)e * FGS_GROW_FLOATS);
+                        dst[0] = make_float4(v_u, v_v, v_ca, v_cbc);
+                        dst[1] = make_float4(v_cd, v_op, v_r, v_g);
+                        dst[2] = make_float4(v_b, v_d, v_ph, 0.0f);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, float *out_rgb,
@@ -266,24 +471,36 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
         hipLaunchKernelGGL(k_composite_fwd<true>, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles,
                            (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height,
                            p.d.background[0], p.d.background[1], p.d.background[2], p.d.phase_amplitude,
-                           tile_order, ranges, dup_ids, rec, phase, pix, out_rgb, out_depth);
+                           tile_order, ranges, dup_ids, rec, phase, pix,
+                           reinterpret_cast<float *>(saved + p.L.phase_ckpt), out_rgb, out_depth);
     else
         hipLaunchKernelGGL(k_composite_fwd<false>, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles,
                            (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height,
                            p.d.background[0], p.d.background[1], p.d.background[2], p.d.phase_amplitude,
-                           tile_order, ranges, dup_ids, rec, phase, pix, out_rgb, out_depth);
+                           tile_order, ranges, dup_ids, rec, phase, pix, nullptr, out_rgb, out_depth);
     FGS_LAUNCH_CHECK("k_composite_fwd");
     return FGS_OK;
 }
 
 int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *saved, char *scratch,
                              const float *g_rgb, const float *g_depth, float *g_phase, hipStream_t st) {
-    (void)phase; (void)g_phase;
-    if (p.d.use_phase) {
-        fgs_set_error("phase-blending backward is not implemented in this build");
-        return FGS_EUNSUPPORTED;
-    }
+    (void)g_phase;  // dL/dphase travels in the gradient rows and is written by k_project_bwd
     const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
+    if (p.d.use_phase) {
+        hipLaunchKernelGGL(k_composite_bwd_phase, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles,
+                           (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],
+                           p.d.background[1], p.d.background[2], p.d.phase_amplitude, (uint32_t)p.L.dup_capacity,
+                           reinterpret_cast<const uint32_t *>(saved + p.L.tile_order),
+                           reinterpret_cast<const uint32_t *>(saved + p.L.ranges),
+                           reinterpret_cast<const uint32_t *>(saved + p.L.dup_ids),
+                           reinterpret_cast<const float *>(saved + p.L.rec), phase,
+                           reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
+                           reinterpret_cast<const float *>(saved + p.L.pix_state),
+                           reinterpret_cast<const float *>(saved + p.L.phase_ckpt), g_rgb, g_depth,
+                           reinterpret_cast<float *>(scratch + p.s_grows));
+        FGS_LAUNCH_CHECK("k_composite_bwd_phase");
+        return FGS_OK;
+    }
     hipLaunchKernelGGL(k_composite_bwd, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
                        (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0], p.d.background[1],
                        p.d.background[2], (uint32_t)p.L.dup_capacity,

@@ -10,7 +10,7 @@
 
 // record field indices (saved.rec)
 // gradient-row field indices (scratch.grows): one 12-float row per (tile, Gaussian) duplicate
-enum { G_U = 0, G_V, G_CA, G_CBC, G_CD, G_OP, G_CR, G_CG, G_CB, G_DEPTH, G_PAD0, G_PAD1 };
+enum { G_U = 0, G_V, G_CA, G_CBC, G_CD, G_OP, G_CR, G_CG, G_CB, G_DEPTH, G_PHASE, G_PAD1 };
 #define FGS_GROW_FLOATS 12
 enum { R_U = 0, R_V, R_CA, R_CBC, R_CD, R_OP, R_CR, R_CG, R_CB, R_DEPTH, R_BBX, R_BBY };
 
@@ -52,7 +52,8 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
                        hipStream_t st);
 int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                            const float *quat, const char *saved, const float *grad_rows, float *g_pos,
-                           float *g_scale, float *g_quat, float *g_color, float *g_opacity, hipStream_t st);
+                           float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
+                           hipStream_t st);
 
 // Stable LSD radix sort of (key,val) uint32 pairs over `num_segs` independent segments.
 // Segment s covers elements [s*seg_stride, s*seg_stride + len) with len = seg_len (host) or

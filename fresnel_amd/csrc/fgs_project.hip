@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ dup_off, const uint32_t *__restrict__ tile_count,
     const float *__restrict__ grad_rows, float *__restrict__ g_pos, float *__restrict__ g_scale,
-    float *__restrict__ g_quat, float *__restrict__ g_color, float *__restrict__ g_opacity) {
+    float *__restrict__ g_quat, float *__restrict__ g_color, float *__restrict__ g_opacity,
+    float *__restrict__ g_phase) {
     const int32_t ri = blockIdx.x * 256 + threadIdx.x;
     if (ri >= total) return;
     const int32_t b = ri / N;
@@ -168,13 +169,14 @@ __global__ __launch_bounds__(256) void k_project_bwd(
             const float4 a = r[0], bq = r[1], cq = r[2];
             s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
             s1.x += bq.x; s1.y += bq.y; s1.z += bq.z; s1.w += bq.w;
-            s2.x += cq.x; s2.y += cq.y;
+            s2.x += cq.x; s2.y += cq.y; s2.z += cq.z;
         }
     }
     const float g_mean[2] = {s0.x, s0.y};
     const float g_conic[3] = {s0.z, s0.w, s1.x};
     const float g_depth = s2.y;
     g_opacity[idx] = s1.y;
+    if (g_phase) g_phase[idx] = s2.z;
     g_color[3 * idx] = s1.z; g_color[3 * idx + 1] = s1.w; g_color[3 * idx + 2] = s2.x;
     if (depth_key[idx] != 0xFFFFFFFFu) {
         const float *__restrict__ V = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
@@ -297,7 +299,8 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
 
 int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                            const float *quat, const char *saved, const float *grad_rows, float *g_pos,
-                           float *g_scale, float *g_quat, float *g_color, float *g_opacity, hipStream_t st) {
+                           float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
+                           hipStream_t st) {
     const int32_t total = p.d.batch * p.d.num_gaussians;
     const int grid = (total + 255) / 256;
     hipLaunchKernelGGL(k_project_bwd, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
@@ -306,7 +309,7 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
                        reinterpret_cast<const uint32_t *>(saved + p.L.order),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                       g_quat, g_color, g_opacity);
+                       g_quat, g_color, g_opacity, g_phase);
     FGS_LAUNCH_CHECK("k_project_bwd");
     return FGS_OK;
 }

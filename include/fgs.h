@@ -32,6 +32,7 @@ extern "C" {
 #define FGS_EUNSUPPORTED (-3)
 
 #define FGS_TILE 16        /* tile edge in pixels */
+#define FGS_PHASE_CKPT 8   /* list entries between (A, Phi) checkpoints on the phase path */
 #define FGS_CAMERA_FLOATS 24
 
 /* Problem shape.  Mirrors TileBasedRenderer.__init__ (DR:434-450). */
@@ -69,6 +70,8 @@ typedef struct FgsSavedLayout {
     size_t dup_ids;    /* uint32 [Dcap]: b*N+n per duplicate, sorted by (image,tile), depth
                                          order inside a tile                              */
     size_t pix_state;  /* float  [B][6][H][W]: C_r,C_g,C_b (pre-bg, pre-clamp), A, D, Phi */
+    size_t phase_ckpt; /* float  [slots][8][64] (use_phase only): per-pixel (A, Phi) of a tile at
+                          the start of every 8th list entry; slot = start/8 + chunk + tile        */
     size_t dup_capacity; /* Dcap (elements, not bytes)                                    */
     int32_t tiles_x, tiles_y;
 } FgsSavedLayout;

@@ -262,3 +262,69 @@ def test_full_size_properties_config3_shape():
     stp = _hip_stages([a[perm][None] for a in arrs], cam, S, S)
     assert np.abs(stp["image"] - st1["image"]).max() <= 1e-5
     assert np.abs(stp["depth"] - st1["depth"]).max() <= 1e-4 * np.abs(st1["depth"]).max()
+
+
+# ------------------------------------------------------------------------------------------
+# Phase-blending path (BASELINE config 4: --use_fresnel_zones 8 --use_phase_blending)
+# ------------------------------------------------------------------------------------------
+def test_golden_g6_phase_forward_and_backward():
+    """Forward vs the REFERENCE (DR:629-667); colour gradient vs the reference's own autograd
+    (the only backward it can produce); all gradients incl. dL/dphase vs the
+    fixture's out-of-place restatement (which reproduced the reference forward exactly)."""
+    g = load_golden("G6_phase256_128")
+    W, H = [int(v) for v in g["size"]]
+    arrs = [g[k] for k in ["positions", "scales", "rotations", "colors", "opacities"]]
+    out = _hip_render(arrs, _camera_from_golden(g), W, H, g["background"], phases=g["phases"],
+                      use_phase=True, amp=float(g["phase_amplitude"]), grads=(g["gI"], g["gD"]))
+    assert rel_to_max(out["image"], g["image"]) <= TOL
+    assert rel_to_max(out["depth"], g["depth"]) <= TOL
+    assert rel_to_max(out["grad_colors"], g["ref_grad_colors"]) <= TOL
+    for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
+        assert rel_to_max(out["grad_" + k], g["restated_grad_" + k]) <= TOL, k
+
+
+def test_phase_zone_depths_batched_vs_oracle():
+    """Config-4 style input: depths snapped to 8 zone centres (massive sort ties -> canonical
+    stable order), edge-aware scale factors, scalar phases, amp 0.25; B=2, ragged frame."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    W, H, N, Bn = 144, 112, 1500, 2
+    rs = np.random.RandomState(44)
+    per = []
+    for b in range(Bn):
+        pos, scale, quat, col, opa = synth_aniso(N, 50 + b, opacity_max=1.0, smin=0.02, smax=0.09)
+        zone = rs.randint(0, 8, N)
+        pos[:, 2] = (-2.0 - 2.0 * (zone + 0.5) / 8.0).astype(np.float32)
+        scale = (scale * rs.uniform(0.5, 1.0, (N, 1))).astype(np.float32)
+        per.append((pos, scale, quat, col, opa))
+    arrs = [np.stack([p[i] for p in per]) for i in range(5)]
+    phases = rs.random_sample((Bn, N)).astype(np.float32)
+    cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    gI = rs.standard_normal((Bn, 3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((Bn, H, W)) * 0.1).astype(np.float32)
+    out = _hip_render(arrs, cam, W, H, (0.05, 0.1, 0.15), phases=phases, use_phase=True, amp=0.25, grads=(gI, gD))
+    for b in range(Bn):
+        r = _oracle([a[b] for a in arrs], ocam, (0.05, 0.1, 0.15), phases=phases[b], amp=0.25)
+        assert len(np.unique(r.proj["depth"][r.proj["visible"].astype(bool)])) <= 8
+        assert rel_to_max(out["image"][b], r.image) <= TOL
+        assert rel_to_max(out["depth"][b], r.depth) <= TOL
+        go = orc.render_backward(r, gI[b], gD[b])
+        for k in ["positions", "scales", "rotations", "colors", "opacities"]:
+            assert rel_to_max(out["grad_" + k][b], go[k]) <= TOL, (b, k)
+        assert rel_to_max(out["grad_phases"][b], go["phases"]) <= TOL
+
+
+def test_phase_rgb_phases_raise_like_the_reference():
+    """(N,3) phases crash the reference's TBR phase path: same error class here."""
+    from fresnel_amd.renderer import Camera, TileBasedRenderer
+    dev = _cuda()
+    pos, scale, quat, col, opa = [torch.from_numpy(a).to(dev) for a in synth_saag(64, 3)]
+    ren = TileBasedRenderer(32, 32, use_phase_blending=True)
+    with pytest.raises(RuntimeError):
+        ren(pos, scale, quat, col, opa, Camera(25.6, 25.6, 16, 16, 32, 32), phases=torch.rand(64, 3, device=dev))
+    # phases are ignored unless use_phase_blending is set (DR:629)
+    ren0 = TileBasedRenderer(32, 32)
+    a = ren0(pos, scale, quat, col, opa, Camera(25.6, 25.6, 16, 16, 32, 32), phases=torch.rand(64, device=dev))
+    b = ren0(pos, scale, quat, col, opa, Camera(25.6, 25.6, 16, 16, 32, 32))
+    assert torch.equal(a, b)

@@ -134,3 +134,55 @@ def test_known_answers_single_and_stacked_gaussian():
     exp = 0.5 * np.array([1, 0, 0]) + 0.5 * 0.7 * np.array([0, 1, 0]) + 0.5 * 0.3 * np.array([0, 0, 1.0])
     assert np.allclose(r2.image[:, H // 2, W // 2], exp, atol=1e-6)
     assert np.isclose(r2.depth[H // 2, W // 2], 0.5 * 2.0 + 0.5 * 0.7 * 3.0, atol=1e-6)
+
+
+def test_phase_backward_matches_fp64_autograd_on_anisotropic_input():
+    """The golden G6 uses isotropic, opacity-0.8 Gaussians and never reaches the A < 1e-6 branch
+    of the phase update (DR:663).  Pin the oracle's composite-level phase adjoint on eccentric
+    Gaussians (tiny first contributions) against fp64 autograd of an out-of-place torch
+    restatement of DR:603-667 written here (test code, independent of the C oracle)."""
+    import torch
+    from helpers import synth_aniso
+    W, H, N, amp, bg = 96, 80, 160, 0.25, (0.05, 0.1, 0.15)
+    rs = np.random.RandomState(3)
+    a = list(synth_aniso(N, 50, opacity_max=1.0, smin=0.02, smax=0.09))
+    phases = rs.random_sample(N).astype(np.float32)
+    cam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    gI = rs.standard_normal((3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
+    r = orc.render(*a, cam, bg=bg, phases=phases, phase_amp=amp)
+    go = orc.render_backward(r, gI, gD)
+    dt = torch.float64
+    leaf = lambda x: torch.tensor(x, dtype=dt, requires_grad=True)
+    mean, conic, opa, col = leaf(r.proj["mean2d"]), leaf(r.proj["conic"]), leaf(a[4]), leaf(a[3])
+    dep, ph = leaf(r.proj["depth"]), leaf(phases)
+    C, A = torch.zeros(H, W, 3, dtype=dt), torch.zeros(H, W, dtype=dt)
+    D, P = torch.zeros(H, W, dtype=dt), torch.zeros(H, W, dtype=dt)
+    tiny = 0
+    for i in r.vis_sorted.tolist():
+        x0, x1, y0, y1 = [int(t) for t in r.proj["bbox"][i]]
+        if x0 >= x1 or y0 >= y1:
+            continue
+        ly, lx = torch.meshgrid(torch.arange(y0, y1, dtype=dt), torch.arange(x0, x1, dtype=dt), indexing="ij")
+        dx, dy = lx - mean[i, 0], ly - mean[i, 1]
+        m = conic[i, 0] * dx * dx + conic[i, 1] * dx * dy + conic[i, 2] * dy * dy
+        alpha = torch.exp(-0.5 * m) * opa[i]
+        pd = torch.abs(ph[i] - P[y0:y1, x0:x1])
+        pd = torch.min(pd, 1.0 - pd)
+        alpha = torch.clamp(alpha * ((1 - amp) + amp * torch.cos(pd * 2 * 3.14159)), 0, 0.99)
+        w = alpha * (1 - A[y0:y1, x0:x1])
+        mask = torch.zeros(H, W, dtype=torch.bool)
+        mask[y0:y1, x0:x1] = True
+        wf = torch.zeros(H, W, dtype=dt).masked_scatter(mask, w)
+        C, D, A = C + wf.unsqueeze(-1) * col[i].view(1, 1, 3), D + wf * dep[i], A + wf
+        tiny += int(((A < 1e-6) & mask).sum())
+        pc = wf / A.clamp(min=1e-6)
+        P = torch.where(mask, P * (1 - pc) + ph[i] * pc, P)
+    assert tiny > 100  # the clamp(min=1e-6) branch is really exercised
+    C = C + (1 - A).unsqueeze(-1) * torch.tensor(bg, dtype=dt).view(1, 1, 3)
+    img = torch.clamp(C.permute(2, 0, 1), 0, 1)
+    assert float((img.detach().float() - torch.from_numpy(r.image)).abs().max()) <= 1e-5
+    ((img * torch.tensor(gI, dtype=dt)).sum() + (D * torch.tensor(gD, dtype=dt)).sum()).backward()
+    for k, t in [("mean2d", mean), ("conic", conic), ("opacities", opa), ("colors", col), ("depth", dep),
+                 ("phases", ph)]:
+        assert rel_to_max(go[k], t.grad.numpy()) <= 1e-5, k
