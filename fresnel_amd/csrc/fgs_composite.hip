@@ -16,6 +16,7 @@
 //
 // Bound: VALU + transcendental (about 25 VALU + 1 v_exp_f32 per Gaussian-pixel forward, ~60
 // backward); HBM traffic is the 52-byte id+record gather per duplicate plus per-pixel state.
+#include <stdlib.h>
 #include "fgs_internal.h"
 
 namespace {
@@ -68,30 +69,58 @@ __device__ __forceinline__ void wave_sum10_lane63(float &a0, float &a1, float &a
 #undef FGS_STEP
 }
 
-template <bool PHASE>
-__global__ __launch_bounds__(64) void k_composite_fwd(
+// Forward: TWO waves per tile (wave w owns sub-tiles 2w and 2w+1, i.e. the upper / lower half of
+// the tile).  The forward has no cross-lane reduction, so splitting a tile over two waves is free
+// and halves the serial length of the longest lists -- with 8 images per GPU the launch is
+// otherwise limited by its few longest tiles.  Both waves share the LDS-staged chunk.
+
+// Staging-time (per lane, parallel over the chunk) decode of a record's bbox against this tile:
+//   msk  bit s   = sub-tile s (8x8, s = 2*row + col) intersects the bbox
+//   bbx' = x0 | (x1 - x0) << 16,  bby' = y0 | (y1 - y0) << 16   (origin + extent), so the
+// per-pixel membership test in the loop is (px - x0) < wx && (py - y0) < wy in unsigned
+// arithmetic: two SDWA subtracts + two SDWA compares, no scalar bit-field decoding.
+// Doing this here keeps the blend loop at ~2 scalar instructions per sub-tile; the scalar unit
+// is shared by the CU's four SIMDs and was the co-bottleneck of the first version.
+__device__ __forceinline__ uint32_t subtile_mask(uint32_t X0, uint32_t Y0, uint32_t x0, uint32_t x1, uint32_t y0,
+                                                 uint32_t y1) {
+    const uint32_t cx0 = (x1 > X0 && x0 < X0 + 8u) ? 1u : 0u, cx1 = (x1 > X0 + 8u && x0 < X0 + 16u) ? 1u : 0u;
+    const uint32_t ry0 = (y1 > Y0 && y0 < Y0 + 8u) ? 1u : 0u, ry1 = (y1 > Y0 + 8u && y0 < Y0 + 16u) ? 1u : 0u;
+    return (cx0 & ry0) | ((cx1 & ry0) << 1) | ((cx0 & ry1) << 2) | ((cx1 & ry1) << 3);
+}
+
+template <bool PHASE, int FWD_WAVES>
+__global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
     float *__restrict__ pix_state, float *__restrict__ phase_ckpt, float *__restrict__ out_rgb,
     float *__restrict__ out_depth) {
-    __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
-    __shared__ float shp[CH];
+    constexpr int FCH = 64 * FWD_WAVES;  // records per LDS chunk (one per thread)
+    __shared__ float4 sh0[FCH], sh1[FCH], sh2[FCH];
+    __shared__ float shp[FCH];
+    __shared__ uint32_t shm[FCH];
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = FWD_WAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    float A[4], Cr[4], Cg[4], Cb[4], Dm[4], Ph[4];
+    constexpr int NS = 4 / FWD_WAVES;  // sub-tiles per wave
+    float A[NS], Cr[NS], Cg[NS], Cb[NS], Dm[NS], Ph[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { A[s] = 0; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; Ph[s] = 0; }
-    for (uint32_t base = c.start; base < c.end; base += CH) {
-        const uint32_t n = min((uint32_t)CH, c.end - base);
-        if (lane < n) {
-            const uint32_t gid = dup_ids[base + lane];
+    for (int s = 0; s < NS; ++s) { A[s] = 0; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; Ph[s] = 0; }
+    for (uint32_t base = c.start; base < c.end; base += FCH) {
+        const uint32_t n = min((uint32_t)FCH, c.end - base);
+        if (threadIdx.x < n) {
+            const uint32_t gid = dup_ids[base + threadIdx.x];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
-            float4 q0 = r[0], q1 = r[1];
+            float4 q0 = r[0], q1 = r[1], q2 = r[2];
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
-            sh0[lane] = q0; sh1[lane] = q1; sh2[lane] = r[2];
-            if (PHASE) shp[lane] = phase[gid];
+            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
+            const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu, by1 = bby >> 16;
+            shm[threadIdx.x] = subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1);
+            q2.z = __uint_as_float(bx0 | ((bx1 - bx0) << 16));
+            q2.w = __uint_as_float(by0 | ((by1 - by0) << 16));
+            sh0[threadIdx.x] = q0; sh1[threadIdx.x] = q1; sh2[threadIdx.x] = q2;
+            if (PHASE) shp[threadIdx.x] = phase[gid];
         }
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
@@ -100,19 +129,18 @@ __global__ __launch_bounds__(64) void k_composite_fwd(
                 const size_t slot = (size_t)(c.start / FGS_PHASE_CKPT) + (base - c.start + j) / FGS_PHASE_CKPT + c.tile;
                 float *ck = phase_ckpt + slot * 512 + lane;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { ck[s * 64] = A[s]; ck[(4 + s) * 64] = Ph[s]; }
+                for (int s = 0; s < NS; ++s) { ck[(wave * NS + s) * 64] = A[s]; ck[(4 + wave * NS + s) * 64] = Ph[s]; }
             }
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-            const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
-            const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
-            const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
+            const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
+            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);  // origin | extent << 16
             const float ph = PHASE ? shp[j] : 0.0f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const uint32_t sx = c.X0 + 8u * (s & 1), sy = c.Y0 + 8u * (s >> 1);
-                if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) continue;  // scalar branch
-                const uint32_t px = sx + lx, py = sy + ly;
-                const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t sg = wave * NS + s;  // sub-tile index inside the tile (scalar)
+                if (!((msk >> sg) & 1u)) continue;  // scalar branch: sub-tile not touched
+                const uint32_t px = c.X0 + 8u * (sg & 1) + lx, py = c.Y0 + 8u * (sg >> 1) + ly;
+                const bool in = (px - (bbx & 0xFFFFu)) < (bbx >> 16) && (py - (bby & 0xFFFFu)) < (bby >> 16);
                 const float dx = (float)px - q0.x, dy = (float)py - q0.y;
                 const float m = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
                 float alpha = __builtin_amdgcn_exp2f(m) * q1.y;
@@ -136,8 +164,9 @@ __global__ __launch_bounds__(64) void k_composite_fwd(
     }
     const size_t HW = (size_t)W * H;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t sg = wave * NS + s;
+        const uint32_t px = c.X0 + 8u * (sg & 1) + lx, py = c.Y0 + 8u * (sg >> 1) + ly;
         if (px < W && py < H) {
             const size_t o = (size_t)py * W + px;
             float *ps = pix_state + (size_t)c.b * 6 * HW + o;
@@ -173,6 +202,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     float *__restrict__ grad_rows) {
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
+    __shared__ uint32_t shm[CH];
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
@@ -203,49 +233,54 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
         if (lane < n) {
             const uint32_t gid = dup_ids[base + lane];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
-            const float4 q2 = r[2];
-            sh0[lane] = r[0]; sh1[lane] = r[1]; sh2[lane] = q2;
+            float4 q2 = r[2];
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
-            const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
-            const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE;
+            const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu, by1 = bby >> 16;
+            const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
             she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
+            shm[lane] = subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1);
+            q2.z = __uint_as_float(bx0 | ((bx1 - bx0) << 16));
+            q2.w = __uint_as_float(by0 | ((by1 - by0) << 16));
+            sh0[lane] = r[0]; sh1[lane] = r[1]; sh2[lane] = q2;
         }
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-            const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
-            const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
-            const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
+            const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
+            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);  // origin | extent << 16
             const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;
-            float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
+            // per-lane partial sums over this lane's (up to four) pixels
+            float v_mx = 0, v_my = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const uint32_t sx = c.X0 + 8u * (s & 1), sy = c.Y0 + 8u * (s >> 1);
-                if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) continue;  // scalar branch
-                const uint32_t px = sx + lx, py = sy + ly;
-                const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
+                if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
+                const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
+                const bool in = (px - (bbx & 0xFFFFu)) < (bbx >> 16) && (py - (bby & 0xFFFFu)) < (bby >> 16);
                 const float dx = (float)px - q0.x, dy = (float)py - q0.y;
                 const float m = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
                 const float G = __builtin_amdgcn_exp2f(m * NEG_HALF_LOG2E);
                 const float raw = G * op;
-                float alpha = fminf(fmaxf(raw, 0.0f), 0.99f);
-                alpha = in ? alpha : 0.0f;
+                const float alpha = in ? fminf(fmaxf(raw, 0.0f), 0.99f) : 0.0f;
+                const bool pass = in && raw >= 0.0f && raw <= 0.99f;  // clamp backward, closed interval
                 const float T = 1.0f - A[s];
                 const float w = alpha * T;
                 const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
                 prefix[s] += w * q;
                 const float S = S0[s] - prefix[s];
                 const float dalpha = T * q - S * __builtin_amdgcn_rcpf(1.0f - alpha);
-                const float draw = (in && raw >= 0.0f && raw <= 0.99f) ? dalpha : 0.0f;
+                const float draw = pass ? dalpha : 0.0f;
                 A[s] += w;
-                const float dm = -0.5f * draw * op * G;
-                v_op += draw * G;
-                v_ca += dm * dx * dx; v_cbc += dm * dx * dy; v_cd += dm * dy * dy;
-                v_u -= dm * (2.0f * ca * dx + cbc * dy);
-                v_v -= dm * (cbc * dx + 2.0f * cd * dy);
+                const float dG = draw * G;
+                const float dm = -0.5f * op * dG;
+                v_op += dG;
+                const float dmx = dm * dx, dmy = dm * dy;
+                v_mx -= dm * (2.0f * ca * dx + cbc * dy);  // dL/du
+                v_my -= dm * (cbc * dx + 2.0f * cd * dy);  // dL/dv
+                v_ca += dmx * dx; v_cbc += dmx * dy; v_cd += dmy * dy;
                 v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
             }
-            wave_sum10_lane63(v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d);
+            wave_sum10_lane63(v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d);
+            const float v_u = v_mx, v_v = v_my;
             if (lane == 63) {
                 const uint32_t e = she[j];
                 if (e < dcap) {
@@ -459,6 +494,13 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
 
 }  // namespace
 
+// Kernel variants are template instantiations; FGS_FWD_VARIANT / FGS_BWD_VARIANT (read once)
+// select them for in-process A/B benchmarking.  Defaults are the measured-fastest ones.
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, float *out_rgb,
                              float *out_depth, hipStream_t st) {
     const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
@@ -467,17 +509,19 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     const uint32_t *tile_order = reinterpret_cast<const uint32_t *>(saved + p.L.tile_order);
     const float *rec = reinterpret_cast<const float *>(saved + p.L.rec);
     float *pix = reinterpret_cast<float *>(saved + p.L.pix_state);
-    if (p.d.use_phase)
-        hipLaunchKernelGGL(k_composite_fwd<true>, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles,
-                           (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height,
-                           p.d.background[0], p.d.background[1], p.d.background[2], p.d.phase_amplitude,
-                           tile_order, ranges, dup_ids, rec, phase, pix,
-                           reinterpret_cast<float *>(saved + p.L.phase_ckpt), out_rgb, out_depth);
-    else
-        hipLaunchKernelGGL(k_composite_fwd<false>, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles,
-                           (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height,
-                           p.d.background[0], p.d.background[1], p.d.background[2], p.d.phase_amplitude,
-                           tile_order, ranges, dup_ids, rec, phase, pix, nullptr, out_rgb, out_depth);
+    float *ckpt = p.d.use_phase ? reinterpret_cast<float *>(saved + p.L.phase_ckpt) : nullptr;
+    const int fw = env_int("FGS_FWD_WAVES", 2);  // waves per tile: 2 measured fastest (A/B in one process)
+#define FGS_FWD_LAUNCH(PH, FW)                                                                                \
+    hipLaunchKernelGGL((k_composite_fwd<PH, FW>), dim3(grid), dim3(64 * FW), 0, st, (uint32_t)p.tiles,       \
+                       (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
+                       p.d.background[1], p.d.background[2], p.d.phase_amplitude, tile_order, ranges, dup_ids, \
+                       rec, phase, pix, ckpt, out_rgb, out_depth)
+    if (p.d.use_phase) {
+        if (fw == 1) FGS_FWD_LAUNCH(true, 1); else FGS_FWD_LAUNCH(true, 2);
+    } else {
+        if (fw == 1) FGS_FWD_LAUNCH(false, 1); else FGS_FWD_LAUNCH(false, 2);
+    }
+#undef FGS_FWD_LAUNCH
     FGS_LAUNCH_CHECK("k_composite_fwd");
     return FGS_OK;
 }

@@ -156,22 +156,35 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const float *__restrict__ grad_rows, float *__restrict__ g_pos, float *__restrict__ g_scale,
     float *__restrict__ g_quat, float *__restrict__ g_color, float *__restrict__ g_opacity,
     float *__restrict__ g_phase) {
-    const int32_t ri = blockIdx.x * 256 + threadIdx.x;
-    if (ri >= total) return;
-    const int32_t b = ri / N;
-    const int32_t idx = b * N + (int32_t)order[ri];
+    // four lanes per Gaussian: lane `sub` sums rows sub, sub+4, ... (neighbouring lanes read
+    // neighbouring 48-byte rows), then two quad shuffles combine the partial sums in a fixed order
+    const int32_t tid = blockIdx.x * 256 + threadIdx.x;
+    const int32_t ri = tid >> 2;
+    const uint32_t sub = threadIdx.x & 3u;
+    const bool live = ri < total;
+    const int32_t b = live ? ri / N : 0;
+    const int32_t idx = live ? b * N + (int32_t)order[ri] : 0;
     float gp[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0};
-    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0;
-    {
+    float acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) {
         const uint32_t cnt = tile_count[idx], off = dup_off[idx];
-        for (uint32_t k = 0; k < cnt && off + k < dcap; ++k) {
+        for (uint32_t k = sub; k < cnt && off + k < dcap; k += 4) {
             const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * FGS_GROW_FLOATS);
             const float4 a = r[0], bq = r[1], cq = r[2];
-            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-            s1.x += bq.x; s1.y += bq.y; s1.z += bq.z; s1.w += bq.w;
-            s2.x += cq.x; s2.y += cq.y; s2.z += cq.z;
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+            acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
+            acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z;
         }
     }
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        acc[k] += __shfl_xor(acc[k], 1, 64);
+        acc[k] += __shfl_xor(acc[k], 2, 64);
+    }
+    if (!live || sub != 0) return;
+    const float4 s0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    const float4 s1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    const float4 s2 = make_float4(acc[8], acc[9], acc[10], 0.0f);
     const float g_mean[2] = {s0.x, s0.y};
     const float g_conic[3] = {s0.z, s0.w, s1.x};
     const float g_depth = s2.y;
@@ -302,7 +315,7 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
                            float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
                            hipStream_t st) {
     const int32_t total = p.d.batch * p.d.num_gaussians;
-    const int grid = (total + 255) / 256;
+    const int grid = (int)(((size_t)total * 4 + 255) / 256);
     hipLaunchKernelGGL(k_project_bwd, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
                        p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat,
                        reinterpret_cast<const uint32_t *>(saved + p.L.depth_key),

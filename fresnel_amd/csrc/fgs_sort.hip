@@ -32,7 +32,7 @@ __device__ __forceinline__ SegInfo block_range(uint32_t seg_len, const uint32_t 
     if (len > seg_capacity) len = seg_capacity;
     const uint32_t bps = gridDim.x;
     uint32_t per = (len + bps - 1) / bps;
-    per = (per + RS_THREADS - 1) / RS_THREADS * RS_THREADS;
+    per = (per + RS_THREADS * 4 - 1) / (RS_THREADS * 4) * (RS_THREADS * 4);
     const uint32_t seg0 = blockIdx.y * seg_stride;
     uint32_t b = blockIdx.x * per, e = b + per;
     if (b > len) b = len;
@@ -106,29 +106,50 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
         for (int w = 0; w < RS_WAVES; ++w) wcnt[w][tid] = 0;
     }
     __syncthreads();
-    for (uint32_t base = r.begin; base < r.end; base += RS_THREADS) {
-        const uint32_t i = base + tid;
-        const bool valid = i < r.end;
-        const uint32_t key = valid ? keys_in[i] : 0u;
-        const uint32_t val = valid ? vals_in[i] : 0u;
-        const uint32_t digit = (key >> shift) & 255u;
-        unsigned long long m = __ballot(valid);
+    // Rounds of 1024 keys: wave w owns the contiguous 256 keys [base + 256 w, +256) and walks them
+    // in four 64-key sub-rounds, ranking against its OWN running digit counters in LDS (a wave's LDS
+    // operations execute in program order, so read-count-then-bump needs no barrier); one block
+    // barrier per round then turns the four waves' counts into global positions.
+    constexpr uint32_t ROUND = RS_THREADS * 4;
+    for (uint32_t base = r.begin; base < r.end; base += ROUND) {
+        uint32_t key[4], val[4], lrank[4];
+        bool valid[4];
 #pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const bool bset = (digit >> bit) & 1u;
-            const unsigned long long bm = __ballot(valid && bset);
-            m &= bset ? bm : ~bm;
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t i = base + wave * 256u + it * 64u + lane;
+            valid[it] = i < r.end;
+            key[it] = valid[it] ? keys_in[i] : 0u;
+            val[it] = valid[it] ? vals_in[i] : 0u;
         }
-        const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (valid && rank == 0) wcnt[wave][digit] = __popcll(m);
-        __syncthreads();
-        if (valid) {
-            uint32_t pre = 0;
 #pragma unroll
-            for (int w = 0; w < RS_WAVES; ++w) pre += (w < (int)wave) ? wcnt[w][digit] : 0u;
-            const uint32_t dst = run_off[digit] + pre + rank;
-            keys_out[dst] = key;
-            vals_out[dst] = val;
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t digit = (key[it] >> shift) & 255u;
+            unsigned long long m = __ballot(valid[it]);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool bset = (digit >> bit) & 1u;
+                const unsigned long long bm = __ballot(valid[it] && bset);
+                m &= bset ? bm : ~bm;
+            }
+            const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t prev = valid[it] ? wcnt[wave][digit] : 0u;
+            lrank[it] = prev + rank;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (valid[it] && rank == 0) wcnt[wave][digit] = prev + (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (valid[it]) {
+                const uint32_t digit = (key[it] >> shift) & 255u;
+                uint32_t pre = 0;
+#pragma unroll
+                for (int w = 0; w < RS_WAVES; ++w) pre += (w < (int)wave) ? wcnt[w][digit] : 0u;
+                const uint32_t dst = run_off[digit] + pre + lrank[it];
+                keys_out[dst] = key[it];
+                vals_out[dst] = val[it];
+            }
         }
         __syncthreads();
         {
