@@ -16,6 +16,7 @@ FGS_TILE = 16
 EXPORTED_SYMBOLS = [
     "fgs_workspace_bytes", "fgs_saved_layout", "fgs_forward", "fgs_backward", "fgs_count_pairs",
     "fgs_last_error", "fgs_version", "fgs_stage_timing_enable", "fgs_stage_timing_read",
+    "fgs_asm_workspace_bytes", "fgs_asm_forward", "fgs_asm_backward",
 ]
 
 STAGES = ["project", "depth_sort", "dup_emit", "tile_sort", "tile_ranges", "composite_fwd",
@@ -38,6 +39,16 @@ class FgsSavedLayout(ctypes.Structure):
                 ("pix_state", ctypes.c_size_t), ("phase_ckpt", ctypes.c_size_t),
                 ("dup_capacity", ctypes.c_size_t),
                 ("tiles_x", ctypes.c_int32), ("tiles_y", ctypes.c_int32)]
+
+
+class FgsAsmDims(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("num_gaussians", ctypes.c_int32),
+                ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("max_radius", ctypes.c_float), ("background", ctypes.c_float * 3),
+                ("num_planes", ctypes.c_int32), ("depth_near", ctypes.c_float),
+                ("depth_far", ctypes.c_float), ("focal_depth", ctypes.c_float),
+                ("pixel_pitch", ctypes.c_float), ("phase_channels", ctypes.c_int32),
+                ("num_cameras", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class FgsError(RuntimeError):
@@ -72,6 +83,11 @@ def load():
     lib.fgs_stage_timing_read.argtypes = [cp(ctypes.c_float), cp(ctypes.c_int32)]
     lib.fgs_stage_timing_enable.restype = ctypes.c_int
     lib.fgs_stage_timing_read.restype = ctypes.c_int
+    lib.fgs_asm_workspace_bytes.argtypes = [cp(FgsAsmDims), cp(ctypes.c_size_t), cp(ctypes.c_size_t)]
+    lib.fgs_asm_forward.argtypes = [cp(FgsAsmDims)] + [vp] * 12
+    lib.fgs_asm_backward.argtypes = [cp(FgsAsmDims)] + [vp] * 19
+    for fn in (lib.fgs_asm_workspace_bytes, lib.fgs_asm_forward, lib.fgs_asm_backward):
+        fn.restype = ctypes.c_int
     for fn in (lib.fgs_workspace_bytes, lib.fgs_saved_layout, lib.fgs_forward, lib.fgs_backward,
                lib.fgs_count_pairs):
         fn.restype = ctypes.c_int

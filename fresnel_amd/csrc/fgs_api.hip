@@ -55,7 +55,7 @@ void fgs_stage_end(int stage, hipStream_t st) {
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-int fgs_make_plan(const FgsDims *d, FgsPlan *p) {
+int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers) {
     if (!d || !p) { fgs_set_error("null dims"); return FGS_EINVAL; }
     if (d->batch < 1 || d->num_gaussians < 1 || d->width < 1 || d->height < 1 || d->width > 32768 ||
         d->height > 32768 || !(d->max_radius > 0.0f) || (d->num_cameras != 1 && d->num_cameras != d->batch)) {
@@ -67,6 +67,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p) {
     if (B * N >= (1ull << 31)) { fgs_set_error("B*N too large"); return FGS_EINVAL; }
     memset(p, 0, sizeof(*p));
     p->d = *d;
+    p->layers = layers;
     const int tx = (d->width + FGS_TILE - 1) / FGS_TILE, ty = (d->height + FGS_TILE - 1) / FGS_TILE;
     p->tiles = tx * ty;
     // bbox width <= floor(2r)+2 pixels -> spans at most floor((2r+1)/16)+2 tile columns
@@ -78,7 +79,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p) {
     const size_t dcap = B * N * (size_t)p->tiles_per_gauss;
     if (dcap >= (1ull << 32) - 256) { fgs_set_error("duplicate capacity exceeds 2^32"); return FGS_EINVAL; }
     uint32_t bits = 0;
-    while ((1ull << bits) < B * (size_t)p->tiles) ++bits;
+    while ((1ull << bits) < B * (size_t)layers * p->tiles) ++bits;
     p->tile_key_bits = bits;
 
     FgsSavedLayout &L = p->L;
@@ -89,12 +90,14 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p) {
     L.order = o; o = align256(o + B * N * 4);
     L.dup_off = o; o = align256(o + B * N * 4);
     L.counters = o; o = align256(o + 16 * 4);
-    L.ranges = o; o = align256(o + B * p->tiles * 2 * 4);
-    L.tile_order = o; o = align256(o + B * p->tiles * 4);
+    L.ranges = o; o = align256(o + B * layers * p->tiles * 2 * 4);
+    L.tile_order = o; o = align256(o + B * layers * p->tiles * 4);
     L.dup_ids = o; o = align256(o + dcap * 4);
     L.pix_state = o; o = align256(o + B * 6 * (size_t)d->width * d->height * 4);
     L.phase_ckpt = o;
     if (d->use_phase) o = align256(o + (dcap / FGS_PHASE_CKPT + B * p->tiles + 2) * 8 * 64 * 4);
+    p->s_layer = o;
+    if (layers > 1) o = align256(o + B * N * 4);
     L.total_bytes = o;
     L.dup_capacity = dcap;
     L.tiles_x = tx; L.tiles_y = ty;

@@ -1,0 +1,619 @@
+// Angular-spectrum wave-field renderer (BASELINE config 5): replaces ASMWaveFieldRenderer.forward
+// (DR:1150-1344) and AngularSpectrumPropagator (DR:929-1065) and their autograd.
+//
+// Pipeline (forward), all on the caller's stream:
+//   k_project (shared; also assigns the nearest depth plane)  -> binning keyed by (image, plane,
+//   tile) -> k_asm_splat (one wave per (image, plane, tile): complex amplitudes a c e^{i phi},
+//   order-independent sum, DR:1233-1283) -> batched 2-D C2C forward FFT of all B*P*3 plane
+//   fields (hipFFT on rocFFT) -> k_asm_transfer + k_asm_accumulate: acc_c = sum_p F_pc H_pc with
+//   H = exp(i 2 pi z_p sqrt(max(l_c^-2 - fx^2 - fy^2, 0))) (DR:989-999) -> ONE inverse FFT per
+//   (image, channel) instead of one per plane (linearity of the propagation, 3 instead of 48) ->
+//   k_asm_max / k_asm_output: sqrt(|U|^2 + 1e-8), per-image max-normalisation, background
+//   composition and clamps (DR:1315-1332).
+// Backward retraces this with the adjoint transforms (3 forward + B*P*3 inverse FFTs).
+//
+// Bounds: the splat is VALU-bound like the compositor; FFTs and the elementwise spectral kernels
+// are HBM-bound (8 B per complex sample per pass).
+//
+// Compiled WITHOUT fast-math: the transfer-function phase reaches ~200 rad, so sin/cos need the
+// accurate range reduction of sincosf.
+#include <hipfft/hipfft.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include "fgs_internal.h"
+#include "fgs_wave.h"
+
+namespace {
+
+constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;
+constexpr int ACH = 64;
+constexpr int ST_ASM = ST_COMPOSITE_FWD;  // stage timers: ASM stages are accounted as "composite"
+
+struct AsmPlan {
+    FgsAsmDims a;
+    FgsPlan base;        // projection + binning with layers = num_planes
+    size_t HW;
+    // saved sections (after base.L.total_bytes)
+    size_t v_field;      // float2 [B][P][3][H][W]  plane fields -> spectra (kept for the backward)
+    size_t v_htab;       // float2 [3][P][H][W]     transfer functions
+    size_t v_total;      // float2 [B][3][H][W]     total field U (unnormalised inverse FFT)
+    size_t v_scal;       // float  [3][B]           per-image maxval | dL/dM | number of maxima
+    size_t v_total_bytes;
+    // scratch sections (after base.s_total)
+    size_t c_acc;        // float2 [B][3][H][W]
+    size_t c_fftwork;
+    size_t c_total_bytes;
+    size_t work_big, work_small;
+};
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- hipFFT plan cache -----------------------------------------------------------------------
+struct FftKey { int h, w, batch; bool operator<(const FftKey &o) const { return std::tie(h, w, batch) < std::tie(o.h, o.w, o.batch); } };
+struct FftPlan { hipfftHandle handle; size_t work; };
+std::mutex g_fft_mu;
+std::map<FftKey, FftPlan> g_fft;
+
+int get_fft_plan(int H, int W, int batch, FftPlan *out) {
+    std::lock_guard<std::mutex> lk(g_fft_mu);
+    const FftKey key{H, W, batch};
+    auto it = g_fft.find(key);
+    if (it != g_fft.end()) { *out = it->second; return FGS_OK; }
+    FftPlan pl{};
+    int n[2] = {H, W};
+    if (hipfftCreate(&pl.handle) != HIPFFT_SUCCESS) { fgs_set_error("hipfftCreate failed"); return FGS_ELAUNCH; }
+    if (hipfftSetAutoAllocation(pl.handle, 0) != HIPFFT_SUCCESS) { fgs_set_error("hipfftSetAutoAllocation failed"); return FGS_ELAUNCH; }
+    const hipfftResult r = hipfftMakePlanMany(pl.handle, 2, n, nullptr, 1, H * W, nullptr, 1, H * W, HIPFFT_C2C, batch, &pl.work);
+    if (r != HIPFFT_SUCCESS) { fgs_set_error("hipfftMakePlanMany(%dx%d x%d) failed: %d", H, W, batch, (int)r); return FGS_ELAUNCH; }
+    g_fft[key] = pl;
+    *out = pl;
+    return FGS_OK;
+}
+
+int run_fft(int H, int W, int batch, float2 *data, int dir, void *work, hipStream_t st) {
+    FftPlan pl;
+    const int rc = get_fft_plan(H, W, batch, &pl);
+    if (rc) return rc;
+    if (hipfftSetStream(pl.handle, st) != HIPFFT_SUCCESS || hipfftSetWorkArea(pl.handle, work) != HIPFFT_SUCCESS) {
+        fgs_set_error("hipfft stream/work-area setup failed");
+        return FGS_ELAUNCH;
+    }
+    const hipfftResult r = hipfftExecC2C(pl.handle, reinterpret_cast<hipfftComplex *>(data),
+                                         reinterpret_cast<hipfftComplex *>(data), dir);
+    if (r != HIPFFT_SUCCESS) { fgs_set_error("hipfftExecC2C failed: %d", (int)r); return FGS_ELAUNCH; }
+    return FGS_OK;
+}
+
+int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
+    if (!a) { fgs_set_error("null dims"); return FGS_EINVAL; }
+    if (a->num_planes < 2 || a->num_planes > 64 || (a->phase_channels != 1 && a->phase_channels != 3) ||
+        !(a->pixel_pitch > 0.0f)) {
+        fgs_set_error("invalid ASM dims: planes=%d phase_channels=%d pitch=%g", a->num_planes, a->phase_channels,
+                      (double)a->pixel_pitch);
+        return FGS_EINVAL;
+    }
+    FgsDims d{};
+    d.batch = a->batch; d.num_gaussians = a->num_gaussians; d.width = a->width; d.height = a->height;
+    d.max_radius = a->max_radius;
+    for (int i = 0; i < 3; ++i) d.background[i] = a->background[i];
+    d.use_phase = 0; d.phase_amplitude = 0.0f; d.num_cameras = a->num_cameras;
+    p->a = *a;
+    const int rc = fgs_make_plan(&d, &p->base, a->num_planes);
+    if (rc) return rc;
+    const size_t B = a->batch, P = a->num_planes, HW = (size_t)a->width * a->height;
+    p->HW = HW;
+    size_t o = p->base.L.total_bytes;
+    p->v_field = o; o = align256(o + B * P * 3 * HW * 8);
+    p->v_htab = o; o = align256(o + 3 * P * HW * 8);
+    p->v_total = o; o = align256(o + B * 3 * HW * 8);
+    p->v_scal = o; o = align256(o + B * 4 * 4);
+    p->v_total_bytes = o;
+    p->work_big = p->work_small = 0;
+    if (need_fft) {
+        FftPlan big, small;
+        int r2 = get_fft_plan(a->height, a->width, (int)(B * P * 3), &big);
+        if (r2) return r2;
+        r2 = get_fft_plan(a->height, a->width, (int)(B * 3), &small);
+        if (r2) return r2;
+        p->work_big = big.work; p->work_small = small.work;
+    }
+    o = p->base.s_total;
+    p->c_acc = o; o = align256(o + B * 3 * HW * 8);
+    p->c_fftwork = o; o = align256(o + (p->work_big > p->work_small ? p->work_big : p->work_small) + 256);
+    p->c_total_bytes = o;
+    return FGS_OK;
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// fftfreq(n, d)[k] as torch computes it: integer index (negative upper half) times 1/(n d)
+__device__ __forceinline__ float fftfreq(int k, int n, float inv_nd) {
+    const int ks = (k < (n + 1) / 2) ? k : k - n;
+    return (float)ks * inv_nd;
+}
+
+// depth planes: torch.linspace(near, far, P), DR:1106
+__device__ __forceinline__ float plane_depth(int k, int P, float near_, float far_) {
+    const float step = (far_ - near_) / (float)(P - 1);
+    return (k < P / 2) ? near_ + step * (float)k : far_ - step * (float)(P - 1 - k);
+}
+
+// H[c][p][ky][kx] = exp(i * ((2 pi * z_p) * kz)), kz = sqrt(max(1/l_c^2 - fx^2 - fy^2, 0))   DR:989-999
+__global__ __launch_bounds__(256) void k_asm_transfer(int W, int H, int P, float near_, float far_, float focal,
+                                                      float inv_ndx, float inv_ndy,
+                                                      const float *__restrict__ wavelengths,
+                                                      float2 *__restrict__ htab) {
+    const size_t HW = (size_t)W * H;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * (size_t)P * HW) return;
+    const int kx = (int)(i % W), ky = (int)((i / W) % H);
+    const int p = (int)((i / HW) % P), c = (int)(i / (HW * P));
+    const float fx = fftfreq(kx, W, inv_ndx), fy = fftfreq(ky, H, inv_ndy);
+    const float il = 1.0f / wavelengths[c];
+    float kz2 = il * il - fx * fx - fy * fy;
+    kz2 = kz2 < 0.0f ? 0.0f : kz2;
+    const float kz = sqrtf(kz2);
+    const float z = focal - plane_depth(p, P, near_, far_);
+    const float theta = (6.28318530717958647692f * z) * kz;
+    float sn, cs;
+    sincosf(theta, &sn, &cs);
+    htab[i] = make_float2(cs, sn);
+}
+
+// One wave per (image, plane, tile); lane = one pixel of each of the four 8x8 sub-tiles.
+// BWD = false: accumulate field += a * c * (cos phi, sin phi) with a = exp(-m/2) * opacity (DR:1263-1283).
+// BWD = true : read the field gradient and reduce the twelve per-Gaussian sums into a gradient row.
+template <bool BWD>
+__global__ __launch_bounds__(64) void k_asm_splat(
+    uint32_t tiles, uint32_t tiles_x, uint32_t P, uint32_t W, uint32_t H, uint32_t dcap, int phase_channels,
+    const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
+    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
+    const uint32_t *__restrict__ dup_off, float2 *__restrict__ field, float *__restrict__ grad_rows) {
+    __shared__ float4 sh0[ACH], sh1[ACH], sh2[ACH], sh3[ACH];
+    __shared__ uint32_t shm[ACH], she[ACH];
+    const uint32_t key = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (b*P + p)*T + t
+    const uint32_t bp = key / tiles, t = key - bp * tiles;
+    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    const uint32_t X0 = tx * FGS_TILE, Y0 = ty * FGS_TILE;
+    const uint32_t start = ranges[2 * key], end = ranges[2 * key + 1];
+    const uint32_t lane = threadIdx.x, lx = lane & 7u, ly = lane >> 3;
+    const size_t HW = (size_t)W * H;
+    float2 *fbase = field + (size_t)bp * 3 * HW;  // [b][p][c][y][x]
+    float re[4][3], im[4][3];  // FWD: accumulators.  BWD: field gradient at this lane's pixels
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t px = X0 + 8u * (s & 1) + lx, py = Y0 + 8u * (s >> 1) + ly;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            re[s][c] = 0.0f; im[s][c] = 0.0f;
+            if (BWD && px < W && py < H) {
+                const float2 g = fbase[(size_t)c * HW + (size_t)py * W + px];
+                re[s][c] = g.x; im[s][c] = g.y;
+            }
+        }
+    }
+    for (uint32_t base = start; base < end; base += ACH) {
+        const uint32_t n = min((uint32_t)ACH, end - base);
+        if (lane < n) {
+            const uint32_t gid = dup_ids[base + lane];
+            const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
+            const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
+            const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu, by1 = bby >> 16;
+            shm[lane] = subtile_mask(X0, Y0, bx0, bx1, by0, by1);
+            if (BWD) {
+                const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
+                she[lane] = dup_off[gid] + (ty - ty0) * (tx1 - tx0 + 1) + (tx - tx0);
+            }
+            float cc[3], cs[3];
+            const float col[3] = {q1.z, q1.w, q2.x};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float ph = phase_channels == 3 ? phase[3 * (size_t)gid + c] : phase[gid];
+                float sn, co;
+                sincosf(ph, &sn, &co);
+                cc[c] = col[c] * co; cs[c] = col[c] * sn;
+            }
+            sh0[lane] = make_float4(q0.x, q0.y, q0.z, q0.w);                       // u, v, ca, cbc
+            sh1[lane] = make_float4(q1.x, q1.y, __uint_as_float(bx0 | ((bx1 - bx0) << 16)),
+                                    __uint_as_float(by0 | ((by1 - by0) << 16)));   // cd, op, bbx', bby'
+            sh2[lane] = make_float4(cc[0], cc[1], cc[2], cs[0]);
+            sh3[lane] = make_float4(cs[1], cs[2], 0.0f, 0.0f);
+        }
+        __syncthreads();
+        for (uint32_t j = 0; j < n; ++j) {
+            const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j], q3 = sh3[j];
+            const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
+            const uint32_t bbx = __float_as_uint(q1.z), bby = __float_as_uint(q1.w);
+            const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;
+            const float cc[3] = {q2.x, q2.y, q2.z}, cs[3] = {q2.w, q3.x, q3.y};
+            float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0;
+            float v_cc[3] = {0, 0, 0}, v_cs[3] = {0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (!((msk >> s) & 1u)) continue;
+                const uint32_t px = X0 + 8u * (s & 1) + lx, py = Y0 + 8u * (s >> 1) + ly;
+                const bool in = (px - (bbx & 0xFFFFu)) < (bbx >> 16) && (py - (bby & 0xFFFFu)) < (bby >> 16);
+                const float dx = (float)px - q0.x, dy = (float)py - q0.y;
+                const float m = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
+                const float G = in ? __builtin_amdgcn_exp2f(m * NEG_HALF_LOG2E) : 0.0f;
+                const float a = G * op;  // amplitude, DR:1270-1271 (no clamp on this path)
+                if (!BWD) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { re[s][c] += a * cc[c]; im[s][c] += a * cs[c]; }
+                } else {
+                    float da = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        da += cc[c] * re[s][c] + cs[c] * im[s][c];
+                        v_cc[c] += a * re[s][c]; v_cs[c] += a * im[s][c];
+                    }
+                    v_op += da * G;
+                    const float dm = -0.5f * (da * op) * G;
+                    v_ca += dm * dx * dx; v_cbc += dm * dx * dy; v_cd += dm * dy * dy;
+                    v_u -= dm * (2.0f * ca * dx + cbc * dy);
+                    v_v -= dm * (cbc * dx + 2.0f * cd * dy);
+                }
+            }
+            if (BWD) {
+                wave_sum12_lane63(v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_cc[0], v_cc[1], v_cc[2], v_cs[0], v_cs[1],
+                                  v_cs[2]);
+                if (lane == 63) {
+                    const uint32_t e = she[j];
+                    if (e < dcap) {
+                        float4 *dst = reinterpret_cast<float4 *>(grad_rows + (size_t)e * FGS_GROW_FLOATS);
+                        dst[0] = make_float4(v_u, v_v, v_ca, v_cbc);
+                        dst[1] = make_float4(v_cd, v_op, v_cc[0], v_cc[1]);
+                        dst[2] = make_float4(v_cc[2], v_cs[0], v_cs[1], v_cs[2]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t px = X0 + 8u * (s & 1) + lx, py = Y0 + 8u * (s >> 1) + ly;
+            if (px < W && py < H) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    fbase[(size_t)c * HW + (size_t)py * W + px] = make_float2(re[s][c], im[s][c]);
+            }
+        }
+    }
+}
+
+// acc[b][c][k] = sum_p F[b][p][c][k] * H[c][p][k]
+__global__ __launch_bounds__(256) void k_asm_accumulate(size_t HW, int B, int P, const float2 *__restrict__ field,
+                                                        const float2 *__restrict__ htab,
+                                                        float2 *__restrict__ acc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * 3 * HW) return;
+    const size_t k = i % HW;
+    const int c = (int)((i / HW) % 3), b = (int)(i / (3 * HW));
+    float2 s = make_float2(0.0f, 0.0f);
+    for (int p = 0; p < P; ++p) {
+        const float2 f = field[(((size_t)b * P + p) * 3 + c) * HW + k];
+        const float2 h = htab[((size_t)c * P + p) * HW + k];
+        const float2 t = cmul(f, h);
+        s.x += t.x; s.y += t.y;
+    }
+    acc[i] = s;
+}
+
+// per-image max of sqrt(|U|^2 + 1e-8) over pixels and channels (DR:1316-1322); r >= 0, so the
+// float ordering equals the ordering of the bit patterns and atomicMax(uint) is exact
+__global__ __launch_bounds__(256) void k_asm_max(size_t HW, float inv_hw, const float2 *__restrict__ total,
+                                                 float *__restrict__ scal) {
+    const int b = blockIdx.y;
+    float mx = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < 3 * HW; i += (size_t)gridDim.x * 256) {
+        const float2 u = total[(size_t)b * 3 * HW + i];
+        const float ur = u.x * inv_hw, ui = u.y * inv_hw;
+        mx = fmaxf(mx, sqrtf(ur * ur + ui * ui + 1e-8f));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63u) == 0) atomicMax(reinterpret_cast<unsigned int *>(scal + b), __float_as_uint(mx));
+}
+
+struct PixOut {
+    float r[3], a[3], n[3], v[3], asum, ta, M;
+};
+
+__device__ __forceinline__ void pixel_forward(const float2 u[3], float inv_hw, float maxval, const float bg[3],
+                                              PixOut &o) {
+    o.M = maxval < 1.0f ? 1.0f : maxval;  // clamp(min=1), DR:1322
+    o.asum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float ur = u[c].x * inv_hw, ui = u[c].y * inv_hw;
+        const float I = ur * ur + ui * ui;
+        o.r[c] = sqrtf(I + 1e-8f);
+        o.a[c] = sqrtf(I);  // |U| of the complex field, DR:1327
+        o.asum += o.a[c];
+        const float q = o.r[c] / o.M;
+        o.n[c] = q < 0.0f ? 0.0f : (q > 1.0f ? 1.0f : q);
+    }
+    o.ta = o.asum < 0.0f ? 0.0f : (o.asum > 1.0f ? 1.0f : o.asum);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o.v[c] = o.n[c] + bg[c] * (1.0f - o.ta);
+}
+
+__global__ __launch_bounds__(256) void k_asm_output(size_t HW, float inv_hw, float bg0, float bg1, float bg2,
+                                                    const float2 *__restrict__ total,
+                                                    const float *__restrict__ scal, float *__restrict__ out) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float2 u[3] = {total[((size_t)b * 3 + 0) * HW + i], total[((size_t)b * 3 + 1) * HW + i],
+                         total[((size_t)b * 3 + 2) * HW + i]};
+    const float bg[3] = {bg0, bg1, bg2};
+    PixOut o;
+    pixel_forward(u, inv_hw, scal[b], bg, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = o.v[c];
+        out[((size_t)b * 3 + c) * HW + i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    }
+}
+
+// backward of k_asm_output, pass 1: gM = dL/dM and the number of maxima (torch.max() spreads
+// the gradient evenly over equal maxima)
+__global__ __launch_bounds__(256) void k_asm_output_bwd1(size_t HW, float inv_hw, float bg0, float bg1, float bg2,
+                                                         const float2 *__restrict__ total,
+                                                         float *__restrict__ scal, const float *__restrict__ g_out) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float gM = 0.0f, cnt = 0.0f;
+    if (i < HW) {
+        const float2 u[3] = {total[((size_t)b * 3 + 0) * HW + i], total[((size_t)b * 3 + 1) * HW + i],
+                             total[((size_t)b * 3 + 2) * HW + i]};
+        const float bg[3] = {bg0, bg1, bg2};
+        const float maxval = scal[b];
+        PixOut o;
+        pixel_forward(u, inv_hw, maxval, bg, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = o.v[c];
+            const float gv = (v >= 0.0f && v <= 1.0f) ? g_out[((size_t)b * 3 + c) * HW + i] : 0.0f;
+            const float q = o.r[c] / o.M;
+            const float gq = (q >= 0.0f && q <= 1.0f) ? gv : 0.0f;
+            gM -= gq * o.r[c] / (o.M * o.M);
+            if (o.r[c] == maxval) cnt += 1.0f;
+        }
+    }
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) { gM += __shfl_xor(gM, of, 64); cnt += __shfl_xor(cnt, of, 64); }
+    if ((threadIdx.x & 63u) == 0) {
+        if (gM != 0.0f) atomicAdd(scal + gridDim.y + b, gM);
+        if (cnt != 0.0f) atomicAdd(scal + 2 * gridDim.y + b, cnt);
+    }
+}
+
+// pass 2: gradient w.r.t. the (unnormalised) total field, written over `gtot`
+__global__ __launch_bounds__(256) void k_asm_output_bwd2(size_t HW, float inv_hw, float bg0, float bg1, float bg2,
+                                                         const float2 *__restrict__ total,
+                                                         const float *__restrict__ scal,
+                                                         const float *__restrict__ g_out, float2 *__restrict__ gtot) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float2 u[3] = {total[((size_t)b * 3 + 0) * HW + i], total[((size_t)b * 3 + 1) * HW + i],
+                         total[((size_t)b * 3 + 2) * HW + i]};
+    const float bg[3] = {bg0, bg1, bg2};
+    const float maxval = scal[b];
+    const float cntm = scal[2 * gridDim.y + b];
+    const float gMshare = (maxval >= 1.0f && cntm > 0.0f) ? scal[gridDim.y + b] / cntm : 0.0f;
+    PixOut o;
+    pixel_forward(u, inv_hw, maxval, bg, o);
+    float gv[3], gta = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gv[c] = (o.v[c] >= 0.0f && o.v[c] <= 1.0f) ? g_out[((size_t)b * 3 + c) * HW + i] : 0.0f;
+        gta -= gv[c] * bg[c];
+    }
+    const float gas = (o.asum >= 0.0f && o.asum <= 1.0f) ? gta : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float q = o.r[c] / o.M;
+        float gr = ((q >= 0.0f && q <= 1.0f) ? gv[c] : 0.0f) / o.M;
+        if (o.r[c] == maxval) gr += gMshare;
+        // r = sqrt(I + 1e-8), a = sqrt(I), I = |u * inv_hw|^2
+        const float gI = gr / (2.0f * o.r[c]) + (o.a[c] > 0.0f ? gas / (2.0f * o.a[c]) : 0.0f);
+        const float k = 2.0f * gI * inv_hw * inv_hw;
+        gtot[((size_t)b * 3 + c) * HW + i] = make_float2(k * u[c].x, k * u[c].y);
+    }
+}
+
+// gF[b][p][c][k] = gAcc[b][c][k] * conj(H[c][p][k]) (overwrites the saved spectra F after using
+// them for the wavelength gradient): theta = 2 pi z kz, dL/dtheta = -Im(H conj(gH)), gH = conj(F) gAcc
+__global__ __launch_bounds__(256) void k_asm_accumulate_bwd(int W, int H, int B, int P, float near_, float far_,
+                                                            float focal, float inv_ndx, float inv_ndy,
+                                                            const float *__restrict__ wavelengths,
+                                                            const float2 *__restrict__ gacc,
+                                                            const float2 *__restrict__ htab,
+                                                            float2 *__restrict__ field,
+                                                            float *__restrict__ g_wavelengths) {
+    const size_t HW = (size_t)W * H;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    float gl = 0.0f;
+    if (i < (size_t)B * HW) {
+        const size_t k = i % HW;
+        const int b = (int)(i / HW);
+        const int kx = (int)(k % W), ky = (int)(k / W);
+        const float fx = fftfreq(kx, W, inv_ndx), fy = fftfreq(ky, H, inv_ndy);
+        const float wl = wavelengths[c];
+        const float il = 1.0f / wl;
+        const float kz2 = il * il - fx * fx - fy * fy;
+        const float kz = kz2 > 0.0f ? sqrtf(kz2) : 0.0f;
+        // d kz / d lambda = -1 / (lambda^3 kz) where kz2 > 0, else 0 (clamp / evanescent)
+        const float dkz = kz2 > 0.0f ? -(il * il * il) / kz : 0.0f;
+        const float2 g = gacc[((size_t)b * 3 + c) * HW + k];
+        for (int p = 0; p < P; ++p) {
+            const size_t fi = (((size_t)b * P + p) * 3 + c) * HW + k;
+            const float2 f = field[fi];
+            const float2 h = htab[((size_t)c * P + p) * HW + k];
+            const float2 gH = cmul(make_float2(f.x, -f.y), g);          // conj(F) * gAcc
+            const float gtheta = -(h.y * gH.x - h.x * gH.y);             // -Im(H * conj(gH))
+            const float z = focal - plane_depth(p, P, near_, far_);
+            gl += gtheta * (6.28318530717958647692f * z) * dkz;
+            field[fi] = cmul(g, make_float2(h.x, -h.y));
+        }
+    }
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) gl += __shfl_xor(gl, of, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = gl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float s = (part[0] + part[1]) + (part[2] + part[3]);
+        if (s != 0.0f) atomicAdd(g_wavelengths + c, s);
+    }
+}
+
+int check_ptrs(const void *const *ptrs, int n, const char *who) {
+    for (int i = 0; i < n; ++i)
+        if (!ptrs[i]) { fgs_set_error("%s: null pointer argument #%d", who, i); return FGS_EINVAL; }
+    return FGS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fgs_asm_workspace_bytes(const FgsAsmDims *dims, size_t *saved_bytes, size_t *scratch_bytes) {
+    AsmPlan p;
+    const int rc = make_asm_plan(dims, &p, true);
+    if (rc) return rc;
+    if (saved_bytes) *saved_bytes = p.v_total_bytes;
+    if (scratch_bytes) *scratch_bytes = p.c_total_bytes;
+    return FGS_OK;
+}
+
+int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *pos, const float *scale,
+                    const float *quat, const float *color, const float *opacity, const float *phase,
+                    const float *wavelengths, float *out_rgb, void *saved, void *scratch, void *stream) {
+    AsmPlan p;
+    int rc = make_asm_plan(dims, &p, true);
+    if (rc) return rc;
+    const void *ptrs[] = {cameras, pos, scale, quat, color, opacity, phase, wavelengths, out_rgb, saved, scratch};
+    if ((rc = check_ptrs(ptrs, 11, "fgs_asm_forward"))) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char *sv = reinterpret_cast<char *>(saved), *sc = reinterpret_cast<char *>(scratch);
+    const FgsAsmDims &a = p.a;
+    const int B = a.batch, P = a.num_planes, W = a.width, H = a.height;
+    const size_t HW = p.HW;
+    fgs_stage_begin(ST_PROJECT, st);
+    if ((rc = fgs_launch_project(p.base, cameras, pos, scale, quat, color, opacity, sv, st, P, a.depth_near, a.depth_far)))
+        return rc;
+    fgs_stage_end(ST_PROJECT, st);
+    if ((rc = fgs_launch_binning(p.base, sv, sc, st))) return rc;
+    fgs_stage_begin(ST_ASM, st);
+    float2 *field = reinterpret_cast<float2 *>(sv + p.v_field);
+    float2 *htab = reinterpret_cast<float2 *>(sv + p.v_htab);
+    float2 *total = reinterpret_cast<float2 *>(sv + p.v_total);
+    float *scal = reinterpret_cast<float *>(sv + p.v_scal);
+    const uint32_t grid = (uint32_t)B * P * p.base.tiles;
+    hipLaunchKernelGGL(k_asm_splat<false>, dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+                       (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
+                       (uint32_t)p.base.L.dup_capacity, a.phase_channels,
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
+                       reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr);
+    FGS_LAUNCH_CHECK("k_asm_splat");
+    if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
+    const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
+    const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
+    const size_t nh = 3 * (size_t)P * HW;
+    hipLaunchKernelGGL(k_asm_transfer, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st, W, H, P, a.depth_near,
+                       a.depth_far, a.focal_depth, inv_ndx, inv_ndy, wavelengths, htab);
+    FGS_LAUNCH_CHECK("k_asm_transfer");
+    const size_t na = (size_t)B * 3 * HW;
+    hipLaunchKernelGGL(k_asm_accumulate, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, HW, B, P, field, htab,
+                       total);
+    FGS_LAUNCH_CHECK("k_asm_accumulate");
+    if ((rc = run_fft(H, W, B * 3, total, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
+    hipError_t e = hipMemsetAsync(scal, 0, (size_t)B * 4 * sizeof(float), st);
+    if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
+    const float inv_hw = 1.0f / (float)HW;
+    unsigned gx = (unsigned)((3 * HW + 255) / 256);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(k_asm_max, dim3(gx, B), dim3(256), 0, st, HW, inv_hw, total, scal);
+    FGS_LAUNCH_CHECK("k_asm_max");
+    hipLaunchKernelGGL(k_asm_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, inv_hw,
+                       a.background[0], a.background[1], a.background[2], total, scal, out_rgb);
+    FGS_LAUNCH_CHECK("k_asm_output");
+    fgs_stage_end(ST_ASM, st);
+    return FGS_OK;
+}
+
+int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *pos, const float *scale,
+                     const float *quat, const float *color, const float *opacity, const float *phase,
+                     const float *wavelengths, void *saved, void *scratch, const float *g_rgb, float *g_pos,
+                     float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
+                     float *g_wavelengths, void *stream) {
+    AsmPlan p;
+    int rc = make_asm_plan(dims, &p, true);
+    if (rc) return rc;
+    const void *ptrs[] = {cameras, pos, scale, quat, color, opacity, phase, wavelengths, saved, scratch, g_rgb,
+                          g_pos, g_scale, g_quat, g_color, g_opacity, g_phase, g_wavelengths};
+    if ((rc = check_ptrs(ptrs, 18, "fgs_asm_backward"))) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char *sv = reinterpret_cast<char *>(saved), *sc = reinterpret_cast<char *>(scratch);
+    const FgsAsmDims &a = p.a;
+    const int B = a.batch, P = a.num_planes, W = a.width, H = a.height;
+    const size_t HW = p.HW;
+    float2 *field = reinterpret_cast<float2 *>(sv + p.v_field);
+    float2 *htab = reinterpret_cast<float2 *>(sv + p.v_htab);
+    float2 *total = reinterpret_cast<float2 *>(sv + p.v_total);
+    float *scal = reinterpret_cast<float *>(sv + p.v_scal);
+    float2 *gtot = reinterpret_cast<float2 *>(sc + p.c_acc);
+    const float inv_hw = 1.0f / (float)HW;
+    fgs_stage_begin(ST_COMPOSITE_BWD, st);
+    hipError_t e = hipMemsetAsync(g_wavelengths, 0, 3 * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(scal + B, 0, 2 * (size_t)B * sizeof(float), st);
+    if (e != hipSuccess) { fgs_set_error("memset g_wavelengths: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
+    const dim3 gpix((unsigned)((HW + 255) / 256), B);
+    hipLaunchKernelGGL(k_asm_output_bwd1, gpix, dim3(256), 0, st, HW, inv_hw, a.background[0], a.background[1],
+                       a.background[2], total, scal, g_rgb);
+    FGS_LAUNCH_CHECK("k_asm_output_bwd1");
+    hipLaunchKernelGGL(k_asm_output_bwd2, gpix, dim3(256), 0, st, HW, inv_hw, a.background[0], a.background[1],
+                       a.background[2], total, scal, g_rgb, gtot);
+    FGS_LAUNCH_CHECK("k_asm_output_bwd2");
+    // adjoint of the unnormalised inverse FFT is the unnormalised forward FFT
+    if ((rc = run_fft(H, W, B * 3, gtot, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
+    const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
+    const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
+    hipLaunchKernelGGL(k_asm_accumulate_bwd, dim3((unsigned)(((size_t)B * HW + 255) / 256), 3), dim3(256), 0, st, W, H,
+                       B, P, a.depth_near, a.depth_far, a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, field,
+                       g_wavelengths);
+    FGS_LAUNCH_CHECK("k_asm_accumulate_bwd");
+    // adjoint of the forward FFT is the unnormalised inverse FFT
+    if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
+    const uint32_t grid = (uint32_t)B * P * p.base.tiles;
+    float *rows = reinterpret_cast<float *>(sc + p.base.s_grows);
+    hipLaunchKernelGGL(k_asm_splat<true>, dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+                       (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
+                       (uint32_t)p.base.L.dup_capacity, a.phase_channels,
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
+                       reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows);
+    FGS_LAUNCH_CHECK("k_asm_splat_bwd");
+    fgs_stage_end(ST_COMPOSITE_BWD, st);
+    fgs_stage_begin(ST_PROJECT_BWD, st);
+    if ((rc = fgs_launch_asm_project_bwd(p.base, cameras, pos, scale, quat, color, phase, a.phase_channels, sv, rows,
+                                         g_pos, g_scale, g_quat, g_color, g_opacity, g_phase, st)))
+        return rc;
+    fgs_stage_end(ST_PROJECT_BWD, st);
+    return FGS_OK;
+}
+
+}  // extern "C"

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
                                                   const uint32_t *__restrict__ tile_count,
                                                   const float *__restrict__ rec,
                                                   const uint32_t *__restrict__ bsum,
+                                                  const uint32_t *__restrict__ layer, uint32_t layers,
                                                   uint32_t *__restrict__ dup_off,
                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t gid, tot;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
     const uint32_t bby = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBY]);
     const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
     const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE, ty1 = ((bby >> 16) - 1) / FGS_TILE;
-    const uint32_t kbase = (gid / N) * tiles;
+    const uint32_t kbase = ((gid / N) * layers + (layer ? layer[gid] : 0u)) * tiles;
     for (uint32_t ty = ty0; ty <= ty1; ++ty)
         for (uint32_t tx = tx0; tx <= tx1; ++tx) {
             if (off < dcap) {
@@ -205,7 +206,8 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     // (3) emit (tile key, gaussian id) in depth order
     hipLaunchKernelGGL(k_dup_emit, dim3(nblk), dim3(256), 0, st, total, N, (uint32_t)p.tiles,
                        (uint32_t)p.L.tiles_x, dcap, order, tile_count, rec, bsum,
-                       reinterpret_cast<uint32_t *>(saved + p.L.dup_off), keys0, vals0);
+                       p.layers > 1 ? reinterpret_cast<const uint32_t *>(saved + p.s_layer) : nullptr,
+                       (uint32_t)p.layers, reinterpret_cast<uint32_t *>(saved + p.L.dup_off), keys0, vals0);
     FGS_LAUNCH_CHECK("k_dup_emit");
     fgs_stage_end(ST_DUP_EMIT, st);
     fgs_stage_begin(ST_TILE_SORT, st);
@@ -216,13 +218,13 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     fgs_stage_end(ST_TILE_SORT, st);
     fgs_stage_begin(ST_TILE_RANGES, st);
     // (5) per-tile [start,end)
-    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)B * p.tiles * 2 * sizeof(uint32_t), st);
+    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)B * p.layers * p.tiles * 2 * sizeof(uint32_t), st);
     if (e != hipSuccess) { fgs_set_error("memset ranges: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     uint32_t rgrid = (dcap + 255) / 256;
     if (rgrid > 2048) rgrid = 2048;
     hipLaunchKernelGGL(k_tile_ranges, dim3(rgrid), dim3(256), 0, st, counters, ks, ranges);
     FGS_LAUNCH_CHECK("k_tile_ranges");
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, B * (uint32_t)p.tiles, ranges,
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, B * (uint32_t)p.layers * (uint32_t)p.tiles, ranges,
                        reinterpret_cast<uint32_t *>(saved + p.L.tile_order));
     FGS_LAUNCH_CHECK("k_tile_order");
     fgs_stage_end(ST_TILE_RANGES, st);

@@ -18,6 +18,7 @@
 // backward); HBM traffic is the 52-byte id+record gather per duplicate plus per-pixel state.
 #include <stdlib.h>
 #include "fgs_internal.h"
+#include "fgs_wave.h"
 
 namespace {
 
@@ -45,48 +46,18 @@ __device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x,
     return c;
 }
 
-// Wave-wide sums of ten values; totals are valid in lane 63.  Hand-written fused
-// v_add_f32_dpp (hipcc emits v_mov_dpp + v_pk_add pairs for the builtin form: 2.5x the
-// instructions).  The ten chains are interleaved so that dependent DPP reads are ten
-// instructions apart (>= the 2 wait states a VALU write -> DPP read needs); the leading s_nop
-// covers the producers of the inputs.  row_shr 1,2,4,8 sum each 16-lane row into its lane 15;
-// row_bcast:15 / row_bcast:31 carry the row totals to lane 63.
-__device__ __forceinline__ void wave_sum10_lane63(float &a0, float &a1, float &a2, float &a3, float &a4,
-                                                  float &a5, float &a6, float &a7, float &a8, float &a9) {
-#define FGS_STEP(ctrl)                                                                                     \
-    "v_add_f32_dpp %0, %0, %0 " ctrl "\n v_add_f32_dpp %1, %1, %1 " ctrl "\n v_add_f32_dpp %2, %2, %2 " ctrl  \
-    "\n v_add_f32_dpp %3, %3, %3 " ctrl "\n v_add_f32_dpp %4, %4, %4 " ctrl "\n v_add_f32_dpp %5, %5, %5 " ctrl \
-    "\n v_add_f32_dpp %6, %6, %6 " ctrl "\n v_add_f32_dpp %7, %7, %7 " ctrl "\n v_add_f32_dpp %8, %8, %8 " ctrl \
-    "\n v_add_f32_dpp %9, %9, %9 " ctrl "\n"
-    asm volatile("s_nop 1\n" FGS_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
-                 FGS_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-                 FGS_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
-                 FGS_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-                 FGS_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 FGS_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n"
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
-                   "+v"(a9));
-#undef FGS_STEP
-}
 
 // Forward: TWO waves per tile (wave w owns sub-tiles 2w and 2w+1, i.e. the upper / lower half of
 // the tile).  The forward has no cross-lane reduction, so splitting a tile over two waves is free
 // and halves the serial length of the longest lists -- with 8 images per GPU the launch is
 // otherwise limited by its few longest tiles.  Both waves share the LDS-staged chunk.
 
-// Staging-time (per lane, parallel over the chunk) decode of a record's bbox against this tile:
-//   msk  bit s   = sub-tile s (8x8, s = 2*row + col) intersects the bbox
-//   bbx' = x0 | (x1 - x0) << 16,  bby' = y0 | (y1 - y0) << 16   (origin + extent), so the
-// per-pixel membership test in the loop is (px - x0) < wx && (py - y0) < wy in unsigned
-// arithmetic: two SDWA subtracts + two SDWA compares, no scalar bit-field decoding.
-// Doing this here keeps the blend loop at ~2 scalar instructions per sub-tile; the scalar unit
-// is shared by the CU's four SIMDs and was the co-bottleneck of the first version.
-__device__ __forceinline__ uint32_t subtile_mask(uint32_t X0, uint32_t Y0, uint32_t x0, uint32_t x1, uint32_t y0,
-                                                 uint32_t y1) {
-    const uint32_t cx0 = (x1 > X0 && x0 < X0 + 8u) ? 1u : 0u, cx1 = (x1 > X0 + 8u && x0 < X0 + 16u) ? 1u : 0u;
-    const uint32_t ry0 = (y1 > Y0 && y0 < Y0 + 8u) ? 1u : 0u, ry1 = (y1 > Y0 + 8u && y0 < Y0 + 16u) ? 1u : 0u;
-    return (cx0 & ry0) | ((cx1 & ry0) << 1) | ((cx0 & ry1) << 2) | ((cx1 & ry1) << 3);
-}
+// The blend loops keep scalar work to ~2 instructions per sub-tile: each record's bbox is decoded
+// at staging time (per lane, parallel over the chunk) into a 4-bit touched-sub-tile mask
+// (subtile_mask, fgs_wave.h) and re-packed as origin | extent << 16, so the per-pixel membership
+// test is (px - x0) < wx && (py - y0) < wy in unsigned arithmetic (two SDWA subtracts + two SDWA
+// compares, no scalar bit-field decoding).  The scalar unit is shared by the CU's four SIMDs and
+// was the co-bottleneck of the first version (SQ_INSTS_SALU 313 M vs SQ_INSTS_VALU 587 M).
 
 template <bool PHASE, int FWD_WAVES>
 __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
@@ -293,25 +264,6 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
         }
         __syncthreads();
     }
-}
-
-// eleven-value variant (adds dL/dphase) for the phase path
-__device__ __forceinline__ void wave_sum11_lane63(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
-                                                  float &a6, float &a7, float &a8, float &a9, float &a10) {
-#define FGS_STEP(ctrl)                                                                                     \
-    "v_add_f32_dpp %0, %0, %0 " ctrl "\n v_add_f32_dpp %1, %1, %1 " ctrl "\n v_add_f32_dpp %2, %2, %2 " ctrl  \
-    "\n v_add_f32_dpp %3, %3, %3 " ctrl "\n v_add_f32_dpp %4, %4, %4 " ctrl "\n v_add_f32_dpp %5, %5, %5 " ctrl \
-    "\n v_add_f32_dpp %6, %6, %6 " ctrl "\n v_add_f32_dpp %7, %7, %7 " ctrl "\n v_add_f32_dpp %8, %8, %8 " ctrl \
-    "\n v_add_f32_dpp %9, %9, %9 " ctrl "\n v_add_f32_dpp %10, %10, %10 " ctrl "\n"
-    asm volatile("s_nop 1\n" FGS_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
-                 FGS_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-                 FGS_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
-                 FGS_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-                 FGS_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 FGS_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n"
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
-                   "+v"(a9), "+v"(a10));
-#undef FGS_STEP
 }
 
 // Phase-blending backward (the reference cannot backprop this path at

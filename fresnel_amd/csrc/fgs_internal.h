@@ -17,6 +17,8 @@ enum { R_U = 0, R_V, R_CA, R_CBC, R_CD, R_OP, R_CR, R_CG, R_CB, R_DEPTH, R_BBX, 
 struct FgsPlan {
     FgsDims d;
     FgsSavedLayout L;
+    int32_t layers;           // independent tile grids per image (ASM depth planes; 1 for TBR)
+    size_t s_layer;           // saved: uint32 [B][N] layer of each Gaussian (layers > 1 only)
     int32_t tiles;            // tiles per image
     int32_t tiles_per_gauss;  // worst-case tiles touched by one Gaussian
     uint32_t tile_key_bits;   // bits of (image*T + tile)
@@ -29,7 +31,7 @@ struct FgsPlan {
     size_t s_grows;           // float [Dcap][12]: per-duplicate gradient rows (composite bwd -> reduce)
 };
 
-int fgs_make_plan(const FgsDims *dims, FgsPlan *plan);
+int fgs_make_plan(const FgsDims *dims, FgsPlan *plan, int layers = 1);
 void fgs_set_error(const char *fmt, ...);
 
 #define FGS_LAUNCH_CHECK(what)                                              \
@@ -47,13 +49,20 @@ void fgs_stage_begin(int stage, hipStream_t st);  // no-ops unless fgs_stage_tim
 void fgs_stage_end(int stage, hipStream_t st);
 
 // ---- stage launchers (each enqueues on `st`, returns FGS_OK / FGS_ELAUNCH) ----
+// plane_* != 0 selects the ASM variant: additionally writes saved.layer = nearest depth plane
+// (DR:1136-1148) of each Gaussian
 int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                        const float *quat, const float *color, const float *opacity, char *saved,
-                       hipStream_t st);
+                       hipStream_t st, int num_planes = 0, float plane_near = 0.0f, float plane_far = 0.0f);
 int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                            const float *quat, const char *saved, const float *grad_rows, float *g_pos,
                            float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
                            hipStream_t st);
+
+int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
+                               const float *quat, const float *color, const float *phase, int phase_channels,
+                               const char *saved, const float *grad_rows, float *g_pos, float *g_scale,
+                               float *g_quat, float *g_color, float *g_opacity, float *g_phase, hipStream_t st);
 
 // Stable LSD radix sort of (key,val) uint32 pairs over `num_segs` independent segments.
 // Segment s covers elements [s*seg_stride, s*seg_stride + len) with len = seg_len (host) or

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void k_project(
     int32_t total, int32_t N, int32_t W, int32_t H, int32_t num_cameras, float max_radius,
     const float *__restrict__ cams, const float *__restrict__ pos, const float *__restrict__ scale,
     const float *__restrict__ quat, const float *__restrict__ color, const float *__restrict__ opacity,
-    float *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ tile_count) {
+    float *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ tile_count,
+    uint32_t *__restrict__ layer, int32_t num_planes, float plane_near, float plane_far) {
     const int32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int32_t b = idx / N;
@@ -140,6 +141,19 @@ __global__ __launch_bounds__(256) void k_project(
                          __uint_as_float((uint32_t)y0 | ((uint32_t)y1 << 16)));
     depth_key[idx] = vis ? fgs_float_key(o.dep) : 0xFFFFFFFFu;
     tile_count[idx] = ntiles;
+    if (layer) {
+        // nearest depth plane, DR:1106 (torch.linspace) + DR:1147-1148 (first argmin of |depth - plane|)
+        const float step = (plane_far - plane_near) / (float)(num_planes - 1);
+        int32_t best = 0;
+        float bd = 3.4e38f;
+        for (int32_t k = 0; k < num_planes; ++k) {
+            const float pk = (k < num_planes / 2) ? plane_near + step * (float)k
+                                                  : plane_far - step * (float)(num_planes - 1 - k);
+            const float dd = fabsf(o.dep - pk);
+            if (dd < bd) { bd = dd; best = k; }
+        }
+        layer[idx] = (uint32_t)best;
+    }
 }
 
 // Gradient-row reduction + projection backward (autograd of DR:98-195 + DR:578-579).
@@ -148,6 +162,11 @@ __global__ __launch_bounds__(256) void k_project(
 // contiguous 48-byte gradient rows in a fixed order (deterministic), then chains
 // (dL/dmean2d, dL/dconic, dL/ddepth) to (dL/dpos, dL/dscale, dL/dquat), recomputing the forward
 // intermediates from the inputs (cheaper than saving ~60 floats per Gaussian).
+// ASM = true: rows come from the angular-spectrum splat backward and hold
+//   (dL/du, dL/dv, dL/dconic[3], dL/dopacity, dL/d(c cos phi)[3], dL/d(c sin phi)[3]);
+// colour and phase gradients are formed here and no gradient flows through depth (the depth
+// only selects the plane, DR:1147-1148).
+template <bool ASM>
 __global__ __launch_bounds__(256) void k_project_bwd(
     int32_t total, int32_t N, int32_t num_cameras, uint32_t dcap, const float *__restrict__ cams,
     const float *__restrict__ pos, const float *__restrict__ scale, const float *__restrict__ quat,
@@ -155,7 +174,8 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const uint32_t *__restrict__ dup_off, const uint32_t *__restrict__ tile_count,
     const float *__restrict__ grad_rows, float *__restrict__ g_pos, float *__restrict__ g_scale,
     float *__restrict__ g_quat, float *__restrict__ g_color, float *__restrict__ g_opacity,
-    float *__restrict__ g_phase) {
+    float *__restrict__ g_phase, const float *__restrict__ color, const float *__restrict__ phase,
+    int32_t phase_channels) {
     // four lanes per Gaussian: lane `sub` sums rows sub, sub+4, ... (neighbouring lanes read
     // neighbouring 48-byte rows), then two quad shuffles combine the partial sums in a fixed order
     const int32_t tid = blockIdx.x * 256 + threadIdx.x;
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const int32_t b = live ? ri / N : 0;
     const int32_t idx = live ? b * N + (int32_t)order[ri] : 0;
     float gp[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0};
-    float acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (live) {
         const uint32_t cnt = tile_count[idx], off = dup_off[idx];
         for (uint32_t k = sub; k < cnt && off + k < dcap; k += 4) {
@@ -173,24 +193,41 @@ __global__ __launch_bounds__(256) void k_project_bwd(
             const float4 a = r[0], bq = r[1], cq = r[2];
             acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
             acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
-            acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z;
+            acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z; acc[11] += cq.w;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
+    for (int k = 0; k < 12; ++k) {
         acc[k] += __shfl_xor(acc[k], 1, 64);
         acc[k] += __shfl_xor(acc[k], 2, 64);
     }
     if (!live || sub != 0) return;
     const float4 s0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
     const float4 s1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    const float4 s2 = make_float4(acc[8], acc[9], acc[10], 0.0f);
+    const float4 s2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
     const float g_mean[2] = {s0.x, s0.y};
     const float g_conic[3] = {s0.z, s0.w, s1.x};
-    const float g_depth = s2.y;
+    float g_depth = s2.y;
     g_opacity[idx] = s1.y;
-    if (g_phase) g_phase[idx] = s2.z;
-    g_color[3 * idx] = s1.z; g_color[3 * idx + 1] = s1.w; g_color[3 * idx + 2] = s2.x;
+    if (!ASM) {
+        if (g_phase) g_phase[idx] = s2.z;
+        g_color[3 * idx] = s1.z; g_color[3 * idx + 1] = s1.w; g_color[3 * idx + 2] = s2.x;
+    } else {
+        g_depth = 0.0f;
+        const float dcc[3] = {s1.z, s1.w, s2.x}, dcs[3] = {s2.y, s2.z, acc[11]};
+        float gph = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float ph = phase_channels == 3 ? phase[3 * idx + ch] : phase[idx];
+            float sn, cs;
+            sincosf(ph, &sn, &cs);
+            const float col = color[3 * idx + ch];
+            g_color[3 * idx + ch] = dcc[ch] * cs + dcs[ch] * sn;
+            const float gp1 = col * (dcs[ch] * cs - dcc[ch] * sn);
+            if (phase_channels == 3) g_phase[3 * idx + ch] = gp1; else gph += gp1;
+        }
+        if (phase_channels != 3) g_phase[idx] = gph;
+    }
     if (depth_key[idx] != 0xFFFFFFFFu) {
         const float *__restrict__ V = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
         const float p[3] = {pos[3 * idx], pos[3 * idx + 1], pos[3 * idx + 2]};
@@ -298,14 +335,16 @@ __global__ __launch_bounds__(256) void k_project_bwd(
 
 int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                        const float *quat, const float *color, const float *opacity, char *saved,
-                       hipStream_t st) {
+                       hipStream_t st, int num_planes, float plane_near, float plane_far) {
     const int32_t total = p.d.batch * p.d.num_gaussians;
     const int grid = (total + 255) / 256;
     hipLaunchKernelGGL(k_project, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians, p.d.width,
                        p.d.height, p.d.num_cameras, p.d.max_radius, cams, pos, scale, quat, color, opacity,
                        reinterpret_cast<float *>(saved + p.L.rec),
                        reinterpret_cast<uint32_t *>(saved + p.L.depth_key),
-                       reinterpret_cast<uint32_t *>(saved + p.L.tile_count));
+                       reinterpret_cast<uint32_t *>(saved + p.L.tile_count),
+                       num_planes > 0 ? reinterpret_cast<uint32_t *>(saved + p.s_layer) : nullptr, num_planes,
+                       plane_near, plane_far);
     FGS_LAUNCH_CHECK("k_project");
     return FGS_OK;
 }
@@ -316,13 +355,30 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
                            hipStream_t st) {
     const int32_t total = p.d.batch * p.d.num_gaussians;
     const int grid = (int)(((size_t)total * 4 + 255) / 256);
-    hipLaunchKernelGGL(k_project_bwd, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
+    hipLaunchKernelGGL(k_project_bwd<false>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
                        p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat,
                        reinterpret_cast<const uint32_t *>(saved + p.L.depth_key),
                        reinterpret_cast<const uint32_t *>(saved + p.L.order),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                       g_quat, g_color, g_opacity, g_phase);
+                       g_quat, g_color, g_opacity, g_phase, nullptr, nullptr, 1);
     FGS_LAUNCH_CHECK("k_project_bwd");
+    return FGS_OK;
+}
+
+int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
+                               const float *quat, const float *color, const float *phase, int phase_channels,
+                               const char *saved, const float *grad_rows, float *g_pos, float *g_scale,
+                               float *g_quat, float *g_color, float *g_opacity, float *g_phase, hipStream_t st) {
+    const int32_t total = p.d.batch * p.d.num_gaussians;
+    const int grid = (int)(((size_t)total * 4 + 255) / 256);
+    hipLaunchKernelGGL(k_project_bwd<true>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
+                       p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat,
+                       reinterpret_cast<const uint32_t *>(saved + p.L.depth_key),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.order),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
+                       g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels);
+    FGS_LAUNCH_CHECK("k_asm_project_bwd");
     return FGS_OK;
 }

@@ -103,6 +103,46 @@ int fgs_backward(const FgsDims *dims, const float *cameras, const float *pos, co
  * `out_pairs` (device). */
 int fgs_count_pairs(const FgsDims *dims, const void *saved, uint64_t *out_pairs, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Angular-spectrum wave-field renderer: replaces ASMWaveFieldRenderer.forward (DR:1150-1344)
+ * and AngularSpectrumPropagator (DR:929-1065).  Gaussians are splatted as complex amplitudes
+ * onto num_planes depth planes (DR:1233-1283), every plane/channel is propagated to the focal
+ * plane with the angular-spectrum transfer function H = exp(i 2 pi z sqrt(max(1/l^2-fx^2-fy^2,0)))
+ * (DR:989-999) using batched hipFFT/rocFFT transforms, summed (one inverse FFT per channel, by
+ * linearity), converted to intensity, normalised by the per-image maximum and composed with
+ * the background (DR:1315-1332).
+ *   phase       (B,N) or (B,N,3) radians (phase_channels = 1 | 3)        DR:1181, 1274-1275
+ *   wavelengths (3,) DEVICE floats, shared by the batch                   DR:1160
+ *   out_rgb     (B,3,H,W)
+ * fgs_asm_backward writes gradients of sum(out_rgb*g_rgb) w.r.t. all Gaussian inputs, the
+ * phases and the three wavelengths (dkz/dlambda is taken as 0 where 1/l^2-fx^2-fy^2 <= 0; the
+ * reference's autograd returns NaN/inf when a frequency lands exactly on that boundary).
+ * fgs_asm_backward CONSUMES `saved` (the stored plane spectra are overwritten by their
+ * gradients): one backward per forward.
+ * The first call for a shape builds the hipFFT plans (host work); later calls only enqueue. */
+typedef struct FgsAsmDims {
+    int32_t batch, num_gaussians, width, height;
+    float max_radius;        /* DR:1087 */
+    float background[3];     /* DR:1086 */
+    int32_t num_planes;      /* num_depth_planes, DR:1088 */
+    float depth_near, depth_far; /* depth_range, DR:1089 */
+    float focal_depth;       /* DR:1090 */
+    float pixel_pitch;       /* DR:1091 */
+    int32_t phase_channels;  /* 1: phases (B,N); 3: phases (B,N,3) */
+    int32_t num_cameras;     /* 1 or B */
+    int32_t reserved;
+} FgsAsmDims;
+
+int fgs_asm_workspace_bytes(const FgsAsmDims *dims, size_t *saved_bytes, size_t *scratch_bytes);
+int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *pos, const float *scale,
+                    const float *quat, const float *color, const float *opacity, const float *phase,
+                    const float *wavelengths, float *out_rgb, void *saved, void *scratch, void *stream);
+int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *pos, const float *scale,
+                     const float *quat, const float *color, const float *opacity, const float *phase,
+                     const float *wavelengths, void *saved, void *scratch, const float *g_rgb,
+                     float *g_pos, float *g_scale, float *g_quat, float *g_color, float *g_opacity,
+                     float *g_phase, float *g_wavelengths, void *stream);
+
 /* Per-stage hipEvent timers (profiling aid; SURVEY §5 "tracing").  When enabled, every stage
  * launched by fgs_forward/fgs_backward is bracketed by an event pair on the caller's stream.
  * fgs_stage_timing_read synchronises on the recorded events, ADDS the elapsed milliseconds per

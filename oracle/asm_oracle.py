@@ -1,0 +1,97 @@
+"""CPU ORACLE for the angular-spectrum path (TEST INFRASTRUCTURE ONLY; see fgs_oracle.c header).
+
+Out-of-place restatement of the reference's AngularSpectrumPropagator (DR:929-1065) and
+ASMWaveFieldRenderer.forward (DR:1150-1344) in torch on the CPU; gradients come from autograd of
+this restatement.  The projection/visibility/bbox stages come from the C oracle (canonical
+fp32), the plane assignment, splat, FFT propagation, intensity and composition are re-stated
+here line by line.  PINNED against the reference's own outputs and gradients in
+tests/golden/G8_*.npz and G9_*.npz (tests/test_oracle_vs_golden.py).
+"""
+import numpy as np
+import torch
+
+from . import fgs_oracle as orc
+
+
+def transfer_function(H, W, pixel_pitch, z, wl, dtype=torch.float32):
+    """DR:959-961 + DR:989-999."""
+    fx = torch.fft.fftfreq(W, d=pixel_pitch).to(dtype)
+    fy = torch.fft.fftfreq(H, d=pixel_pitch).to(dtype)
+    FX, FY = torch.meshgrid(fx, fy, indexing="xy")
+    kz_sq = torch.clamp((1.0 / wl) ** 2 - FX ** 2 - FY ** 2, min=0)
+    return torch.exp(1j * 2 * torch.pi * z * torch.sqrt(kz_sq))
+
+
+def propagate(field, z, wl, pixel_pitch=1.0 / 256.0):
+    """DR:1041-1047 for one (H,W) complex field."""
+    H, W = field.shape
+    rdt = torch.float64 if field.dtype == torch.complex128 else torch.float32
+    Htf = transfer_function(H, W, pixel_pitch, torch.as_tensor(z, dtype=rdt), torch.as_tensor(wl, dtype=rdt), rdt)
+    return torch.fft.ifft2(torch.fft.fft2(field) * Htf)
+
+
+def render(pos, scale, quat, color, opacity, phases, wavelengths, cam, bg=(0.0, 0.0, 0.0), max_radius=64.0,
+           num_planes=16, depth_range=(0.1, 2.0), focal_depth=0.5, pixel_pitch=1.0 / 256.0,
+           dtype=torch.float32, grad_out=None):
+    """ASM forward for one image; with grad_out (3,H,W) also returns gradients of sum(img*grad_out)
+    w.r.t. mean2d/conic/opacity/colour/phase/wavelengths chained through the C oracle's projection
+    backward to positions/scales/rotations."""
+    proj = orc.project(pos, scale, quat, cam, max_radius)
+    W, H = cam.width, cam.height
+    vis = proj["visible"].astype(bool)
+    N = len(vis)
+    t = lambda a, g=False: torch.tensor(np.asarray(a), dtype=dtype, requires_grad=g)
+    need = grad_out is not None
+    mean, conic = t(proj["mean2d"], need), t(proj["conic"], need)
+    opa, col, ph, wl = t(opacity, need), t(color, need), t(phases, need), t(wavelengths, need)
+    planes = torch.linspace(depth_range[0], depth_range[1], num_planes)          # DR:1106 (fp32)
+    depth32 = torch.tensor(proj["depth"], dtype=torch.float32)
+    plane_idx = (depth32.unsqueeze(1) - planes.unsqueeze(0)).abs().argmin(dim=1)  # DR:1147-1148
+    fields = [[torch.zeros(H, W, dtype=dtype), torch.zeros(H, W, dtype=dtype)] for _ in range(num_planes * 3)]
+    for i in range(N):  # DR:1238-1283 (order-independent accumulation)
+        if not vis[i]:
+            continue
+        x0, x1, y0, y1 = [int(v) for v in proj["bbox"][i]]
+        if x0 >= x1 or y0 >= y1:
+            continue
+        ly, lx = torch.meshgrid(torch.arange(y0, y1, dtype=dtype), torch.arange(x0, x1, dtype=dtype), indexing="ij")
+        dx, dy = lx - mean[i, 0], ly - mean[i, 1]
+        m = conic[i, 0] * dx * dx + conic[i, 1] * dx * dy + conic[i, 2] * dy * dy
+        amp = torch.exp(-0.5 * m) * opa[i]
+        p = int(plane_idx[i])
+        for c in range(3):
+            phc = ph[i, c] if ph.dim() == 2 else ph[i]
+            pad = (x0, W - x1, y0, H - y1)
+            fields[p * 3 + c][0] = fields[p * 3 + c][0] + torch.nn.functional.pad(amp * col[i, c] * torch.cos(phc), pad)
+            fields[p * 3 + c][1] = fields[p * 3 + c][1] + torch.nn.functional.pad(amp * col[i, c] * torch.sin(phc), pad)
+    total = [torch.zeros(H, W, dtype=torch.complex128 if dtype == torch.float64 else torch.complex64) for _ in range(3)]
+    for p in range(num_planes):  # DR:1291-1313
+        z = torch.tensor(focal_depth, dtype=torch.float32) - planes[p]
+        fc = [torch.complex(fields[p * 3 + c][0], fields[p * 3 + c][1]) for c in range(3)]
+        if max(float(f.detach().abs().max()) for f in fc) < 1e-8:
+            continue
+        for c in range(3):
+            Htf = transfer_function(H, W, pixel_pitch, z.to(dtype), wl[c], dtype)
+            total[c] = total[c] + torch.fft.ifft2(torch.fft.fft2(fc[c]) * Htf)
+    tf = torch.stack(total, dim=-1)                                   # (H,W,3) complex
+    rendered = torch.sqrt(tf.real ** 2 + tf.imag ** 2 + 1e-8)          # DR:1316-1319
+    rendered = torch.clamp(rendered / rendered.max().clamp(min=1.0), 0, 1)
+    total_amp = tf.abs().sum(dim=-1, keepdim=True).clamp(0, 1)         # DR:1327
+    rendered = rendered + torch.tensor(bg, dtype=dtype).view(1, 1, 3) * (1 - total_amp)
+    img = torch.clamp(rendered.permute(2, 0, 1), 0, 1)
+    out = dict(image=img.detach().float().numpy(), plane_idx=plane_idx.numpy(), proj=proj)
+    if need:
+        (img * torch.tensor(grad_out, dtype=dtype)).sum().backward()
+        z = lambda x: np.zeros_like(np.asarray(x), dtype=np.float32) if x.grad is None else x.grad.float().numpy()
+        g_pos, g_scale, g_quat = np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32)
+        import ctypes
+        gm, gc = np.ascontiguousarray(z(mean)), np.ascontiguousarray(z(conic))
+        gd = np.zeros(N, np.float32)
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        pos32, sc32, q32 = f32(pos), f32(scale), f32(quat)
+        orc.lib().fgs_or_project_bwd(ctypes.c_int32(N), P(pos32), P(sc32), P(q32), ctypes.byref(cam),
+                                     P(proj["visible"]), P(gm), P(gc), P(gd), P(g_pos), P(g_scale), P(g_quat))
+        out.update(grad_positions=g_pos, grad_scales=g_scale, grad_rotations=g_quat, grad_colors=z(col),
+                   grad_opacities=z(opa), grad_phases=z(ph), grad_wavelengths=z(wl))
+    return out

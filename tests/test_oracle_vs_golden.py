@@ -186,3 +186,37 @@ def test_phase_backward_matches_fp64_autograd_on_anisotropic_input():
     for k, t in [("mean2d", mean), ("conic", conic), ("opacities", opa), ("colors", col), ("depth", dep),
                  ("phases", ph)]:
         assert rel_to_max(go[k], t.grad.numpy()) <= 1e-5, k
+
+
+# ------------------------------------------------------------------------------------------
+# Angular-spectrum path: pin oracle/asm_oracle.py against the reference (G8, G9)
+# ------------------------------------------------------------------------------------------
+def test_asm_propagator_known_answers_g8():
+    import torch
+    from oracle import asm_oracle
+    g = load_golden("G8_asm_propagator_64")
+    f = torch.from_numpy(g["field"])
+    out0 = asm_oracle.propagate(f, 0.0, 0.05)
+    assert np.abs(out0.numpy() - g["field"]).max() <= 1e-5           # z = 0 is the identity
+    assert np.abs(out0.numpy() - g["out_z0"]).max() <= 1e-5
+    assert rel_to_max(asm_oracle.propagate(f, 0.3, 0.05).numpy(), g["out_z03_l005"]) <= 1e-4
+    assert rel_to_max(asm_oracle.propagate(f, -0.7, 0.0635).numpy(), g["out_zm07_l00635"]) <= 1e-4
+    Htf = asm_oracle.transfer_function(64, 64, float(g["pixel_pitch"]), torch.tensor(0.3), torch.tensor(0.05))
+    assert rel_to_max(Htf.numpy(), g["H_z03_l005"]) <= 1e-4
+
+
+@pytest.mark.parametrize("tag", ["scalar", "rgb"])
+def test_asm_renderer_g9(tag):
+    from oracle import asm_oracle
+    g = load_golden(f"G9_asm256_128_{tag}")
+    cam = oracle_camera(g)
+    r = asm_oracle.render(g["positions"], g["scales"], g["rotations"], g["colors"], g["opacities"], g["phases"],
+                          g["wavelengths"], cam, bg=g["background"], grad_out=g["gI"])
+    assert np.abs(r["image"] - g["image"]).max() <= 1e-5
+    for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
+        assert rel_to_max(r["grad_" + k], g["grad_" + k]) <= 1e-5, k
+    # wavelength gradient: the reference returns NaN for 1/lambda = 20 (a frequency sits exactly on
+    # the evanescent boundary, sqrt'(0) = inf); compare the finite channels only
+    fin = np.isfinite(g["grad_wavelengths"])
+    assert fin.sum() == 2
+    assert rel_to_max(r["grad_wavelengths"][fin], g["grad_wavelengths"][fin]) <= 1e-5
