@@ -34,9 +34,11 @@ FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
 DECODER_GRAD_FLOATS = 673_537  # DirectPatchDecoder gradient bucket (measured)
 
 WORKLOADS = {
-    # name: (N gaussians, resolution, images per GPU)
-    "config3": (32768, 512, 8),
+    # name: (N gaussians, resolution, images per GPU)   -- BASELINE.json configs[1..4]
+    "config3": (32768, 512, 8),    # the metric's configuration (default)
     "config2": (8192, 256, 16),
+    "config4": (8192, 256, 16),    # config-2 shapes + 8 depth zones + scalar phases, phase blending
+    "config5": (8192, 512, 1),     # ASMWaveFieldRenderer, per-channel wavelengths, hipFFT
 }
 
 
@@ -89,13 +91,26 @@ def main():
     N, S, per_gpu = WORKLOADS[args.workload]
     if args.images_per_gpu:
         per_gpu = args.images_per_gpu
-    cfg_id = 3 if args.workload == "config3" else 2
+    cfg_id = int(args.workload[-1])
     # image-wise shard: rank r owns images [r*per_gpu, (r+1)*per_gpu)
     pos, scale, quat, col, opa = synth_batch(per_gpu, N, 1000 * cfg_id + rank * per_gpu, device)
+    phases = None
+    g = torch.Generator().manual_seed(977 + rank)
+    if args.workload == "config4":  # z snapped to 8 zone centres, edge-aware scale factor, phases U(0,1)
+        zone = torch.randint(0, 8, (per_gpu, N), generator=g).float().to(device)
+        pos[..., 2] = -2.0 - 2.0 * (zone + 0.5) / 8.0
+        scale = scale * (0.5 + 0.5 * torch.rand(per_gpu, N, 1, generator=g).to(device))
+        phases = torch.rand(per_gpu, N, generator=g).to(device).requires_grad_(True)
+    if args.workload == "config5":
+        phases = (torch.rand(per_gpu, N, generator=g) * 2 * np.pi).to(device).requires_grad_(True)
     leaves = [t.requires_grad_(True) for t in (pos, scale, quat, col, opa)]
     cam = R.Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
     cam_t = R.pack_cameras(cam, device)
-    cfg = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, False, 0.25)
+    cfg = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, args.workload == "config4", 0.25)
+    asm = None
+    if args.workload == "config5":
+        asm = R.ASMWaveFieldRenderer(S, S).to(device)
+        wl = torch.tensor([0.0635, 0.05, 0.041], device=device, requires_grad=True)
     g = torch.Generator().manual_seed(4242 + rank)
     gI = torch.randn(per_gpu, 3, S, S, generator=g).to(device)
     gD = (torch.randn(per_gpu, S, S, generator=g) * 0.1).to(device)
@@ -104,8 +119,12 @@ def main():
     def step():
         for t in leaves:
             t.grad = None
-        img, dep = R.GaussianRenderer.apply(*leaves, None, cam_t, cfg)
-        torch.autograd.backward([img, dep], [gI, gD])
+        if asm is not None:
+            img = asm(*leaves, cam, phases=phases, wavelengths_rgb=wl)
+            torch.autograd.backward([img], [gI])
+        else:
+            img, dep = R.GaussianRenderer.apply(*leaves, phases, cam_t, cfg)
+            torch.autograd.backward([img, dep], [gI, gD])
         if bucket is not None:
             dist.all_reduce(bucket)  # decoder-gradient bucket of the DP training step
 
@@ -114,7 +133,8 @@ def main():
     torch.cuda.synchronize()
 
     # unit of work: composited Gaussian-pixels of this rank's batch (device-side count)
-    _, _, saved, dims, _ = R.forward_raw(*[t.detach() for t in leaves], None, cam_t, cfg)
+    cfg0 = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, False, 0.25)
+    _, _, saved, dims, _ = R.forward_raw(*[t.detach() for t in leaves], None, cam_t, cfg0)
     pairs_dev = torch.zeros(1, dtype=torch.int64, device=device)
     import ctypes
     B.check(B.load().fgs_count_pairs(ctypes.byref(dims), ctypes.c_void_p(saved.data_ptr()),

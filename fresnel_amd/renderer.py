@@ -65,6 +65,32 @@ class Camera:
                     float(self.near), float(self.far), 0.0, 0.0]
 
 
+def create_camera_from_pose(elevation_rad: float, azimuth_rad: float, render_size: int,
+                            focal_length_mult: float = 0.8, distance: float = 2.0) -> Camera:
+    """Orbit camera looking at the origin (same formula and defaults as the reference's
+    create_camera_from_pose, TGD:684-757): used for multi-pose training / novel-view evaluation.
+    A list of such cameras can be passed to the batched renderer (one per image)."""
+    import numpy as np
+    cam = np.array([distance * np.cos(elevation_rad) * np.sin(azimuth_rad), distance * np.sin(elevation_rad),
+                    distance * np.cos(elevation_rad) * np.cos(azimuth_rad)])
+    fwd = -cam
+    nrm = np.linalg.norm(fwd)
+    fwd = np.array([0.0, 0.0, -1.0]) if nrm < 1e-6 else fwd / nrm
+    right = np.cross(fwd, np.array([0.0, 1.0, 0.0]))
+    rn = np.linalg.norm(right)
+    right = np.array([1.0, 0.0, 0.0]) if rn < 1e-6 else right / rn
+    up = np.cross(right, fwd)
+    R = np.array([right, up, -fwd])
+    t = -R @ cam
+    view = torch.eye(4)
+    view[:3, :3] = torch.from_numpy(R).float()
+    view[:3, 3] = torch.from_numpy(t).float()
+    camera = Camera(fx=render_size * focal_length_mult, fy=render_size * focal_length_mult,
+                    cx=render_size / 2, cy=render_size / 2, width=render_size, height=render_size)
+    camera.set_view(view)
+    return camera
+
+
 def pack_cameras(cameras: Union[Camera, Sequence[Camera]], device) -> torch.Tensor:
     cams = [cameras] if isinstance(cameras, Camera) else list(cameras)
     return torch.tensor([c.packed() for c in cams], dtype=torch.float32, device=device)
