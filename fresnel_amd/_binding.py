@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libfgs_hip.so")
+LIB_PATH = os.environ.get("FGS_LIB", os.path.join(_HERE, "_lib", "libfgs_hip.so"))  # FGS_LIB: A/B builds
 
 FGS_CAMERA_FLOATS = 24
 FGS_TILE = 16
