@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--images-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a 1-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,12 +80,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()  # (rehearsal: several ranks may share one GPU)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)  # nccl IS RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # nccl IS RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     from fresnel_amd import _binding as B
     from fresnel_amd import renderer as R
