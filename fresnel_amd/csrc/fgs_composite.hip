@@ -178,12 +178,12 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const size_t HW = (size_t)W * H;
-    float gr[4], gg[4], gb[4], gd[4], S0[4], A[4], prefix[4];
+    float gr[4], gg[4], gb[4], gd[4], S[4], A[4];  // S: T_fin (gI.bg) + sum over not-yet-visited w q
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
-        gr[s] = gg[s] = gb[s] = gd[s] = S0[s] = 0.0f;
-        A[s] = 0.0f; prefix[s] = 0.0f;
+        gr[s] = gg[s] = gb[s] = gd[s] = S[s] = 0.0f;
+        A[s] = 0.0f;
         if (px < W && py < H) {
             const size_t o = (size_t)py * W + px;
             const float *ps = pix_state + (size_t)c.b * 6 * HW + o;
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             gg[s] = (pg >= 0.0f && pg <= 1.0f) ? gi[HW] : 0.0f;
             gb[s] = (pb >= 0.0f && pb <= 1.0f) ? gi[2 * HW] : 0.0f;
             gd[s] = g_depth[(size_t)c.b * HW + o];
-            S0[s] = Tf * (gr[s] * bg0 + gg[s] * bg1 + gb[s] * bg2) + (gr[s] * Cr + gg[s] * Cg + gb[s] * Cb) +
-                    gd[s] * ps[4 * HW];
+            S[s] = Tf * (gr[s] * bg0 + gg[s] * bg1 + gb[s] * bg2) + (gr[s] * Cr + gg[s] * Cg + gb[s] * Cb) +
+                   gd[s] * ps[4 * HW];
         }
     }
     for (uint32_t base = c.start; base < c.end; base += CH) {
@@ -236,9 +236,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                 const float T = 1.0f - A[s];
                 const float w = alpha * T;
                 const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
-                prefix[s] += w * q;
-                const float S = S0[s] - prefix[s];
-                const float dalpha = T * q - S * __builtin_amdgcn_rcpf(1.0f - alpha);
+                S[s] -= w * q;
+                const float dalpha = T * q - S[s] * __builtin_amdgcn_rcpf(1.0f - alpha);
                 const float draw = pass ? dalpha : 0.0f;
                 A[s] += w;
                 const float dG = draw * G;
