@@ -17,6 +17,7 @@ EXPORTED_SYMBOLS = [
     "fgs_workspace_bytes", "fgs_saved_layout", "fgs_forward", "fgs_backward", "fgs_count_pairs",
     "fgs_last_error", "fgs_version", "fgs_stage_timing_enable", "fgs_stage_timing_read",
     "fgs_asm_workspace_bytes", "fgs_asm_forward", "fgs_asm_backward",
+    "fgs_wave_workspace_bytes", "fgs_wave_forward", "fgs_wave_backward",
 ]
 
 STAGES = ["project", "depth_sort", "dup_emit", "tile_sort", "tile_ranges", "composite_fwd",
@@ -49,6 +50,13 @@ class FgsAsmDims(ctypes.Structure):
                 ("depth_far", ctypes.c_float), ("focal_depth", ctypes.c_float),
                 ("pixel_pitch", ctypes.c_float), ("phase_channels", ctypes.c_int32),
                 ("num_cameras", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class FgsWaveDims(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("num_gaussians", ctypes.c_int32),
+                ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("max_radius", ctypes.c_float), ("background", ctypes.c_float * 3),
+                ("phase_channels", ctypes.c_int32), ("num_cameras", ctypes.c_int32)]
 
 
 class FgsError(RuntimeError):
@@ -86,7 +94,11 @@ def load():
     lib.fgs_asm_workspace_bytes.argtypes = [cp(FgsAsmDims), cp(ctypes.c_size_t), cp(ctypes.c_size_t)]
     lib.fgs_asm_forward.argtypes = [cp(FgsAsmDims)] + [vp] * 12
     lib.fgs_asm_backward.argtypes = [cp(FgsAsmDims)] + [vp] * 19
-    for fn in (lib.fgs_asm_workspace_bytes, lib.fgs_asm_forward, lib.fgs_asm_backward):
+    lib.fgs_wave_workspace_bytes.argtypes = [cp(FgsWaveDims), cp(ctypes.c_size_t), cp(ctypes.c_size_t)]
+    lib.fgs_wave_forward.argtypes = [cp(FgsWaveDims)] + [vp] * 12
+    lib.fgs_wave_backward.argtypes = [cp(FgsWaveDims)] + [vp] * 18
+    for fn in (lib.fgs_asm_workspace_bytes, lib.fgs_asm_forward, lib.fgs_asm_backward,
+               lib.fgs_wave_workspace_bytes, lib.fgs_wave_forward, lib.fgs_wave_backward):
         fn.restype = ctypes.c_int
     for fn in (lib.fgs_workspace_bytes, lib.fgs_saved_layout, lib.fgs_forward, lib.fgs_backward,
                lib.fgs_count_pairs):

@@ -164,12 +164,15 @@ __global__ __launch_bounds__(256) void k_asm_transfer(int W, int H, int P, float
 // One wave per (image, plane, tile); lane = one pixel of each of the four 8x8 sub-tiles.
 // BWD = false: accumulate field += a * c * (cos phi, sin phi) with a = exp(-m/2) * opacity (DR:1263-1283).
 // BWD = true : read the field gradient and reduce the twelve per-Gaussian sums into a gradient row.
-template <bool BWD>
+// WAVE = true (WaveFieldRenderer, DR:832-891): a single layer, and additionally the amplitude-weighted
+// depth sums (sum a*depth, sum a) in `dw`; gradient rows are 16 floats wide (slot 12 = dL/ddepth).
+template <bool BWD, bool WAVE>
 __global__ __launch_bounds__(64) void k_asm_splat(
     uint32_t tiles, uint32_t tiles_x, uint32_t P, uint32_t W, uint32_t H, uint32_t dcap, int phase_channels,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
-    const uint32_t *__restrict__ dup_off, float2 *__restrict__ field, float *__restrict__ grad_rows) {
+    const uint32_t *__restrict__ dup_off, float2 *__restrict__ field, float *__restrict__ grad_rows,
+    float2 *__restrict__ dw) {
     __shared__ float4 sh0[ACH], sh1[ACH], sh2[ACH], sh3[ACH];
     __shared__ uint32_t shm[ACH], she[ACH];
     const uint32_t key = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (b*P + p)*T + t
@@ -181,9 +184,15 @@ __global__ __launch_bounds__(64) void k_asm_splat(
     const size_t HW = (size_t)W * H;
     float2 *fbase = field + (size_t)bp * 3 * HW;  // [b][p][c][y][x]
     float re[4][3], im[4][3];  // FWD: accumulators.  BWD: field gradient at this lane's pixels
+    float wd[4], ww[4];        // WAVE: sum a*depth, sum a   (BWD: their gradients)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const uint32_t px = X0 + 8u * (s & 1) + lx, py = Y0 + 8u * (s >> 1) + ly;
+        wd[s] = 0.0f; ww[s] = 0.0f;
+        if (WAVE && BWD && px < W && py < H) {
+            const float2 g = dw[(size_t)bp * HW + (size_t)py * W + px];
+            wd[s] = g.x; ww[s] = g.y;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             re[s][c] = 0.0f; im[s][c] = 0.0f;
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(64) void k_asm_splat(
             sh1[lane] = make_float4(q1.x, q1.y, __uint_as_float(bx0 | ((bx1 - bx0) << 16)),
                                     __uint_as_float(by0 | ((by1 - by0) << 16)));   // cd, op, bbx', bby'
             sh2[lane] = make_float4(cc[0], cc[1], cc[2], cs[0]);
-            sh3[lane] = make_float4(cs[1], cs[2], 0.0f, 0.0f);
+            sh3[lane] = make_float4(cs[1], cs[2], q2.y, 0.0f);  // .z = depth (WAVE)
         }
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
@@ -228,8 +237,9 @@ __global__ __launch_bounds__(64) void k_asm_splat(
             const uint32_t bbx = __float_as_uint(q1.z), bby = __float_as_uint(q1.w);
             const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;
             const float cc[3] = {q2.x, q2.y, q2.z}, cs[3] = {q2.w, q3.x, q3.y};
-            float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0;
+            float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_dep = 0;
             float v_cc[3] = {0, 0, 0}, v_cs[3] = {0, 0, 0};
+            const float dz = q3.z;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!((msk >> s) & 1u)) continue;
@@ -242,8 +252,10 @@ __global__ __launch_bounds__(64) void k_asm_splat(
                 if (!BWD) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { re[s][c] += a * cc[c]; im[s][c] += a * cs[c]; }
+                    if (WAVE) { wd[s] += a * dz; ww[s] += a; }  // DR:890-891
                 } else {
                     float da = 0.0f;
+                    if (WAVE) { da = wd[s] * dz + ww[s]; v_dep += a * wd[s]; }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         da += cc[c] * re[s][c] + cs[c] * im[s][c];
@@ -259,13 +271,18 @@ __global__ __launch_bounds__(64) void k_asm_splat(
             if (BWD) {
                 wave_sum12_lane63(v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_cc[0], v_cc[1], v_cc[2], v_cs[0], v_cs[1],
                                   v_cs[2]);
+                if (WAVE) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v_dep += __shfl_xor(v_dep, o, 64);
+                }
                 if (lane == 63) {
                     const uint32_t e = she[j];
                     if (e < dcap) {
-                        float4 *dst = reinterpret_cast<float4 *>(grad_rows + (size_t)e * FGS_GROW_FLOATS);
+                        float4 *dst = reinterpret_cast<float4 *>(grad_rows + (size_t)e * (WAVE ? 16 : FGS_GROW_FLOATS));
                         dst[0] = make_float4(v_u, v_v, v_ca, v_cbc);
                         dst[1] = make_float4(v_cd, v_op, v_cc[0], v_cc[1]);
                         dst[2] = make_float4(v_cc[2], v_cs[0], v_cs[1], v_cs[2]);
+                        if (WAVE) dst[3] = make_float4(v_dep, 0.0f, 0.0f, 0.0f);
                     }
                 }
             }
@@ -280,6 +297,7 @@ __global__ __launch_bounds__(64) void k_asm_splat(
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     fbase[(size_t)c * HW + (size_t)py * W + px] = make_float2(re[s][c], im[s][c]);
+                if (WAVE) dw[(size_t)bp * HW + (size_t)py * W + px] = make_float2(wd[s], ww[s]);
             }
         }
     }
@@ -475,6 +493,168 @@ __global__ __launch_bounds__(256) void k_asm_accumulate_bwd(int W, int H, int B,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// WaveFieldRenderer (DR:689-926): order-independent complex accumulation without
+// depth planes or propagation; intensity -> sqrt -> per-image max normalisation -> background
+// where the total amplitude is low; depth map = sum(a depth) / (sum a + 1e-8).
+// ---------------------------------------------------------------------------------------------
+struct WavePix {
+    float r[3], n[3], v[3], tasq, ta, M;
+};
+
+__device__ __forceinline__ void wave_pixel_forward(const float2 u[3], float maxval, const float bg[3], WavePix &o) {
+    o.M = maxval < 1.0f ? 1.0f : maxval;
+    float isum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float I = u[c].x * u[c].x + u[c].y * u[c].y;
+        isum += I;
+        o.r[c] = sqrtf(I + 1e-8f);                           // DR:898
+        const float q = o.r[c] / o.M;                        // DR:902-905
+        o.n[c] = q < 0.0f ? 0.0f : (q > 1.0f ? 1.0f : q);
+    }
+    o.tasq = sqrtf(isum + 1e-8f);                            // DR:908
+    o.ta = o.tasq < 0.0f ? 0.0f : (o.tasq > 1.0f ? 1.0f : o.tasq);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o.v[c] = o.n[c] + bg[c] * (1.0f - o.ta);
+}
+
+__global__ __launch_bounds__(256) void k_wave_max(size_t HW, const float2 *__restrict__ field, float *__restrict__ scal) {
+    const int b = blockIdx.y;
+    float mx = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < 3 * HW; i += (size_t)gridDim.x * 256) {
+        const float2 u = field[(size_t)b * 3 * HW + i];
+        mx = fmaxf(mx, sqrtf(u.x * u.x + u.y * u.y + 1e-8f));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63u) == 0) atomicMax(reinterpret_cast<unsigned int *>(scal + b), __float_as_uint(mx));
+}
+
+__global__ __launch_bounds__(256) void k_wave_output(size_t HW, float bg0, float bg1, float bg2,
+                                                     const float2 *__restrict__ field, const float2 *__restrict__ dw,
+                                                     const float *__restrict__ scal, float *__restrict__ out,
+                                                     float *__restrict__ out_depth) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float2 u[3] = {field[((size_t)b * 3 + 0) * HW + i], field[((size_t)b * 3 + 1) * HW + i],
+                         field[((size_t)b * 3 + 2) * HW + i]};
+    const float bg[3] = {bg0, bg1, bg2};
+    WavePix o;
+    wave_pixel_forward(u, scal[b], bg, o);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = o.v[c];
+        out[((size_t)b * 3 + c) * HW + i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    }
+    const float2 d = dw[(size_t)b * HW + i];
+    out_depth[(size_t)b * HW + i] = d.x / (d.y + 1e-8f);      // DR:924
+}
+
+__global__ __launch_bounds__(256) void k_wave_output_bwd1(size_t HW, float bg0, float bg1, float bg2,
+                                                          const float2 *__restrict__ field, float *__restrict__ scal,
+                                                          const float *__restrict__ g_out) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float gM = 0.0f, cnt = 0.0f;
+    if (i < HW) {
+        const float2 u[3] = {field[((size_t)b * 3 + 0) * HW + i], field[((size_t)b * 3 + 1) * HW + i],
+                             field[((size_t)b * 3 + 2) * HW + i]};
+        const float bg[3] = {bg0, bg1, bg2};
+        const float maxval = scal[b];
+        WavePix o;
+        wave_pixel_forward(u, maxval, bg, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float gv = (o.v[c] >= 0.0f && o.v[c] <= 1.0f) ? g_out[((size_t)b * 3 + c) * HW + i] : 0.0f;
+            const float q = o.r[c] / o.M;
+            const float gq = (q >= 0.0f && q <= 1.0f) ? gv : 0.0f;
+            gM -= gq * o.r[c] / (o.M * o.M);
+            if (o.r[c] == maxval) cnt += 1.0f;
+        }
+    }
+#pragma unroll
+    for (int of = 32; of > 0; of >>= 1) { gM += __shfl_xor(gM, of, 64); cnt += __shfl_xor(cnt, of, 64); }
+    if ((threadIdx.x & 63u) == 0) {
+        if (gM != 0.0f) atomicAdd(scal + gridDim.y + b, gM);
+        if (cnt != 0.0f) atomicAdd(scal + 2 * gridDim.y + b, cnt);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wave_output_bwd2(size_t HW, float bg0, float bg1, float bg2,
+                                                          const float2 *__restrict__ field,
+                                                          const float2 *__restrict__ dw, const float *__restrict__ scal,
+                                                          const float *__restrict__ g_out,
+                                                          const float *__restrict__ g_depth, float2 *__restrict__ gfield,
+                                                          float2 *__restrict__ gdw) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const float2 u[3] = {field[((size_t)b * 3 + 0) * HW + i], field[((size_t)b * 3 + 1) * HW + i],
+                         field[((size_t)b * 3 + 2) * HW + i]};
+    const float bg[3] = {bg0, bg1, bg2};
+    const float maxval = scal[b];
+    const float cntm = scal[2 * gridDim.y + b];
+    const float gMshare = (maxval >= 1.0f && cntm > 0.0f) ? scal[gridDim.y + b] / cntm : 0.0f;
+    WavePix o;
+    wave_pixel_forward(u, maxval, bg, o);
+    float gv[3], gta = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gv[c] = (o.v[c] >= 0.0f && o.v[c] <= 1.0f) ? g_out[((size_t)b * 3 + c) * HW + i] : 0.0f;
+        gta -= gv[c] * bg[c];
+    }
+    // ta = clamp(sqrt(sum_c I_c + 1e-8), 0, 1): d ta / d I_c = 1 / (2 tasq) inside the clamp
+    const float gIsum = (o.tasq >= 0.0f && o.tasq <= 1.0f) ? gta / (2.0f * o.tasq) : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float q = o.r[c] / o.M;
+        float gr = ((q >= 0.0f && q <= 1.0f) ? gv[c] : 0.0f) / o.M;
+        if (o.r[c] == maxval) gr += gMshare;
+        const float gI = gr / (2.0f * o.r[c]) + gIsum;
+        gfield[((size_t)b * 3 + c) * HW + i] = make_float2(2.0f * gI * u[c].x, 2.0f * gI * u[c].y);
+    }
+    // depth_map = Ad / (Wt + 1e-8)
+    const float2 d = dw[(size_t)b * HW + i];
+    const float gdm = g_depth[(size_t)b * HW + i];
+    const float den = d.y + 1e-8f;
+    gdw[(size_t)b * HW + i] = make_float2(gdm / den, -gdm * d.x / (den * den));
+}
+
+struct WavePlan {
+    FgsWaveDims w;
+    FgsPlan base;
+    size_t HW, v_field, v_dw, v_scal, v_total_bytes, c_gfield, c_gdw, c_rows, c_total_bytes;
+};
+
+int make_wave_plan(const FgsWaveDims *w, WavePlan *p) {
+    if (!w) { fgs_set_error("null dims"); return FGS_EINVAL; }
+    if (w->phase_channels != 1 && w->phase_channels != 3) { fgs_set_error("invalid phase_channels"); return FGS_EINVAL; }
+    FgsDims d{};
+    d.batch = w->batch; d.num_gaussians = w->num_gaussians; d.width = w->width; d.height = w->height;
+    d.max_radius = w->max_radius;
+    for (int i = 0; i < 3; ++i) d.background[i] = w->background[i];
+    d.num_cameras = w->num_cameras;
+    p->w = *w;
+    const int rc = fgs_make_plan(&d, &p->base, 1);
+    if (rc) return rc;
+    const size_t B = w->batch, HW = (size_t)w->width * w->height;
+    p->HW = HW;
+    size_t o = p->base.L.total_bytes;
+    p->v_field = o; o = align256(o + B * 3 * HW * 8);
+    p->v_dw = o; o = align256(o + B * HW * 8);
+    p->v_scal = o; o = align256(o + B * 4 * 4);
+    p->v_total_bytes = o;
+    o = p->base.s_total;
+    p->c_gfield = o; o = align256(o + B * 3 * HW * 8);
+    p->c_gdw = o; o = align256(o + B * HW * 8);
+    p->c_rows = o; o = align256(o + p->base.L.dup_capacity * 16 * 4);
+    p->c_total_bytes = o;
+    return FGS_OK;
+}
+
 int check_ptrs(const void *const *ptrs, int n, const char *who) {
     for (int i = 0; i < n; ++i)
         if (!ptrs[i]) { fgs_set_error("%s: null pointer argument #%d", who, i); return FGS_EINVAL; }
@@ -518,14 +698,14 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     float2 *total = reinterpret_cast<float2 *>(sv + p.v_total);
     float *scal = reinterpret_cast<float *>(sv + p.v_scal);
     const uint32_t grid = (uint32_t)B * P * p.base.tiles;
-    hipLaunchKernelGGL(k_asm_splat<false>, dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+    hipLaunchKernelGGL((k_asm_splat<false, false>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
                        (uint32_t)p.base.L.dup_capacity, a.phase_channels,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
                        reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr);
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, (float2 *)nullptr);
     FGS_LAUNCH_CHECK("k_asm_splat");
     if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
@@ -598,19 +778,119 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
     const uint32_t grid = (uint32_t)B * P * p.base.tiles;
     float *rows = reinterpret_cast<float *>(sc + p.base.s_grows);
-    hipLaunchKernelGGL(k_asm_splat<true>, dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+    hipLaunchKernelGGL((k_asm_splat<true, false>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
                        (uint32_t)p.base.L.dup_capacity, a.phase_channels,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
                        reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows);
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows, (float2 *)nullptr);
     FGS_LAUNCH_CHECK("k_asm_splat_bwd");
     fgs_stage_end(ST_COMPOSITE_BWD, st);
     fgs_stage_begin(ST_PROJECT_BWD, st);
     if ((rc = fgs_launch_asm_project_bwd(p.base, cameras, pos, scale, quat, color, phase, a.phase_channels, sv, rows,
                                          g_pos, g_scale, g_quat, g_color, g_opacity, g_phase, st)))
+        return rc;
+    fgs_stage_end(ST_PROJECT_BWD, st);
+    return FGS_OK;
+}
+
+int fgs_wave_workspace_bytes(const FgsWaveDims *dims, size_t *saved_bytes, size_t *scratch_bytes) {
+    WavePlan p;
+    const int rc = make_wave_plan(dims, &p);
+    if (rc) return rc;
+    if (saved_bytes) *saved_bytes = p.v_total_bytes;
+    if (scratch_bytes) *scratch_bytes = p.c_total_bytes;
+    return FGS_OK;
+}
+
+int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float *pos, const float *scale,
+                     const float *quat, const float *color, const float *opacity, const float *phase,
+                     float *out_rgb, float *out_depth, void *saved, void *scratch, void *stream) {
+    WavePlan p;
+    int rc = make_wave_plan(dims, &p);
+    if (rc) return rc;
+    const void *ptrs[] = {cameras, pos, scale, quat, color, opacity, phase, out_rgb, out_depth, saved, scratch};
+    if ((rc = check_ptrs(ptrs, 11, "fgs_wave_forward"))) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char *sv = reinterpret_cast<char *>(saved), *sc = reinterpret_cast<char *>(scratch);
+    const int B = p.w.batch, W = p.w.width, H = p.w.height;
+    const size_t HW = p.HW;
+    fgs_stage_begin(ST_PROJECT, st);
+    if ((rc = fgs_launch_project(p.base, cameras, pos, scale, quat, color, opacity, sv, st))) return rc;
+    fgs_stage_end(ST_PROJECT, st);
+    if ((rc = fgs_launch_binning(p.base, sv, sc, st))) return rc;
+    fgs_stage_begin(ST_ASM, st);
+    float2 *field = reinterpret_cast<float2 *>(sv + p.v_field);
+    float2 *dw = reinterpret_cast<float2 *>(sv + p.v_dw);
+    float *scal = reinterpret_cast<float *>(sv + p.v_scal);
+    const uint32_t grid = (uint32_t)B * p.base.tiles;
+    hipLaunchKernelGGL((k_asm_splat<false, true>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+                       (uint32_t)p.base.L.tiles_x, 1u, (uint32_t)W, (uint32_t)H, (uint32_t)p.base.L.dup_capacity,
+                       p.w.phase_channels, reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
+                       reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, dw);
+    FGS_LAUNCH_CHECK("k_wave_splat");
+    hipError_t e = hipMemsetAsync(scal, 0, (size_t)B * 4 * sizeof(float), st);
+    if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
+    unsigned gx = (unsigned)((3 * HW + 255) / 256);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(k_wave_max, dim3(gx, B), dim3(256), 0, st, HW, field, scal);
+    FGS_LAUNCH_CHECK("k_wave_max");
+    hipLaunchKernelGGL(k_wave_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, p.w.background[0],
+                       p.w.background[1], p.w.background[2], field, dw, scal, out_rgb, out_depth);
+    FGS_LAUNCH_CHECK("k_wave_output");
+    fgs_stage_end(ST_ASM, st);
+    return FGS_OK;
+}
+
+int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float *pos, const float *scale,
+                      const float *quat, const float *color, const float *opacity, const float *phase,
+                      void *saved, void *scratch, const float *g_rgb, const float *g_depth, float *g_pos,
+                      float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
+                      void *stream) {
+    WavePlan p;
+    int rc = make_wave_plan(dims, &p);
+    if (rc) return rc;
+    const void *ptrs[] = {cameras, pos, scale, quat, color, opacity, phase, saved, scratch, g_rgb, g_depth,
+                          g_pos, g_scale, g_quat, g_color, g_opacity, g_phase};
+    if ((rc = check_ptrs(ptrs, 17, "fgs_wave_backward"))) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char *sv = reinterpret_cast<char *>(saved), *sc = reinterpret_cast<char *>(scratch);
+    const int B = p.w.batch, W = p.w.width, H = p.w.height;
+    const size_t HW = p.HW;
+    float2 *field = reinterpret_cast<float2 *>(sv + p.v_field);
+    float2 *dw = reinterpret_cast<float2 *>(sv + p.v_dw);
+    float *scal = reinterpret_cast<float *>(sv + p.v_scal);
+    float2 *gfield = reinterpret_cast<float2 *>(sc + p.c_gfield);
+    float2 *gdw = reinterpret_cast<float2 *>(sc + p.c_gdw);
+    float *rows = reinterpret_cast<float *>(sc + p.c_rows);
+    fgs_stage_begin(ST_COMPOSITE_BWD, st);
+    hipError_t e = hipMemsetAsync(scal + B, 0, 2 * (size_t)B * sizeof(float), st);
+    if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
+    const dim3 gpix((unsigned)((HW + 255) / 256), B);
+    hipLaunchKernelGGL(k_wave_output_bwd1, gpix, dim3(256), 0, st, HW, p.w.background[0], p.w.background[1],
+                       p.w.background[2], field, scal, g_rgb);
+    FGS_LAUNCH_CHECK("k_wave_output_bwd1");
+    hipLaunchKernelGGL(k_wave_output_bwd2, gpix, dim3(256), 0, st, HW, p.w.background[0], p.w.background[1],
+                       p.w.background[2], field, dw, scal, g_rgb, g_depth, gfield, gdw);
+    FGS_LAUNCH_CHECK("k_wave_output_bwd2");
+    const uint32_t grid = (uint32_t)B * p.base.tiles;
+    hipLaunchKernelGGL((k_asm_splat<true, true>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+                       (uint32_t)p.base.L.tiles_x, 1u, (uint32_t)W, (uint32_t)H, (uint32_t)p.base.L.dup_capacity,
+                       p.w.phase_channels, reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
+                       reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), gfield, rows, gdw);
+    FGS_LAUNCH_CHECK("k_wave_splat_bwd");
+    fgs_stage_end(ST_COMPOSITE_BWD, st);
+    fgs_stage_begin(ST_PROJECT_BWD, st);
+    if ((rc = fgs_launch_asm_project_bwd(p.base, cameras, pos, scale, quat, color, phase, p.w.phase_channels, sv, rows,
+                                         g_pos, g_scale, g_quat, g_color, g_opacity, g_phase, st, true)))
         return rc;
     fgs_stage_end(ST_PROJECT_BWD, st);
     return FGS_OK;

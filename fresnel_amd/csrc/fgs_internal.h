@@ -62,7 +62,8 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
 int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                                const float *quat, const float *color, const float *phase, int phase_channels,
                                const char *saved, const float *grad_rows, float *g_pos, float *g_scale,
-                               float *g_quat, float *g_color, float *g_opacity, float *g_phase, hipStream_t st);
+                               float *g_quat, float *g_color, float *g_opacity, float *g_phase, hipStream_t st,
+                               bool wave_rows = false);
 
 // Stable LSD radix sort of (key,val) uint32 pairs over `num_segs` independent segments.
 // Segment s covers elements [s*seg_stride, s*seg_stride + len) with len = seg_len (host) or

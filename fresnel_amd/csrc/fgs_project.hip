@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void k_project(
 //   (dL/du, dL/dv, dL/dconic[3], dL/dopacity, dL/d(c cos phi)[3], dL/d(c sin phi)[3]);
 // colour and phase gradients are formed here and no gradient flows through depth (the depth
 // only selects the plane, DR:1147-1148).
-template <bool ASM>
+// MODE 2 (WaveFieldRenderer): ASM rows widened to 16 floats, slot 12 = dL/ddepth (amplitude-weighted depth map)
+template <int MODE>
 __global__ __launch_bounds__(256) void k_project_bwd(
     int32_t total, int32_t N, int32_t num_cameras, uint32_t dcap, const float *__restrict__ cams,
     const float *__restrict__ pos, const float *__restrict__ scale, const float *__restrict__ quat,
@@ -185,19 +186,22 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const int32_t b = live ? ri / N : 0;
     const int32_t idx = live ? b * N + (int32_t)order[ri] : 0;
     float gp[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0};
-    float acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr bool ASM = MODE != 0;
+    constexpr int ROWF = MODE == 2 ? 16 : FGS_GROW_FLOATS;
+    float acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (live) {
         const uint32_t cnt = tile_count[idx], off = dup_off[idx];
         for (uint32_t k = sub; k < cnt && off + k < dcap; k += 4) {
-            const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * FGS_GROW_FLOATS);
+            const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * ROWF);
             const float4 a = r[0], bq = r[1], cq = r[2];
+            if (MODE == 2) acc[12] += r[3].x;
             acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
             acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
             acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z; acc[11] += cq.w;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
+    for (int k = 0; k < 13; ++k) {
         acc[k] += __shfl_xor(acc[k], 1, 64);
         acc[k] += __shfl_xor(acc[k], 2, 64);
     }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
         if (g_phase) g_phase[idx] = s2.z;
         g_color[3 * idx] = s1.z; g_color[3 * idx + 1] = s1.w; g_color[3 * idx + 2] = s2.x;
     } else {
-        g_depth = 0.0f;
+        g_depth = MODE == 2 ? acc[12] : 0.0f;
         const float dcc[3] = {s1.z, s1.w, s2.x}, dcs[3] = {s2.y, s2.z, acc[11]};
         float gph = 0.0f;
 #pragma unroll
@@ -355,7 +359,7 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
                            hipStream_t st) {
     const int32_t total = p.d.batch * p.d.num_gaussians;
     const int grid = (int)(((size_t)total * 4 + 255) / 256);
-    hipLaunchKernelGGL(k_project_bwd<false>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
+    hipLaunchKernelGGL(k_project_bwd<0>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
                        p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat,
                        reinterpret_cast<const uint32_t *>(saved + p.L.depth_key),
                        reinterpret_cast<const uint32_t *>(saved + p.L.order),
@@ -369,10 +373,22 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
 int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                                const float *quat, const float *color, const float *phase, int phase_channels,
                                const char *saved, const float *grad_rows, float *g_pos, float *g_scale,
-                               float *g_quat, float *g_color, float *g_opacity, float *g_phase, hipStream_t st) {
+                               float *g_quat, float *g_color, float *g_opacity, float *g_phase, hipStream_t st,
+                               bool wave_rows) {
     const int32_t total = p.d.batch * p.d.num_gaussians;
     const int grid = (int)(((size_t)total * 4 + 255) / 256);
-    hipLaunchKernelGGL(k_project_bwd<true>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
+    if (wave_rows) {
+        hipLaunchKernelGGL(k_project_bwd<2>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
+                           p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat,
+                           reinterpret_cast<const uint32_t *>(saved + p.L.depth_key),
+                           reinterpret_cast<const uint32_t *>(saved + p.L.order),
+                           reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
+                           reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
+                           g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels);
+        FGS_LAUNCH_CHECK("k_wave_project_bwd");
+        return FGS_OK;
+    }
+    hipLaunchKernelGGL(k_project_bwd<1>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
                        p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat,
                        reinterpret_cast<const uint32_t *>(saved + p.L.depth_key),
                        reinterpret_cast<const uint32_t *>(saved + p.L.order),

@@ -143,6 +143,30 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
                      float *g_pos, float *g_scale, float *g_quat, float *g_color, float *g_opacity,
                      float *g_phase, float *g_wavelengths, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * WaveFieldRenderer (DR:689-926; selected by --use_wave_rendering / --use_qsr, TGD:1891-1897):
+ * order-independent complex amplitude accumulation U = sum a c exp(i phi) (DR:832-887), intensity
+ * -> sqrt -> per-image max normalisation -> background where the total amplitude is low
+ * (DR:893-914); depth map = sum(a depth) / (sum a + 1e-8) (DR:889-891, 924).
+ *   phase (B,N) or (B,N,3) radians; out_rgb (B,3,H,W); out_depth (B,H,W). */
+typedef struct FgsWaveDims {
+    int32_t batch, num_gaussians, width, height;
+    float max_radius;
+    float background[3];
+    int32_t phase_channels;  /* 1 | 3 */
+    int32_t num_cameras;     /* 1 or B */
+} FgsWaveDims;
+
+int fgs_wave_workspace_bytes(const FgsWaveDims *dims, size_t *saved_bytes, size_t *scratch_bytes);
+int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float *pos, const float *scale,
+                     const float *quat, const float *color, const float *opacity, const float *phase,
+                     float *out_rgb, float *out_depth, void *saved, void *scratch, void *stream);
+int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float *pos, const float *scale,
+                      const float *quat, const float *color, const float *opacity, const float *phase,
+                      void *saved, void *scratch, const float *g_rgb, const float *g_depth, float *g_pos,
+                      float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
+                      void *stream);
+
 /* Per-stage hipEvent timers (profiling aid; SURVEY §5 "tracing").  When enabled, every stage
  * launched by fgs_forward/fgs_backward is bracketed by an event pair on the caller's stream.
  * fgs_stage_timing_read synchronises on the recorded events, ADDS the elapsed milliseconds per

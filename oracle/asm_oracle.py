@@ -95,3 +95,63 @@ def render(pos, scale, quat, color, opacity, phases, wavelengths, cam, bg=(0.0, 
         out.update(grad_positions=g_pos, grad_scales=g_scale, grad_rotations=g_quat, grad_colors=z(col),
                    grad_opacities=z(opa), grad_phases=z(ph), grad_wavelengths=z(wl))
     return out
+
+
+def render_wave(pos, scale, quat, color, opacity, phases, cam, bg=(0.0, 0.0, 0.0), max_radius=64.0,
+                dtype=torch.float32, grad_out=None, grad_depth=None):
+    """WaveFieldRenderer (DR:747-926) for one image: order-independent complex accumulation, intensity,
+    max normalisation, background, amplitude-weighted depth map.  Gradients by autograd of this
+    restatement, chained through the C oracle's projection backward."""
+    proj = orc.project(pos, scale, quat, cam, max_radius)
+    W, H = cam.width, cam.height
+    vis = proj["visible"].astype(bool)
+    N = len(vis)
+    need = grad_out is not None
+    t = lambda a, g=False: torch.tensor(np.asarray(a), dtype=dtype, requires_grad=g)
+    mean, conic, dep = t(proj["mean2d"], need), t(proj["conic"], need), t(proj["depth"], need)
+    opa, col, ph = t(opacity, need), t(color, need), t(phases, need)
+    re = [torch.zeros(H, W, dtype=dtype) for _ in range(3)]
+    im = [torch.zeros(H, W, dtype=dtype) for _ in range(3)]
+    ad, wt = torch.zeros(H, W, dtype=dtype), torch.zeros(H, W, dtype=dtype)
+    for i in range(N):
+        if not vis[i]:
+            continue
+        x0, x1, y0, y1 = [int(v) for v in proj["bbox"][i]]
+        if x0 >= x1 or y0 >= y1:
+            continue
+        ly, lx = torch.meshgrid(torch.arange(y0, y1, dtype=dtype), torch.arange(x0, x1, dtype=dtype), indexing="ij")
+        dx, dy = lx - mean[i, 0], ly - mean[i, 1]
+        m = conic[i, 0] * dx * dx + conic[i, 1] * dx * dy + conic[i, 2] * dy * dy
+        amp = torch.exp(-0.5 * m) * opa[i]
+        pad = (x0, W - x1, y0, H - y1)
+        for c in range(3):
+            phc = ph[i, c] if ph.dim() == 2 else ph[i]
+            re[c] = re[c] + torch.nn.functional.pad(amp * col[i, c] * torch.cos(phc), pad)
+            im[c] = im[c] + torch.nn.functional.pad(amp * col[i, c] * torch.sin(phc), pad)
+        ad = ad + torch.nn.functional.pad(amp * dep[i], pad)
+        wt = wt + torch.nn.functional.pad(amp, pad)
+    wr, wi = torch.stack(re, -1), torch.stack(im, -1)
+    rendered = torch.sqrt(wr ** 2 + wi ** 2 + 1e-8)
+    rendered = torch.clamp(rendered / rendered.max().clamp(min=1.0), 0, 1)
+    ta = torch.sqrt((wr ** 2 + wi ** 2).sum(dim=-1, keepdim=True) + 1e-8).clamp(0, 1)
+    rendered = rendered + torch.tensor(bg, dtype=dtype).view(1, 1, 3) * (1 - ta)
+    img = torch.clamp(rendered.permute(2, 0, 1), 0, 1)
+    dmap = ad / (wt + 1e-8)
+    out = dict(image=img.detach().float().numpy(), depth=dmap.detach().float().numpy(), proj=proj)
+    if need:
+        loss = (img * torch.tensor(grad_out, dtype=dtype)).sum()
+        if grad_depth is not None:
+            loss = loss + (dmap * torch.tensor(grad_depth, dtype=dtype)).sum()
+        loss.backward()
+        z = lambda x: np.zeros_like(np.asarray(x.detach()), dtype=np.float32) if x.grad is None else x.grad.float().numpy()
+        import ctypes
+        g_pos, g_scale, g_quat = np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32)
+        gm, gc, gd = np.ascontiguousarray(z(mean)), np.ascontiguousarray(z(conic)), np.ascontiguousarray(z(dep))
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        pos32, sc32, q32 = f32(pos), f32(scale), f32(quat)
+        orc.lib().fgs_or_project_bwd(ctypes.c_int32(N), P(pos32), P(sc32), P(q32), ctypes.byref(cam),
+                                     P(proj["visible"]), P(gm), P(gc), P(gd), P(g_pos), P(g_scale), P(g_quat))
+        out.update(grad_positions=g_pos, grad_scales=g_scale, grad_rotations=g_quat, grad_colors=z(col),
+                   grad_opacities=z(opa), grad_phases=z(ph))
+    return out

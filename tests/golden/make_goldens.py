@@ -17,6 +17,7 @@ Cases:
   G7 off-axis view matrix (orbit camera el=20deg az=135deg)
   G8 AngularSpectrumPropagator 64x64 known answers
   G9 ASMWaveFieldRenderer N=256 @128x128, scalar and (N,3) phases, grads incl. wavelengths
+  G10 WaveFieldRenderer N=256 @128x128, scalar and (N,3) phases, image + depth + grads
 
 Upstream gradients gI ~ N(0,1), gD ~ N(0,0.01) come from numpy's frozen legacy
 RandomState(seed) so tests can regenerate them bit-exactly; they are stored too.
@@ -35,7 +36,7 @@ import torch
 
 from models.differentiable_renderer import (  # noqa: E402  (the reference, read-only)
     Camera, TileBasedRenderer, compute_2d_covariance,
-    AngularSpectrumPropagator, ASMWaveFieldRenderer,
+    AngularSpectrumPropagator, ASMWaveFieldRenderer, WaveFieldRenderer,
 )
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -359,5 +360,38 @@ def main():
         save(rec, f"G9_asm256_128_{tag}.npz")
 
 
+def wave_goldens():
+    """G10: WaveFieldRenderer (DR:689-926), N=256 @128x128, scalar and per-channel phases,
+    image + depth map + all gradients."""
+    R = 128
+    pos, scale, rot, col, opa = dummy_saag(256, 10)
+    g = torch.Generator().manual_seed(10)
+    rot = torch.randn(256, 4, generator=g)
+    scale = torch.rand(256, 3, generator=g) * 0.06 + 0.03
+    ph_s = torch.rand(256, generator=g) * 2 * np.pi
+    ph_v = torch.rand(256, 3, generator=g) * 2 * np.pi
+    cam = frontal_camera(R)
+    for tag, ph in (("scalar", ph_s), ("rgb", ph_v)):
+        ren = WaveFieldRenderer(R, R, background=(0.1, 0.15, 0.2))
+        leaves = [t.clone().requires_grad_(True) for t in (pos, scale, rot, col, opa, ph)]
+        img, dep = ren(*leaves[:5], cam, return_depth=True, phases=leaves[5])
+        gI, gD = upstream(110, R, R)
+        ((img * torch.from_numpy(gI)).sum() + (dep * torch.from_numpy(gD)).sum()).backward()
+        rec = dict(positions=pos.numpy(), scales=scale.numpy(), rotations=rot.numpy(), colors=col.numpy(),
+                   opacities=opa.numpy(), phases=ph.numpy(), background=np.array([0.1, 0.15, 0.2], np.float32),
+                   view=cam.view_matrix.numpy(), size=np.array([R, R], np.int32),
+                   intr=np.array([cam.fx, cam.fy, cam.cx, cam.cy, cam.near, cam.far]), gI=gI, gD=gD,
+                   seed_up=np.int32(110), image=img.detach().numpy(), depth=dep.detach().numpy())
+        for n, t in zip(["positions", "scales", "rotations", "colors", "opacities", "phases"], leaves):
+            rec["grad_" + n] = t.grad.numpy()
+        for k, v in META.items():
+            rec["meta_" + k] = np.array(v)
+        save(rec, f"G10_wave256_128_{tag}.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if "--wave-only" in sys.argv:
+        wave_goldens()
+    else:
+        main()
+        wave_goldens()

@@ -220,3 +220,17 @@ def test_asm_renderer_g9(tag):
     fin = np.isfinite(g["grad_wavelengths"])
     assert fin.sum() == 2
     assert rel_to_max(r["grad_wavelengths"][fin], g["grad_wavelengths"][fin]) <= 1e-5
+
+
+@pytest.mark.parametrize("tag", ["scalar", "rgb"])
+def test_wave_renderer_g10(tag):
+    """oracle/asm_oracle.render_wave vs the reference WaveFieldRenderer (DR:689-926)."""
+    from oracle import asm_oracle
+    g = load_golden(f"G10_wave256_128_{tag}")
+    r = asm_oracle.render_wave(g["positions"], g["scales"], g["rotations"], g["colors"], g["opacities"],
+                               g["phases"], oracle_camera(g), bg=g["background"], grad_out=g["gI"],
+                               grad_depth=g["gD"])
+    assert np.abs(r["image"] - g["image"]).max() <= 1e-5
+    assert rel_to_max(r["depth"], g["depth"]) <= 1e-5
+    for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
+        assert rel_to_max(r["grad_" + k], g["grad_" + k]) <= 1e-4, k
