@@ -237,6 +237,14 @@ class TileBasedRenderer(nn.Module):
             raise RuntimeError(
                 f"TileBasedRenderer phase blending expects phases of shape (N,), got {tuple(phases.shape[1:])}")
         bg = tuple(float(b) for b in self.background.tolist())
+        if positions.shape[1] == 0:
+            # no Gaussians at all: the reference's zero-visible branch (DR:545-552) -- background, zero depth
+            Bn, dev = positions.shape[0], positions.device
+            img = torch.tensor(bg, device=dev).view(1, 3, 1, 1).expand(Bn, 3, self.height, self.width) + positions.sum() * 0.0
+            depth = torch.zeros(Bn, self.height, self.width, device=dev) + positions.sum() * 0.0
+            if not batched:
+                img, depth = img[0], depth[0]
+            return (img, depth) if return_depth else img
         img, depth = render_batch(positions, scales, rotations, colors, opacities, camera, self.width,
                                   self.height, bg, self.max_radius, phases if use_phase else None,
                                   use_phase, self.phase_amplitude)

@@ -66,6 +66,7 @@ class TrainingConfig:  # subset of TGD:97-162 that this path uses; same names an
     num_fresnel_zones: int = 8
     use_phase_blending: bool = False
     phase_amplitude: float = 0.25
+    use_wave_rendering: bool = False  # WaveFieldRenderer (TGD:178, 1891-1897); --use_qsr implies it
     device: str = "cuda" if torch.cuda.is_available() else "cpu"
     log_interval: int = 10
     save_interval: int = 10
@@ -122,8 +123,12 @@ def default_renderer_factory(cfg: TrainingConfig, device):
     """The product renderer: HIP TileBasedRenderer + the reference camera (TGD:1898-1917)."""
     from .renderer import Camera, TileBasedRenderer
     res = cfg.image_size
-    renderer = TileBasedRenderer(res, res, use_phase_blending=cfg.use_phase_blending,
-                                 phase_amplitude=cfg.phase_amplitude).to(device)
+    if cfg.use_wave_rendering:  # TGD:1891-1897
+        from .renderer import WaveFieldRenderer
+        renderer = WaveFieldRenderer(res, res).to(device)
+    else:                       # TGD:1898-1906
+        renderer = TileBasedRenderer(res, res, use_phase_blending=cfg.use_phase_blending,
+                                     phase_amplitude=cfg.phase_amplitude).to(device)
     camera = Camera(fx=res * 0.8, fy=res * 0.8, cx=res / 2, cy=res / 2, width=res, height=res)
     return renderer, camera
 
@@ -132,7 +137,9 @@ def train_step(model, renderer, camera, batch, optimizer, cfg: TrainingConfig, d
     """One optimizer step on this rank's image shard.  Returns (loss_dict | None if skipped)."""
     images, feats, depth = batch
     out = model(feats, depth)
-    phases = out.get("phases") if cfg.use_phase_blending else None
+    phases = out.get("phases") if (cfg.use_phase_blending or cfg.use_wave_rendering) else None
+    if cfg.use_wave_rendering and phases is not None:
+        phases = phases * (2.0 * math.pi)  # wave renderers take radians (DR:772), the decoder emits [0,1]
     # ONE batched call replaces the per-image loop of TGD:1209-1223
     rendered, rdepth = renderer(out["positions"], out["scales"], out["rotations"], out["colors"],
                                 out["opacities"], camera, return_depth=True, phases=phases)
@@ -171,7 +178,7 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
     model = PatchGaussianDecoder(cfg.feature_dim, cfg.gaussians_per_patch, grid=cfg.feature_size,
                                  use_fresnel_zones=cfg.use_fresnel_zones,
                                  num_fresnel_zones=cfg.num_fresnel_zones,
-                                 use_phase_output=cfg.use_phase_blending).to(device)
+                                 use_phase_output=cfg.use_phase_blending or cfg.use_wave_rendering).to(device)
     dp.broadcast_parameters(model)
     renderer, camera = renderer_factory(cfg, device)
     optimizer = AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
@@ -228,6 +235,8 @@ def main(argv=None):
     ap.add_argument("--num_fresnel_zones", type=int, default=c.num_fresnel_zones)
     ap.add_argument("--use_phase_blending", action="store_true")
     ap.add_argument("--phase_amplitude", type=float, default=c.phase_amplitude)
+    ap.add_argument("--use_wave_rendering", action="store_true", help="WaveFieldRenderer (TGD:1469)")
+    ap.add_argument("--use_qsr", action="store_true", help="macro flag: implies --use_wave_rendering (TGD:1550-1553)")
     ap.add_argument("--resume", default=None)
     ap.add_argument("--renderer", default="hip", choices=["hip"],
                     help="only the HIP rasterizer ships; there is no CPU fallback")
@@ -245,6 +254,7 @@ def main(argv=None):
                          use_fresnel_zones=bool(a.use_fresnel_zones),
                          num_fresnel_zones=a.use_fresnel_zones or a.num_fresnel_zones,
                          use_phase_blending=a.use_phase_blending, phase_amplitude=a.phase_amplitude,
+                         use_wave_rendering=a.use_wave_rendering or a.use_qsr,
                          device=f"cuda:{local_rank}", seed=a.seed)
     dp = DPContext(device=torch.device(cfg.device))
     try:

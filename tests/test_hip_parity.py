@@ -328,3 +328,33 @@ def test_phase_rgb_phases_raise_like_the_reference():
     a = ren0(pos, scale, quat, col, opa, Camera(25.6, 25.6, 16, 16, 32, 32), phases=torch.rand(64, device=dev))
     b = ren0(pos, scale, quat, col, opa, Camera(25.6, 25.6, 16, 16, 32, 32))
     assert torch.equal(a, b)
+
+
+def test_edge_cases_tiny_frames_single_gaussian_and_empty_input():
+    """Frame smaller than one tile, a single Gaussian, N not a multiple of anything, a Gaussian far
+    larger than the frame (radius cap + full-frame bbox), and N = 0."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd.renderer import Camera, TileBasedRenderer
+    dev = _cuda()
+    rs = np.random.RandomState(3)
+    for (W, H, N) in [(8, 8, 1), (5, 9, 7), (17, 33, 3), (40, 24, 131)]:
+        pos = (rs.standard_normal((N, 3)) * 0.3).astype(np.float32)
+        pos[:, 2] -= 1.5
+        scale = (rs.random_sample((N, 3)) * 0.4 + 0.02).astype(np.float32)
+        quat = rs.standard_normal((N, 4)).astype(np.float32)
+        col = rs.random_sample((N, 3)).astype(np.float32)
+        opa = rs.random_sample(N).astype(np.float32)
+        cam = Camera(0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+        ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+        gI = rs.standard_normal((3, H, W)).astype(np.float32)
+        gD = rs.standard_normal((H, W)).astype(np.float32)
+        out = _hip_render([pos, scale, quat, col, opa], cam, W, H, (0.3, 0.2, 0.1), grads=(gI, gD))
+        r = _oracle([pos, scale, quat, col, opa], ocam, (0.3, 0.2, 0.1))
+        assert rel_to_max(out["image"], r.image) <= TOL and rel_to_max(out["depth"], r.depth) <= TOL
+        go = orc.render_backward(r, gI, gD)
+        for k in ["positions", "scales", "rotations", "colors", "opacities"]:
+            assert rel_to_max(out["grad_" + k], go[k]) <= TOL, (W, H, N, k)
+    ren = TileBasedRenderer(16, 12, background=(0.5, 0.25, 0.125))
+    z = lambda *s: torch.zeros(*s, device=dev)
+    img, dep = ren(z(0, 3), z(0, 3), z(0, 4), z(0, 3), z(0), Camera(12.8, 9.6, 8, 6, 16, 12), return_depth=True)
+    assert img.shape == (3, 12, 16) and torch.all(img[1] == 0.25) and not dep.any()

@@ -19,3 +19,17 @@ def test_harness_trains_through_hip_renderer(tmp_path):
     assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "losses", "config"}  # TGD:1304-1310
     for p in model.parameters():
         assert torch.isfinite(p).all()
+
+
+def test_harness_wave_and_phase_renderers(tmp_path):
+    """--use_wave_rendering (WaveFieldRenderer) and --use_phase_blending --use_fresnel_zones (config 4)
+    train through the HIP kernels without NaNs."""
+    from fresnel_amd.train import TrainingConfig, run_training
+    for kw in (dict(use_wave_rendering=True), dict(use_phase_blending=True, use_fresnel_zones=True)):
+        cfg = TrainingConfig(batch_size=2, epochs=1, lr=2e-3, image_size=64, feature_size=6, feature_dim=16,
+                             gaussians_per_patch=4, device="cuda:0", steps_per_epoch=3, save_interval=100,
+                             output_dir=str(tmp_path), log_interval=1000, **kw)
+        model, hist = run_training(cfg, log=lambda *a: None)
+        assert len(hist) == 1 and "total" in hist[0] and hist[0]["total"] == hist[0]["total"]
+        for p in model.parameters():
+            assert torch.isfinite(p).all()
