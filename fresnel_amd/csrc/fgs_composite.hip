@@ -174,6 +174,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
     __shared__ uint32_t shm[CH];
+    __shared__ __attribute__((aligned(16))) float qpart[4][10][16];  // quad partial sums of 4 list entries
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
@@ -249,15 +250,29 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                 v_ca += dmx * dx; v_cbc += dmx * dy; v_cd += dmy * dy;
                 v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
             }
-            wave_sum10_lane63(v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d);
-            const float v_u = v_mx, v_v = v_my;
-            if (lane == 63) {
-                const uint32_t e = she[j];
-                if (e < dcap) {
-                    float4 *dst = reinterpret_cast<float4 *>(grad_rows + (size_t)e * FGS_GROW_FLOATS);
-                    dst[0] = make_float4(v_u, v_v, v_ca, v_cbc);
-                    dst[1] = make_float4(v_cd, v_op, v_r, v_g);
-                    dst[2] = make_float4(v_b, v_d, 0.0f, 0.0f);
+            // ---- reduce the ten sums over the 64 lanes ----
+            // two DPP steps leave the quad sums in lanes 3, 7, 11, ...; those 16 lanes park them in LDS
+            // ([entry][value][quad]); every four list entries 40 lanes finish the 40 (entry, value) sums
+            // (four ds_read_b128 + 15 adds each) and store them straight into the gradient rows.
+            // ~26 VALU instructions per duplicate instead of the 60 of a full DPP tree.
+            quad_sum10(v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d);
+            if ((lane & 3u) == 3u) {
+                float *qp = &qpart[j & 3u][0][lane >> 2];
+                qp[0 * 16] = v_mx; qp[1 * 16] = v_my; qp[2 * 16] = v_ca; qp[3 * 16] = v_cbc; qp[4 * 16] = v_cd;
+                qp[5 * 16] = v_op; qp[6 * 16] = v_r; qp[7 * 16] = v_g; qp[8 * 16] = v_b; qp[9 * 16] = v_d;
+            }
+            if ((j & 3u) == 3u || j + 1 == n) {
+                const uint32_t j0 = j & ~3u;
+                if (lane < 40u) {
+                    const uint32_t r = lane / 10u, kk = lane - 10u * r;
+                    if (j0 + r <= j) {
+                        const float4 *src = reinterpret_cast<const float4 *>(&qpart[r][kk][0]);
+                        const float4 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
+                        const float tot = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+                                          (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+                        const uint32_t e = she[j0 + r];
+                        if (e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + kk] = tot;
+                    }
                 }
             }
         }

@@ -49,3 +49,14 @@ __device__ __forceinline__ uint32_t subtile_mask(uint32_t X0, uint32_t Y0, uint3
     const uint32_t ry0 = (y1 > Y0 && y0 < Y0 + 8u) ? 1u : 0u, ry1 = (y1 > Y0 + 8u && y0 < Y0 + 16u) ? 1u : 0u;
     return (cx0 & ry0) | ((cx1 & ry0) << 1) | ((cx0 & ry1) << 2) | ((cx1 & ry1) << 3);
 }
+
+// Quad sums of ten values: after row_shr:1 and row_shr:2 every lane with (lane & 3) == 3 holds the
+// sum over its quad.  20 VALU instructions; the remaining 16-way sum is finished through LDS by
+// the caller (see k_composite_bwd).
+__device__ __forceinline__ void quad_sum10(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
+                                           float &a6, float &a7, float &a8, float &a9) {
+    asm volatile("s_nop 1\n" FGS_DPP10("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 FGS_DPP10("row_shr:2 row_mask:0xf bank_mask:0xf") "s_nop 1\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
+                   "+v"(a9));
+}
