@@ -39,7 +39,9 @@ class FgsSavedLayout(ctypes.Structure):
                 ("ranges", ctypes.c_size_t), ("tile_order", ctypes.c_size_t), ("dup_ids", ctypes.c_size_t),
                 ("pix_state", ctypes.c_size_t), ("phase_ckpt", ctypes.c_size_t),
                 ("dup_capacity", ctypes.c_size_t),
-                ("tiles_x", ctypes.c_int32), ("tiles_y", ctypes.c_int32)]
+                ("tiles_x", ctypes.c_int32), ("tiles_y", ctypes.c_int32),
+                ("seg_off", ctypes.c_size_t), ("seg_tile", ctypes.c_size_t), ("seg_ckpt", ctypes.c_size_t),
+                ("seg_capacity", ctypes.c_size_t)]
 
 
 class FgsAsmDims(ctypes.Structure):

@@ -24,7 +24,7 @@ SOURCES = {
     "fgs_project.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "fgs_sort.hip": [],
     "fgs_bin.hip": [],
-    "fgs_composite.hip": ["-ffast-math", "-fno-finite-math-only"],
+    "fgs_composite.hip": ["-ffast-math", "-fno-finite-math-only", "-fno-slp-vectorize"],
     "fgs_asm.hip": [],
 }
 LINK_LIBS = ["-lhipfft"]

@@ -98,6 +98,14 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers) {
     if (d->use_phase) o = align256(o + (dcap / FGS_PHASE_CKPT + B * p->tiles + 2) * 8 * 64 * 4);
     p->s_layer = o;
     if (layers > 1) o = align256(o + B * N * 4);
+    const size_t ucap = dcap / FGS_SEG + B * p->tiles;
+    L.seg_off = o; L.seg_tile = o; L.seg_ckpt = o; L.seg_capacity = 0;
+    if (layers == 1 && !d->use_phase) {
+        L.seg_capacity = ucap;
+        L.seg_off = o; o = align256(o + (B * p->tiles + 1) * 4);
+        L.seg_tile = o; o = align256(o + ucap * 4);
+        L.seg_ckpt = o; o = align256(o + ucap * 5 * 256 * 4);
+    }
     L.total_bytes = o;
     L.dup_capacity = dcap;
     L.tiles_x = tx; L.tiles_y = ty;

@@ -127,10 +127,18 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t *__restrict_
 // the hardware dispatcher hands workgroups to CUs in blockIdx order, so heavy tiles start
 // early and light ones fill the tail).  Single-block counting sort into 64 length buckets;
 // the order inside a bucket is arbitrary -- it affects scheduling only, never results.
+//
+// The same block also cuts every list into depth segments of FGS_SEG entries (the backward's work
+// units): exclusive scan of ceil(len / FGS_SEG) over the tiles -> seg_off, the unit -> tile map
+// seg_tile, and the unit count in seg_off[ntiles] and counters[2].
 __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, const uint32_t *__restrict__ ranges,
-                                                     uint32_t *__restrict__ tile_order) {
+                                                     uint32_t *__restrict__ tile_order,
+                                                     uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_tile,
+                                                     uint32_t *__restrict__ counters) {
     __shared__ uint32_t hist[64];
     __shared__ uint32_t maxc;
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) maxc = 1;
     __syncthreads();
@@ -152,6 +160,36 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, const uint
         const uint32_t pos = atomicAdd(&hist[63u - (uint32_t)(((unsigned long long)cnt * 63ull) / mx)], 1u);
         tile_order[pos] = t;
     }
+    if (!seg_off) return;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < ntiles; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        const uint32_t n = t < ntiles ? (ranges[2 * t + 1] - ranges[2 * t] + FGS_SEG - 1) / FGS_SEG : 0u;
+        uint32_t x = n;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= (uint32_t)o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int i = 0; i < 16; ++i) { const uint32_t h = wsum[i]; wsum[i] = run; run += h; }
+        }
+        __syncthreads();
+        const uint32_t off = carry + wsum[wave] + x - n;
+        if (t < ntiles) {
+            seg_off[t] = off;
+            for (uint32_t k = 0; k < n; ++k) seg_tile[off + k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = off + n;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { seg_off[ntiles] = carry; counters[2] = carry; }
 }
 
 __global__ __launch_bounds__(256) void k_count_pairs(uint32_t total, const float *__restrict__ rec,
@@ -225,7 +263,9 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     hipLaunchKernelGGL(k_tile_ranges, dim3(rgrid), dim3(256), 0, st, counters, ks, ranges);
     FGS_LAUNCH_CHECK("k_tile_ranges");
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, B * (uint32_t)p.layers * (uint32_t)p.tiles, ranges,
-                       reinterpret_cast<uint32_t *>(saved + p.L.tile_order));
+                       reinterpret_cast<uint32_t *>(saved + p.L.tile_order),
+                       p.L.seg_capacity ? reinterpret_cast<uint32_t *>(saved + p.L.seg_off) : nullptr,
+                       p.L.seg_capacity ? reinterpret_cast<uint32_t *>(saved + p.L.seg_tile) : nullptr, counters);
     FGS_LAUNCH_CHECK("k_tile_order");
     fgs_stage_end(ST_TILE_RANGES, st);
     return FGS_OK;

@@ -17,11 +17,14 @@
 // Bound: VALU + transcendental (about 25 VALU + 1 v_exp_f32 per Gaussian-pixel forward, ~60
 // backward); HBM traffic is the 52-byte id+record gather per duplicate plus per-pixel state.
 #include <stdlib.h>
+#include <stdio.h>
+#include <vector>
 #include "fgs_internal.h"
 #include "fgs_wave.h"
 
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;  // exp(-m/2) = exp2(m * this)
 constexpr float PHASE_KAPPA = 2.0f * 3.14159f;              // DR:642 uses the literal 3.14159
 constexpr int CH = 64;                                      // records per LDS chunk (one per lane)
@@ -30,11 +33,10 @@ struct TileCtx {
     uint32_t tile, b, tx, ty, X0, Y0, start, end;
 };
 
-__device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x,
-                                            const uint32_t *__restrict__ tile_order,
-                                            const uint32_t *__restrict__ ranges) {
+__device__ __forceinline__ TileCtx tile_ctx_of(uint32_t tile, uint32_t tiles, uint32_t tiles_x,
+                                               const uint32_t *__restrict__ ranges) {
     TileCtx c;
-    c.tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
+    c.tile = tile;
     c.b = c.tile / tiles;
     const uint32_t t = c.tile - c.b * tiles;
     c.ty = t / tiles_x;
@@ -44,6 +46,12 @@ __device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x,
     c.start = ranges[2 * c.tile];
     c.end = ranges[2 * c.tile + 1];
     return c;
+}
+
+__device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x,
+                                            const uint32_t *__restrict__ tile_order,
+                                            const uint32_t *__restrict__ ranges) {
+    return tile_ctx_of(tile_order ? tile_order[blockIdx.x] : blockIdx.x, tiles, tiles_x, ranges);
 }
 
 
@@ -65,8 +73,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
     float *__restrict__ pix_state, float *__restrict__ phase_ckpt, float *__restrict__ out_rgb,
-    float *__restrict__ out_depth) {
+    float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off, float *__restrict__ seg_ckpt) {
     constexpr int FCH = 64 * FWD_WAVES;  // records per LDS chunk (one per thread)
+    static_assert(FGS_SEG % FCH == 0, "segment boundaries must fall on chunk boundaries");
     __shared__ float4 sh0[FCH], sh1[FCH], sh2[FCH];
     __shared__ float shp[FCH];
     __shared__ uint32_t shm[FCH];
@@ -80,6 +89,16 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     for (int s = 0; s < NS; ++s) { A[s] = 0; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; Ph[s] = 0; }
     for (uint32_t base = c.start; base < c.end; base += FCH) {
         const uint32_t n = min((uint32_t)FCH, c.end - base);
+        if (!PHASE && base != c.start && ((base - c.start) % FGS_SEG) == 0) {
+            // state in front of this depth segment: the backward work unit (tile, segment) restarts from it
+            float *ck = seg_ckpt + ((size_t)seg_off[c.tile] + (base - c.start) / FGS_SEG) * (5 * 256) + lane;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t sg = wave * NS + s;
+                ck[(0 * 4 + sg) * 64] = Cr[s]; ck[(1 * 4 + sg) * 64] = Cg[s]; ck[(2 * 4 + sg) * 64] = Cb[s];
+                ck[(3 * 4 + sg) * 64] = A[s]; ck[(4 * 4 + sg) * 64] = Dm[s];
+            }
+        }
         if (threadIdx.x < n) {
             const uint32_t gid = dup_ids[base + threadIdx.x];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
@@ -167,24 +186,35 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
 // k_project_bwd sums them in a fixed order.
 __global__ __launch_bounds__(64) void k_composite_bwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, uint32_t dcap,
-    const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
+    const uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg_off,
+    const uint32_t *__restrict__ seg_tile, const float *__restrict__ seg_ckpt, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const uint32_t *__restrict__ dup_off,
     const float *__restrict__ pix_state, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
-    float *__restrict__ grad_rows) {
+    float *__restrict__ grad_rows, unsigned long long *__restrict__ dbg_ts) {
+    const unsigned long long dbg_t0 = dbg_ts ? wall_clock64() : 0ull;
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
     __shared__ uint32_t shm[CH];
     __shared__ __attribute__((aligned(16))) float qpart[4][10][16];  // quad partial sums of 4 list entries
-    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
+    // work unit = (tile, depth segment): blockIdx.x indexes the unit list built by k_tile_order; the grid is
+    // sized from the capacity, surplus blocks leave at once
+    if (blockIdx.x >= counters[2]) return;
+    const uint32_t unit_tile = seg_tile[blockIdx.x];
+    const uint32_t seg = blockIdx.x - seg_off[unit_tile];
+    TileCtx c = tile_ctx_of(unit_tile, tiles, tiles_x, ranges);
+    c.start += seg * FGS_SEG;
+    c.end = min(c.end, c.start + FGS_SEG);
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const size_t HW = (size_t)W * H;
-    float gr[4], gg[4], gb[4], gd[4], S[4], A[4];  // S: T_fin (gI.bg) + sum over not-yet-visited w q
+    // T: running transmittance (w = alpha T, T -= w: one instruction less per pixel than T = 1 - A, A += w)
+    // S: T_fin (gI.bg) + sum over not-yet-visited w q
+    float gr[4], gg[4], gb[4], gd[4], S[4], T[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
         gr[s] = gg[s] = gb[s] = gd[s] = S[s] = 0.0f;
-        A[s] = 0.0f;
+        T[s] = 1.0f;
         if (px < W && py < H) {
             const size_t o = (size_t)py * W + px;
             const float *ps = pix_state + (size_t)c.b * 6 * HW + o;
@@ -199,54 +229,75 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             S[s] = Tf * (gr[s] * bg0 + gg[s] * bg1 + gb[s] * bg2) + (gr[s] * Cr + gg[s] * Cg + gb[s] * Cb) +
                    gd[s] * ps[4 * HW];
         }
+        if (seg) {
+            // restart from the forward's state in front of this segment: T, and S minus the part of Total that
+            // belongs to the list entries before it
+            const float *ck = seg_ckpt + (size_t)blockIdx.x * (5 * 256) + s * 64 + lane;
+            T[s] = 1.0f - ck[3 * 256];
+            S[s] -= gr[s] * ck[0] + gg[s] * ck[256] + gb[s] * ck[2 * 256] + gd[s] * ck[4 * 256];
+        }
     }
+    const uint32_t ix0 = c.X0 + lx, iy0 = c.Y0 + ly;
+    const float fx0 = (float)ix0, fy0 = (float)iy0;
     for (uint32_t base = c.start; base < c.end; base += CH) {
         const uint32_t n = min((uint32_t)CH, c.end - base);
         if (lane < n) {
             const uint32_t gid = dup_ids[base + lane];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
             float4 q2 = r[2];
+            const float4 q1n = r[1];
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
             const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu, by1 = bby >> 16;
             const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
             she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
-            shm[lane] = subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1);
+            // a negative opacity clamps to alpha = 0 with zero gradient everywhere (DR:646): drop the record
+            shm[lane] = q1n.y >= 0.0f ? subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1) : 0u;
             q2.z = __uint_as_float(bx0 | ((bx1 - bx0) << 16));
             q2.w = __uint_as_float(by0 | ((by1 - by0) << 16));
-            sh0[lane] = r[0]; sh1[lane] = r[1]; sh2[lane] = q2;
+            float4 q0 = r[0], q1 = r[1];
+            q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;  // conic in exp2 units
+            sh0[lane] = q0; sh1[lane] = q1; sh2[lane] = q2;
         }
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
             const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);  // origin | extent << 16
-            const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;
-            // per-lane partial sums over this lane's (up to four) pixels
+            const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;  // conic pre-multiplied by K = -log2(e)/2
+            // terms shared by the sub-tiles of a column / row, formed once per list entry
+            const float dxa = fx0 - q0.x, dya = fy0 - q0.y;
+            const float hp = 0.69314718055994530942f * op;  // dL/dm' = ln2 * opacity * dL/dG (m' = K m)
+            // bbox membership as VGPR lane masks, one (v_cmp, v_cndmask) pair per column / row half and list
+            // entry (in_mask): the per-pixel select then is a v_and_b32 on G -- see the issue-cost table in
+            // DESIGN.md (a v_cndmask on a scalar-written VCC costs ~23 cycles, v_and_b32 ~2.5).
+            const uint32_t rx = ix0 - (bbx & 0xFFFFu), ry = iy0 - (bby & 0xFFFFu);
+            const uint32_t mx0 = in_mask(rx, bbx), mx1 = in_mask(rx + 8u, bbx);
+            const uint32_t my0 = in_mask(ry, bby), my1 = in_mask(ry + 8u, bby);
+            // per-lane partial sums over this lane's (up to four) pixels; the conic sums are in exp2 units
+            // (rescaled by K when the totals are stored)
             float v_mx = 0, v_my = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
-                const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
-                const bool in = (px - (bbx & 0xFFFFu)) < (bbx >> 16) && (py - (bby & 0xFFFFu)) < (bby >> 16);
-                const float dx = (float)px - q0.x, dy = (float)py - q0.y;
-                const float m = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
-                const float G = __builtin_amdgcn_exp2f(m * NEG_HALF_LOG2E);
-                const float raw = G * op;
-                const float alpha = in ? fminf(fmaxf(raw, 0.0f), 0.99f) : 0.0f;
-                const bool pass = in && raw >= 0.0f && raw <= 0.99f;  // clamp backward, closed interval
-                const float T = 1.0f - A[s];
-                const float w = alpha * T;
+                const uint32_t mk = ((s & 1) ? mx1 : mx0) & ((s >> 1) ? my1 : my0);
+                const float dx = (s & 1) ? dxa + 8.0f : dxa, dy = (s >> 1) ? dya + 8.0f : dya;
+                const float ax = ca * dx, cy = cd * dy;
+                const float t = cbc * dy + ax;
+                // G is zeroed outside the bbox: alpha, w and every gradient term below then vanish by themselves
+                const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(cy * dy + t * dx)) & mk);
+                const float raw = G * op;  // >= 0: records with a negative opacity are dropped at staging
+                const float alpha = fminf(raw, 0.99f);
+                const float w = alpha * T[s];
                 const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
                 S[s] -= w * q;
-                const float dalpha = T * q - S[s] * __builtin_amdgcn_rcpf(1.0f - alpha);
-                const float draw = pass ? dalpha : 0.0f;
-                A[s] += w;
-                const float dG = draw * G;
-                const float dm = -0.5f * op * dG;
+                const float dalpha = T[s] * q - S[s] * __builtin_amdgcn_rcpf(1.0f - alpha);
+                T[s] -= w;
+                const float dG = select_le(raw, 0.99f, dalpha) * G;  // clamp backward: closed interval [0, 0.99]
                 v_op += dG;
-                const float dmx = dm * dx, dmy = dm * dy;
-                v_mx -= dm * (2.0f * ca * dx + cbc * dy);  // dL/du
-                v_my -= dm * (cbc * dx + 2.0f * cd * dy);  // dL/dv
+                const float dmp = hp * dG;
+                const float dmx = dmp * dx, dmy = dmp * dy;
+                v_mx -= dmp * (t + ax);                // dL/du  = -sum dm' (2 ca' dx + cbc' dy)
+                v_my -= dmp * (cbc * dx + (cy + cy));  // dL/dv  = -sum dm' (cbc' dx + 2 cd' dy)
                 v_ca += dmx * dx; v_cbc += dmx * dy; v_cd += dmy * dy;
                 v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
             }
@@ -271,12 +322,22 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                         const float tot = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
                                           (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
                         const uint32_t e = she[j0 + r];
-                        if (e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + kk] = tot;
+                        // dL/dconic = K * (sums in exp2 units); the other seven sums are already final
+                        const float scl = (kk >= 2u && kk <= 4u) ? NEG_HALF_LOG2E : 1.0f;
+                        if (e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + kk] = tot * scl;
                     }
                 }
             }
         }
         __syncthreads();
+    }
+    if (dbg_ts && threadIdx.x == 0) {  // scratch instrumentation (FGS_DBG_TS): per-tile start/end, placement, length
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *t = dbg_ts + 4ull * blockIdx.x;
+        t[0] = dbg_t0; t[1] = wall_clock64(); t[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        t[3] = c.end - c.start;
     }
 }
 
@@ -476,12 +537,14 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     const float *rec = reinterpret_cast<const float *>(saved + p.L.rec);
     float *pix = reinterpret_cast<float *>(saved + p.L.pix_state);
     float *ckpt = p.d.use_phase ? reinterpret_cast<float *>(saved + p.L.phase_ckpt) : nullptr;
+    const uint32_t *seg_off = reinterpret_cast<const uint32_t *>(saved + p.L.seg_off);
+    float *seg_ckpt = reinterpret_cast<float *>(saved + p.L.seg_ckpt);
     const int fw = env_int("FGS_FWD_WAVES", 2);  // waves per tile: 2 measured fastest (A/B in one process)
 #define FGS_FWD_LAUNCH(PH, FW)                                                                                \
     hipLaunchKernelGGL((k_composite_fwd<PH, FW>), dim3(grid), dim3(64 * FW), 0, st, (uint32_t)p.tiles,       \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
                        p.d.background[1], p.d.background[2], p.d.phase_amplitude, tile_order, ranges, dup_ids, \
-                       rec, phase, pix, ckpt, out_rgb, out_depth)
+                       rec, phase, pix, ckpt, out_rgb, out_depth, seg_off, seg_ckpt)
     if (p.d.use_phase) {
         if (fw == 1) FGS_FWD_LAUNCH(true, 1); else FGS_FWD_LAUNCH(true, 2);
     } else {
@@ -511,16 +574,30 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
         FGS_LAUNCH_CHECK("k_composite_bwd_phase");
         return FGS_OK;
     }
-    hipLaunchKernelGGL(k_composite_bwd, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
+    unsigned long long *dbg = nullptr;
+    const char *dbg_path = getenv("FGS_DBG_TS");  // scratch instrumentation: per-unit timeline dump
+    const uint32_t ugrid = (uint32_t)p.L.seg_capacity;
+    if (dbg_path) { (void)hipMalloc(&dbg, (size_t)ugrid * 32); (void)hipMemsetAsync(dbg, 0, (size_t)ugrid * 32, st); }
+    hipLaunchKernelGGL(k_composite_bwd, dim3(ugrid), dim3(64), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
                        (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0], p.d.background[1],
                        p.d.background[2], (uint32_t)p.L.dup_capacity,
-                       reinterpret_cast<const uint32_t *>(saved + p.L.tile_order),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.counters),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.seg_off),
+                       reinterpret_cast<const uint32_t *>(saved + p.L.seg_tile),
+                       reinterpret_cast<const float *>(saved + p.L.seg_ckpt),
                        reinterpret_cast<const uint32_t *>(saved + p.L.ranges),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_ids),
                        reinterpret_cast<const float *>(saved + p.L.rec),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const float *>(saved + p.L.pix_state), g_rgb, g_depth,
-                       reinterpret_cast<float *>(scratch + p.s_grows));
+                       reinterpret_cast<float *>(scratch + p.s_grows), dbg);
+    if (dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)ugrid * 4);
+        (void)hipMemcpy(h.data(), dbg, (size_t)ugrid * 32, hipMemcpyDeviceToHost);
+        (void)hipFree(dbg);
+        if (FILE *f = fopen(dbg_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
     FGS_LAUNCH_CHECK("k_composite_bwd");
     return FGS_OK;
 }

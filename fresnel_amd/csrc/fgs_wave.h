@@ -50,6 +50,24 @@ __device__ __forceinline__ uint32_t subtile_mask(uint32_t X0, uint32_t Y0, uint3
     return (cx0 & ry0) | ((cx1 & ry0) << 1) | ((cx0 & ry1) << 2) | ((cx1 & ry1) << 3);
 }
 
+// Lane mask (all ones / zero) of (r < extent), bb = origin | extent << 16.  The compare and the select are kept
+// ADJACENT in one asm block: a v_cndmask reading VCC straight after the v_cmp that wrote it issues in ~2.6
+// cycles on gfx950, any other VCC-reading v_cndmask (stale VCC, or VCC written by s_and_b64) in 14-23
+// (scratch/ubench/valu3.hip, valu4.hip).
+__device__ __forceinline__ uint32_t in_mask(uint32_t r, uint32_t bb) {
+    uint32_t m;
+    asm("v_cmp_lt_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:WORD_1\n\tv_cndmask_b32 %0, 0, -1, vcc"
+        : "=v"(m) : "v"(r), "v"(bb) : "vcc");
+    return m;
+}
+
+// (x <= lim) ? v : 0 with the same adjacent compare/select pairing.
+__device__ __forceinline__ float select_le(float x, float lim, float v) {
+    float o;
+    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(o) : "v"(x), "v"(lim), "v"(v) : "vcc");
+    return o;
+}
+
 // Quad sums of ten values: after row_shr:1 and row_shr:2 every lane with (lane & 3) == 3 holds the
 // sum over its quad.  20 VALU instructions; the remaining 16-way sum is finished through LDS by
 // the caller (see k_composite_bwd).

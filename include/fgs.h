@@ -32,6 +32,7 @@ extern "C" {
 #define FGS_EUNSUPPORTED (-3)
 
 #define FGS_TILE 16        /* tile edge in pixels */
+#define FGS_SEG 256        /* list entries per backward work unit (depth segment of a tile's list) */
 #define FGS_PHASE_CKPT 8   /* list entries between (A, Phi) checkpoints on the phase path */
 #define FGS_CAMERA_FLOATS 24
 
@@ -74,6 +75,14 @@ typedef struct FgsSavedLayout {
                           the start of every 8th list entry; slot = start/8 + chunk + tile        */
     size_t dup_capacity; /* Dcap (elements, not bytes)                                    */
     int32_t tiles_x, tiles_y;
+    /* Depth segments (non-phase path): a tile's list is cut into segments of FGS_SEG entries; each
+     * segment is one work unit of the backward, so a launch is balanced however uneven the lists are. */
+    size_t seg_off;    /* uint32 [B*T+1]: first unit of each (image,tile); [B*T] = number of units U
+                                          (also counters[2])                                        */
+    size_t seg_tile;   /* uint32 [Ucap]: (image,tile) of each unit; segment index = unit - seg_off    */
+    size_t seg_ckpt;   /* float  [Ucap][5][4][64]: per-pixel C_r,C_g,C_b,A,D of the tile at the START
+                                          of each unit with segment index >= 1 (written by the forward) */
+    size_t seg_capacity; /* Ucap = Dcap / FGS_SEG + B*T                                             */
 } FgsSavedLayout;
 
 /* Sizes of the two caller-provided device buffers.  `saved` must stay untouched between
