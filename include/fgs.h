@@ -32,7 +32,7 @@ extern "C" {
 #define FGS_EUNSUPPORTED (-3)
 
 #define FGS_TILE 16        /* tile edge in pixels */
-#define FGS_SEG 256        /* list entries per backward work unit (depth segment of a tile's list) */
+#define FGS_SEG 128        /* list entries per backward work unit (depth segment of a tile's list) */
 #define FGS_PHASE_CKPT 8   /* list entries between (A, Phi) checkpoints on the phase path */
 #define FGS_CAMERA_FLOATS 24
 
