@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
+#include <type_traits>
 #include "fgs_internal.h"
 #include "fgs_wave.h"
 
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
         }
     }
     const uint32_t ix0 = c.X0 + lx, iy0 = c.Y0 + ly;
-    const float fx0 = (float)ix0, fy0 = (float)iy0;
+    float fx0 = (float)ix0, fy0 = (float)iy0;
+    asm("" : "+v"(fx0), "+v"(fy0));  // hoisted for good: no v_cvt in the list loop
     for (uint32_t base = c.start; base < c.end; base += CH) {
         const uint32_t n = min((uint32_t)CH, c.end - base);
         if (lane < n) {
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
             she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
             // a negative opacity clamps to alpha = 0 with zero gradient everywhere (DR:646): drop the record
-            shm[lane] = q1n.y >= 0.0f ? subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1) : 0u;
+            shm[lane] = (q1n.y >= 0.0f ? subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1) : 0u) | (q1n.y <= 0.98f ? 16u : 0u);
             q2.z = __uint_as_float(bx0 | ((bx1 - bx0) << 16));
             q2.w = __uint_as_float(by0 | ((by1 - by0) << 16));
             float4 q0 = r[0], q1 = r[1];
@@ -265,7 +267,9 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);  // origin | extent << 16
             const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;  // conic pre-multiplied by K = -log2(e)/2
             // terms shared by the sub-tiles of a column / row, formed once per list entry
-            const float dxa = fx0 - q0.x, dya = fy0 - q0.y;
+            const float dxa = fx0 - q0.x, dya = fy0 - q0.y, dxb = dxa + 8.0f, dyb = dya + 8.0f;
+            float bdya = cbc * dya, bdyb = cbc * dyb, cyya = (cd * dya) * dya, cyyb = (cd * dyb) * dyb;
+            asm("" : "+v"(bdya), "+v"(bdyb), "+v"(cyya), "+v"(cyyb));  // keep the row terms: do not recompute them per sub-tile
             const float hp = 0.69314718055994530942f * op;  // dL/dm' = ln2 * opacity * dL/dG (m' = K m)
             // bbox membership as VGPR lane masks, one (v_cmp, v_cndmask) pair per column / row half and list
             // entry (in_mask): the per-pixel select then is a v_and_b32 on G -- see the issue-cost table in
@@ -276,31 +280,40 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             // per-lane partial sums over this lane's (up to four) pixels; the conic sums are in exp2 units
             // (rescaled by K when the totals are stored)
             float v_mx = 0, v_my = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
+            // CLAMP = false: opacity <= 0.98 and G <= 1 (+ rounding), so alpha = min(G op, 0.99) never binds and
+            // neither the min nor the clamp-gradient select is needed (flag bit 4 of the staged mask)
+            auto passes = [&](auto clamp_tag, auto full_tag) {
+                constexpr bool CLAMP = decltype(clamp_tag)::value;
+                constexpr bool FULL = decltype(full_tag)::value;  // all four sub-tiles touched: straight-line code
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
-                const uint32_t mk = ((s & 1) ? mx1 : mx0) & ((s >> 1) ? my1 : my0);
-                const float dx = (s & 1) ? dxa + 8.0f : dxa, dy = (s >> 1) ? dya + 8.0f : dya;
-                const float ax = ca * dx, cy = cd * dy;
-                const float t = cbc * dy + ax;
-                // G is zeroed outside the bbox: alpha, w and every gradient term below then vanish by themselves
-                const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(cy * dy + t * dx)) & mk);
-                const float raw = G * op;  // >= 0: records with a negative opacity are dropped at staging
-                const float alpha = fminf(raw, 0.99f);
-                const float w = alpha * T[s];
-                const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
-                S[s] -= w * q;
-                const float dalpha = T[s] * q - S[s] * __builtin_amdgcn_rcpf(1.0f - alpha);
-                T[s] -= w;
-                const float dG = select_le(raw, 0.99f, dalpha) * G;  // clamp backward: closed interval [0, 0.99]
-                v_op += dG;
-                const float dmp = hp * dG;
-                const float dmx = dmp * dx, dmy = dmp * dy;
-                v_mx -= dmp * (t + ax);                // dL/du  = -sum dm' (2 ca' dx + cbc' dy)
-                v_my -= dmp * (cbc * dx + (cy + cy));  // dL/dv  = -sum dm' (cbc' dx + 2 cd' dy)
-                v_ca += dmx * dx; v_cbc += dmx * dy; v_cd += dmy * dy;
-                v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
-            }
+                for (int s = 0; s < 4; ++s) {
+                    if (!FULL && !((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
+                    const uint32_t mk = ((s & 1) ? mx1 : mx0) & ((s >> 1) ? my1 : my0);
+                    const float dx = (s & 1) ? dxb : dxa, dy = (s >> 1) ? dyb : dya;
+                    const float t = ca * dx + ((s >> 1) ? bdyb : bdya);
+                    // G is zeroed outside the bbox: alpha, w and every gradient term below then vanish by themselves
+                    const float G = __uint_as_float(
+                        __float_as_uint(__builtin_amdgcn_exp2f(t * dx + ((s >> 1) ? cyyb : cyya))) & mk);
+                    const float raw = G * op;  // >= 0: records with a negative opacity are dropped at staging
+                    const float alpha = CLAMP ? fminf(raw, 0.99f) : raw;
+                    const float w = alpha * T[s];
+                    const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
+                    S[s] -= w * q;
+                    const float dalpha = T[s] * q - S[s] * __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T[s] -= w;
+                    // clamp backward: closed interval [0, 0.99]
+                    const float dG = (CLAMP ? select_le(raw, 0.99f, dalpha) : dalpha) * G;
+                    v_op += dG;
+                    const float dmp = hp * dG;
+                    const float dmx = dmp * dx, dmy = dmp * dy;
+                    v_mx += dmx; v_my += dmy;  // first moments; dL/d(u,v) = -conic_sym' (v_mx, v_my) is formed in k_project_bwd
+                    v_ca += dmx * dx; v_cbc += dmx * dy; v_cd += dmy * dy;
+                    v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
+                }
+            };
+            if ((msk & 31u) == 31u) passes(std::false_type{}, std::true_type{});
+            else if (msk & 16u) passes(std::false_type{}, std::false_type{});
+            else passes(std::true_type{}, std::false_type{});
             // ---- reduce the ten sums over the 64 lanes ----
             // two DPP steps leave the quad sums in lanes 3, 7, 11, ...; those 16 lanes park them in LDS
             // ([entry][value][quad]); every four list entries 40 lanes finish the 40 (entry, value) sums

@@ -283,7 +283,14 @@ __global__ __launch_bounds__(256) void k_project_bwd(
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 GJ[i][j] = (G2[i][0] * JSt[0][j] + G2[i][1] * JSt[1][j]) + (G2[0][i] * JS[0][j] + G2[1][i] * JS[1][j]);
-        const float gu = g_mean[0], gv = g_mean[1];
+        float gu = g_mean[0], gv = g_mean[1];
+        if (MODE == 0 && phase_channels) {
+            // MODE 0 reuses `phase_channels` as a flag: slots 0/1 of the rows hold the first moments
+            // M = sum dm' (dx, dy) in exp2 units (k_composite_bwd); dL/d(u,v) = -K conic_sym M, K = -log2(e)/2
+            const float kc = 0.72134752044448170368f, cbc = Y[0][1] + Y[1][0];
+            gu = kc * (2.0f * Y[0][0] * g_mean[0] + cbc * g_mean[1]);
+            gv = kc * (cbc * g_mean[0] + 2.0f * Y[1][1] * g_mean[1]);
+        }
         const float zs = o.zs, z2 = o.z2, z3 = o.z2 * o.zs;
         const float gxc = GJ[0][2] * fx / z2 + gu * (-fx / zs);
         const float gyc = GJ[1][2] * fy / z2 + gv * (fy / zs);
@@ -365,7 +372,7 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
                        reinterpret_cast<const uint32_t *>(saved + p.L.order),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                       g_quat, g_color, g_opacity, g_phase, nullptr, nullptr, 1);
+                       g_quat, g_color, g_opacity, g_phase, nullptr, nullptr, p.d.use_phase ? 0 : 1);
     FGS_LAUNCH_CHECK("k_project_bwd");
     return FGS_OK;
 }
