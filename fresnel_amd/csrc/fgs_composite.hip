@@ -253,7 +253,9 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
             she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
             // a negative opacity clamps to alpha = 0 with zero gradient everywhere (DR:646): drop the record
-            shm[lane] = (q1n.y >= 0.0f ? subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1) : 0u) | (q1n.y <= 0.98f ? 16u : 0u);
+            // bit 4: opacity <= 0.98 (the alpha clamp cannot bind); bit 5: the bbox covers the whole tile
+            shm[lane] = (q1n.y >= 0.0f ? subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1) : 0u) | (q1n.y <= 0.98f ? 16u : 0u) |
+                        ((bx0 <= c.X0 && bx1 >= c.X0 + 16u && by0 <= c.Y0 && by1 >= c.Y0 + 16u) ? 32u : 0u);
             q2.z = __uint_as_float(bx0 | ((bx1 - bx0) << 16));
             q2.w = __uint_as_float(by0 | ((by1 - by0) << 16));
             float4 q0 = r[0], q1 = r[1];
@@ -274,17 +276,21 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             // bbox membership as VGPR lane masks, one (v_cmp, v_cndmask) pair per column / row half and list
             // entry (in_mask): the per-pixel select then is a v_and_b32 on G -- see the issue-cost table in
             // DESIGN.md (a v_cndmask on a scalar-written VCC costs ~23 cycles, v_and_b32 ~2.5).
-            const uint32_t rx = ix0 - (bbx & 0xFFFFu), ry = iy0 - (bby & 0xFFFFu);
-            const uint32_t mx0 = in_mask(rx, bbx), mx1 = in_mask(rx + 8u, bbx);
-            const uint32_t my0 = in_mask(ry, bby), my1 = in_mask(ry + 8u, bby);
             // per-lane partial sums over this lane's (up to four) pixels; the conic sums are in exp2 units
             // (rescaled by K when the totals are stored)
             float v_mx = 0, v_my = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
             // CLAMP = false: opacity <= 0.98 and G <= 1 (+ rounding), so alpha = min(G op, 0.99) never binds and
             // neither the min nor the clamp-gradient select is needed (flag bit 4 of the staged mask)
-            auto passes = [&](auto clamp_tag, auto full_tag) {
+            auto passes = [&](auto clamp_tag, auto full_tag, auto inside_tag) {
                 constexpr bool CLAMP = decltype(clamp_tag)::value;
                 constexpr bool FULL = decltype(full_tag)::value;  // all four sub-tiles touched: straight-line code
+                constexpr bool INSIDE = decltype(inside_tag)::value;  // tile entirely inside the bbox: no lane masks
+                uint32_t mx0 = 0, mx1 = 0, my0 = 0, my1 = 0;
+                if (!INSIDE) {
+                    const uint32_t rx = ix0 - (bbx & 0xFFFFu), ry = iy0 - (bby & 0xFFFFu);
+                    mx0 = in_mask(rx, bbx); mx1 = in_mask(rx + 8u, bbx);
+                    my0 = in_mask(ry, bby); my1 = in_mask(ry + 8u, bby);
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     if (!FULL && !((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
@@ -292,8 +298,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                     const float dx = (s & 1) ? dxb : dxa, dy = (s >> 1) ? dyb : dya;
                     const float t = ca * dx + ((s >> 1) ? bdyb : bdya);
                     // G is zeroed outside the bbox: alpha, w and every gradient term below then vanish by themselves
-                    const float G = __uint_as_float(
-                        __float_as_uint(__builtin_amdgcn_exp2f(t * dx + ((s >> 1) ? cyyb : cyya))) & mk);
+                    const float Gu = __builtin_amdgcn_exp2f(t * dx + ((s >> 1) ? cyyb : cyya));
+                    const float G = INSIDE ? Gu : __uint_as_float(__float_as_uint(Gu) & mk);
                     const float raw = G * op;  // >= 0: records with a negative opacity are dropped at staging
                     const float alpha = CLAMP ? fminf(raw, 0.99f) : raw;
                     const float w = alpha * T[s];
@@ -311,9 +317,10 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                     v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
                 }
             };
-            if ((msk & 31u) == 31u) passes(std::false_type{}, std::true_type{});
-            else if (msk & 16u) passes(std::false_type{}, std::false_type{});
-            else passes(std::true_type{}, std::false_type{});
+            if ((msk & 63u) == 63u) passes(std::false_type{}, std::true_type{}, std::true_type{});
+            else if ((msk & 31u) == 31u) passes(std::false_type{}, std::true_type{}, std::false_type{});
+            else if (msk & 16u) passes(std::false_type{}, std::false_type{}, std::false_type{});
+            else passes(std::true_type{}, std::false_type{}, std::false_type{});
             // ---- reduce the ten sums over the 64 lanes ----
             // two DPP steps leave the quad sums in lanes 3, 7, 11, ...; those 16 lanes park them in LDS
             // ([entry][value][quad]); every four list entries 40 lanes finish the 40 (entry, value) sums
