@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
     __shared__ uint32_t shm[CH];
-    __shared__ __attribute__((aligned(16))) float qpart[4][10][16];  // quad partial sums of 4 list entries
+    __shared__ __attribute__((aligned(16))) float red[10][80];  // per-lane partial sums of one list entry, transposed
     // work unit = (tile, depth segment): blockIdx.x indexes the unit list built by k_tile_order; the grid is
     // sized from the capacity, surplus blocks leave at once
     if (blockIdx.x >= counters[2]) return;
@@ -322,31 +322,29 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             else if (msk & 16u) passes(std::false_type{}, std::false_type{}, std::false_type{});
             else passes(std::true_type{}, std::false_type{}, std::false_type{});
             // ---- reduce the ten sums over the 64 lanes ----
-            // two DPP steps leave the quad sums in lanes 3, 7, 11, ...; those 16 lanes park them in LDS
-            // ([entry][value][quad]); every four list entries 40 lanes finish the 40 (entry, value) sums
-            // (four ds_read_b128 + 15 adds each) and store them straight into the gradient rows.
-            // ~26 VALU instructions per duplicate instead of the 60 of a full DPP tree.
-            quad_sum10(v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d);
-            if ((lane & 3u) == 3u) {
-                float *qp = &qpart[j & 3u][0][lane >> 2];
-                qp[0 * 16] = v_mx; qp[1 * 16] = v_my; qp[2 * 16] = v_ca; qp[3 * 16] = v_cbc; qp[4 * 16] = v_cd;
-                qp[5 * 16] = v_op; qp[6 * 16] = v_r; qp[7 * 16] = v_g; qp[8 * 16] = v_b; qp[9 * 16] = v_d;
-            }
-            if ((j & 3u) == 3u || j + 1 == n) {
-                const uint32_t j0 = j & ~3u;
+            // Through LDS, transposed: every lane parks its ten partial sums ([value][16-lane part][16 + pad]),
+            // then lane 4 k + p adds the 16 partials of part p of value k (four ds_read_b128, 15 adds), two DPP
+            // steps fold the four parts, and lanes 3, 7, .., 39 store the ten totals of this duplicate straight
+            // into its gradient row.  ~20 VALU-cycles-equivalents of plain adds instead of 20 DPP adds at 4.3
+            // cycles each; LDS instructions of one wave execute in order, so no barrier is needed.
+            {
+                float *wp = &red[0][(lane >> 4) * 20u + (lane & 15u)];
+                wp[0 * 80] = v_mx; wp[1 * 80] = v_my; wp[2 * 80] = v_ca; wp[3 * 80] = v_cbc; wp[4 * 80] = v_cd;
+                wp[5 * 80] = v_op; wp[6 * 80] = v_r; wp[7 * 80] = v_g; wp[8 * 80] = v_b; wp[9 * 80] = v_d;
+                __builtin_amdgcn_wave_barrier();
                 if (lane < 40u) {
-                    const uint32_t r = lane / 10u, kk = lane - 10u * r;
-                    if (j0 + r <= j) {
-                        const float4 *src = reinterpret_cast<const float4 *>(&qpart[r][kk][0]);
-                        const float4 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
-                        const float tot = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
-                                          (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-                        const uint32_t e = she[j0 + r];
-                        // dL/dconic = K * (sums in exp2 units); the other seven sums are already final
-                        const float scl = (kk >= 2u && kk <= 4u) ? NEG_HALF_LOG2E : 1.0f;
-                        if (e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + kk] = tot * scl;
-                    }
+                    const uint32_t kk = lane >> 2;
+                    const float4 *src = reinterpret_cast<const float4 *>(&red[kk][(lane & 3u) * 20u]);
+                    const float4 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
+                    float tot = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+                                (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+                    quad_sum1(tot);
+                    const uint32_t e = she[j];
+                    // dL/dconic = K * (sums in exp2 units); the other seven sums are already final
+                    const float scl = (kk >= 2u && kk <= 4u) ? NEG_HALF_LOG2E : 1.0f;
+                    if ((lane & 3u) == 3u && e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + kk] = tot * scl;
                 }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();

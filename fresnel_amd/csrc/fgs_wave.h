@@ -68,6 +68,12 @@ __device__ __forceinline__ float select_le(float x, float lim, float v) {
     return o;
 }
 
+// Quad sum of one value: lanes with (lane & 3) == 3 end up with the sum over their quad.
+__device__ __forceinline__ void quad_sum1(float &a) {
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n" : "+v"(a));
+}
+
 // Quad sums of ten values: after row_shr:1 and row_shr:2 every lane with (lane & 3) == 3 holds the
 // sum over its quad.  20 VALU instructions; the remaining 16-way sum is finished through LDS by
 // the caller (see k_composite_bwd).
