@@ -195,7 +195,6 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     const unsigned long long dbg_t0 = dbg_ts ? wall_clock64() : 0ull;
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
-    __shared__ uint32_t shm[CH];
     __shared__ __attribute__((aligned(16))) float red[10][80];  // per-lane partial sums of one list entry, transposed
     // work unit = (tile, depth segment): blockIdx.x indexes the unit list built by k_tile_order; the grid is
     // sized from the capacity, surplus blocks leave at once
@@ -238,8 +237,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             S[s] -= gr[s] * ck[0] + gg[s] * ck[256] + gb[s] * ck[2 * 256] + gd[s] * ck[4 * 256];
         }
     }
-    const uint32_t ix0 = c.X0 + lx, iy0 = c.Y0 + ly;
-    float fx0 = (float)ix0, fy0 = (float)iy0;
+    const uint32_t shx = lx, shy = 16u + ly;  // this lane's column / row bit in the staged pixel bits
+    float fx0 = (float)(c.X0 + lx), fy0 = (float)(c.Y0 + ly);
     asm("" : "+v"(fx0), "+v"(fy0));  // hoisted for good: no v_cvt in the list loop
     for (uint32_t base = c.start; base < c.end; base += CH) {
         const uint32_t n = min((uint32_t)CH, c.end - base);
@@ -247,17 +246,13 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             const uint32_t gid = dup_ids[base + lane];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
             float4 q2 = r[2];
-            const float4 q1n = r[1];
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
-            const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu, by1 = bby >> 16;
+            const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu;
             const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
             she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
-            // a negative opacity clamps to alpha = 0 with zero gradient everywhere (DR:646): drop the record
-            // bit 4: opacity <= 0.98 (the alpha clamp cannot bind); bit 5: the bbox covers the whole tile
-            shm[lane] = (q1n.y >= 0.0f ? subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1) : 0u) | (q1n.y <= 0.98f ? 16u : 0u) |
-                        ((bx0 <= c.X0 && bx1 >= c.X0 + 16u && by0 <= c.Y0 && by1 >= c.Y0 + 16u) ? 32u : 0u);
-            q2.z = __uint_as_float(bx0 | ((bx1 - bx0) << 16));
-            q2.w = __uint_as_float(by0 | ((by1 - by0) << 16));
+            uint32_t flags, bits;
+            stage_decode(c.X0, c.Y0, bbx, bby, r[1].y, flags, bits);
+            q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
             float4 q0 = r[0], q1 = r[1];
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;  // conic in exp2 units
             sh0[lane] = q0; sh1[lane] = q1; sh2[lane] = q2;
@@ -265,17 +260,16 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-            const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
-            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);  // origin | extent << 16
+            const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));  // stage_decode flags
+            const uint32_t bits = __float_as_uint(q2.z);                                // stage_decode pixel bits
             const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;  // conic pre-multiplied by K = -log2(e)/2
             // terms shared by the sub-tiles of a column / row, formed once per list entry
             const float dxa = fx0 - q0.x, dya = fy0 - q0.y, dxb = dxa + 8.0f, dyb = dya + 8.0f;
             float bdya = cbc * dya, bdyb = cbc * dyb, cyya = (cd * dya) * dya, cyyb = (cd * dyb) * dyb;
             asm("" : "+v"(bdya), "+v"(bdyb), "+v"(cyya), "+v"(cyyb));  // keep the row terms: do not recompute them per sub-tile
             const float hp = 0.69314718055994530942f * op;  // dL/dm' = ln2 * opacity * dL/dG (m' = K m)
-            // bbox membership as VGPR lane masks, one (v_cmp, v_cndmask) pair per column / row half and list
-            // entry (in_mask): the per-pixel select then is a v_and_b32 on G -- see the issue-cost table in
-            // DESIGN.md (a v_cndmask on a scalar-written VCC costs ~23 cycles, v_and_b32 ~2.5).
+            // bbox membership: the lane's column / row bits of the staged pixel bits become all-ones / zero masks
+            // (v_bfe_i32) and zero G with a bit-and -- no per-pixel compare / select (issue costs: DESIGN.md).
             // per-lane partial sums over this lane's (up to four) pixels; the conic sums are in exp2 units
             // (rescaled by K when the totals are stored)
             float v_mx = 0, v_my = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
@@ -286,10 +280,9 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                 constexpr bool FULL = decltype(full_tag)::value;  // all four sub-tiles touched: straight-line code
                 constexpr bool INSIDE = decltype(inside_tag)::value;  // tile entirely inside the bbox: no lane masks
                 uint32_t mx0 = 0, mx1 = 0, my0 = 0, my1 = 0;
-                if (!INSIDE) {
-                    const uint32_t rx = ix0 - (bbx & 0xFFFFu), ry = iy0 - (bby & 0xFFFFu);
-                    mx0 = in_mask(rx, bbx); mx1 = in_mask(rx + 8u, bbx);
-                    my0 = in_mask(ry, bby); my1 = in_mask(ry + 8u, bby);
+                if (!INSIDE) {  // one v_bfe_i32 per column / row half: the lane's bit as an all-ones / zero mask
+                    mx0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx, 1); mx1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u, 1);
+                    my0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy, 1); my1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u, 1);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {

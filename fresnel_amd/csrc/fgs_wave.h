@@ -50,6 +50,26 @@ __device__ __forceinline__ uint32_t subtile_mask(uint32_t X0, uint32_t Y0, uint3
     return (cx0 & ry0) | ((cx1 & ry0) << 1) | ((cx0 & ry1) << 2) | ((cx1 & ry1) << 3);
 }
 
+// Staging-time decode (per lane, parallel over the chunk) of a record against the 16x16 tile at (X0, Y0), for the
+// non-phase composite kernels:
+//   flags  bits 0-3: sub-tile s (8x8, s = 2*row + col) intersects the bbox -- all clear when the opacity is
+//                    negative (alpha clamps to 0 with zero gradient, DR:646: the record contributes nothing);
+//          bit 4:    opacity <= 0.98, so alpha = min(G op, 0.99) cannot bind (G <= 1 up to rounding);
+//          bit 5:    the bbox covers the whole tile (no per-pixel membership test needed)
+//   bits   bit i (i < 16): pixel column X0 + i lies in [x0, x1);  bit 16 + i: pixel row Y0 + i lies in [y0, y1).
+// In the list loop a lane turns its column / row bit into an all-ones / zero mask with one v_bfe_i32.
+__device__ __forceinline__ void stage_decode(uint32_t X0, uint32_t Y0, uint32_t bbx, uint32_t bby, float op,
+                                             uint32_t &flags, uint32_t &bits) {
+    const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
+    flags = (op >= 0.0f ? subtile_mask(X0, Y0, x0, x1, y0, y1) : 0u) | (op <= 0.98f ? 16u : 0u) |
+            ((x0 <= X0 && x1 >= X0 + 16u && y0 <= Y0 && y1 >= Y0 + 16u) ? 32u : 0u);
+    const int lx0 = max((int)x0 - (int)X0, 0), lx1 = min((int)x1 - (int)X0, 16);
+    const int ly0 = max((int)y0 - (int)Y0, 0), ly1 = min((int)y1 - (int)Y0, 16);
+    const uint32_t xm = lx1 > lx0 ? ((1u << (lx1 - lx0)) - 1u) << lx0 : 0u;
+    const uint32_t ym = ly1 > ly0 ? ((1u << (ly1 - ly0)) - 1u) << ly0 : 0u;
+    bits = xm | (ym << 16);
+}
+
 // Lane mask (all ones / zero) of (r < extent), bb = origin | extent << 16.  The compare and the select are kept
 // ADJACENT in one asm block: a v_cndmask reading VCC straight after the v_cmp that wrote it issues in ~2.6
 // cycles on gfx950, any other VCC-reading v_cndmask (stale VCC, or VCC written by s_and_b64) in 14-23
