@@ -96,20 +96,39 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
     const uint32_t c = sorted_count(i, total, N, order, tile_count, &gid);
     uint32_t off = bsum[blockIdx.x] + block_exclusive_scan_256(c, &tot);
     if (i < total) dup_off[gid] = off;
-    if (c == 0) return;
-    const uint32_t bbx = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBX]);
-    const uint32_t bby = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBY]);
-    const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
-    const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE, ty1 = ((bby >> 16) - 1) / FGS_TILE;
-    const uint32_t kbase = ((gid / N) * layers + (layer ? layer[gid] : 0u)) * tiles;
-    for (uint32_t ty = ty0; ty <= ty1; ++ty)
-        for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-            if (off < dcap) {
-                keys[off] = kbase + ty * tiles_x + tx;
-                vals[off] = gid;
+    // Wave-cooperative emission: the wave walks over its Gaussians (uniform loop, parameters broadcast with
+    // v_readlane) and the 64 lanes write each Gaussian's duplicates side by side -- coalesced runs instead of
+    // 64 scattered 4-byte stores per instruction.
+    uint32_t tx0 = 0, ty0 = 0, w = 1, kbase = 0;
+    if (c != 0) {
+        const uint32_t bbx = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBX]);
+        const uint32_t bby = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBY]);
+        tx0 = (bbx & 0xFFFFu) / FGS_TILE;
+        ty0 = (bby & 0xFFFFu) / FGS_TILE;
+        w = ((bbx >> 16) - 1) / FGS_TILE - tx0 + 1;
+        kbase = ((gid / N) * layers + (layer ? layer[gid] : 0u)) * tiles;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long m = __ballot(c != 0);
+    while (m) {
+        const int g = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint32_t cg = __builtin_amdgcn_readlane(c, g), og = __builtin_amdgcn_readlane(off, g);
+        const uint32_t wg = __builtin_amdgcn_readlane(w, g), txg = __builtin_amdgcn_readlane(tx0, g);
+        const uint32_t tyg = __builtin_amdgcn_readlane(ty0, g), kb = __builtin_amdgcn_readlane(kbase, g);
+        const uint32_t idg = __builtin_amdgcn_readlane(gid, g);
+        const float rw = 1.0f / (float)wg;
+        for (uint32_t t = lane; t < cg; t += 64) {
+            uint32_t r = (uint32_t)(((float)t + 0.5f) * rw);  // t / wg (t < 2^20, exact after the fix-up below)
+            if (r * wg > t) --r;
+            if ((r + 1) * wg <= t) ++r;
+            const uint32_t o = og + t;
+            if (o < dcap) {
+                keys[o] = kb + (tyg + r) * tiles_x + txg + (t - r * wg);
+                vals[o] = idg;
             }
-            ++off;
         }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t *__restrict__ counters,
@@ -142,12 +161,16 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, const uint
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) maxc = 1;
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) atomicMax(&maxc, ranges[2 * t + 1] - ranges[2 * t]);
+    uint32_t mymax = 0;
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) mymax = max(mymax, ranges[2 * t + 1] - ranges[2 * t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o, 64));
+    if ((threadIdx.x & 63u) == 0) atomicMax(&maxc, mymax);  // one LDS atomic per wave
     __syncthreads();
-    const uint32_t mx = maxc;
+    const float scale = 63.0f / (float)maxc;  // bucket = 63 - floor(len * 63 / max), in float: scheduling only
     for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
         const uint32_t cnt = ranges[2 * t + 1] - ranges[2 * t];
-        atomicAdd(&hist[63u - (uint32_t)(((unsigned long long)cnt * 63ull) / mx)], 1u);
+        atomicAdd(&hist[63u - min(63u, (uint32_t)((float)cnt * scale))], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, const uint
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
         const uint32_t cnt = ranges[2 * t + 1] - ranges[2 * t];
-        const uint32_t pos = atomicAdd(&hist[63u - (uint32_t)(((unsigned long long)cnt * 63ull) / mx)], 1u);
+        const uint32_t pos = atomicAdd(&hist[63u - min(63u, (uint32_t)((float)cnt * scale))], 1u);
         tile_order[pos] = t;
     }
     if (!seg_off) return;

@@ -7,6 +7,6 @@ for lib in libfgs_hip_prev.so libfgs_hip.so; do
 import json,sys
 d=json.loads(open('gpurun_out/ab32_%s.json'%sys.argv[1]).read().strip().splitlines()[-1])
 st=d['roofline'].get('stage_avg_ms',{})
-print('B32', sys.argv[1], d['ms_per_step'], st.get('composite_fwd'), st.get('composite_bwd'), st.get('project_bwd'))
+print('B32', sys.argv[1], d['ms_per_step'], ' '.join('%s=%.3f' % (k[:9], v) for k, v in st.items()))
 PY
 done; done
