@@ -158,18 +158,27 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, const uint
     __shared__ uint32_t maxc;
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
+    // list lengths are read from global memory once and kept in LDS (when they fit) for the four sweeps below
+    constexpr uint32_t LCAP = 8192;
+    __shared__ uint32_t lcnt[LCAP];
+    const bool cached = ntiles <= LCAP;
+    auto len_of = [&](uint32_t t) -> uint32_t { return cached ? lcnt[t] : ranges[2 * t + 1] - ranges[2 * t]; };
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) maxc = 1;
     __syncthreads();
     uint32_t mymax = 0;
-    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) mymax = max(mymax, ranges[2 * t + 1] - ranges[2 * t]);
+    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
+        const uint2 r = reinterpret_cast<const uint2 *>(ranges)[t];
+        if (cached) lcnt[t] = r.y - r.x;
+        mymax = max(mymax, r.y - r.x);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o, 64));
     if ((threadIdx.x & 63u) == 0) atomicMax(&maxc, mymax);  // one LDS atomic per wave
     __syncthreads();
     const float scale = 63.0f / (float)maxc;  // bucket = 63 - floor(len * 63 / max), in float: scheduling only
     for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
-        const uint32_t cnt = ranges[2 * t + 1] - ranges[2 * t];
+        const uint32_t cnt = len_of(t);
         atomicAdd(&hist[63u - min(63u, (uint32_t)((float)cnt * scale))], 1u);
     }
     __syncthreads();
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, const uint
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
-        const uint32_t cnt = ranges[2 * t + 1] - ranges[2 * t];
+        const uint32_t cnt = len_of(t);
         const uint32_t pos = atomicAdd(&hist[63u - min(63u, (uint32_t)((float)cnt * scale))], 1u);
         tile_order[pos] = t;
     }
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, const uint
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t base = 0; base < ntiles; base += 1024) {
         const uint32_t t = base + threadIdx.x;
-        const uint32_t n = t < ntiles ? (ranges[2 * t + 1] - ranges[2 * t] + FGS_SEG - 1) / FGS_SEG : 0u;
+        const uint32_t n = t < ntiles ? (len_of(t) + FGS_SEG - 1) / FGS_SEG : 0u;
         uint32_t x = n;  // inclusive scan inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
