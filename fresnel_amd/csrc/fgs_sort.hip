@@ -42,13 +42,13 @@ __device__ __forceinline__ SegInfo block_range(uint32_t seg_len, const uint32_t 
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(
     const uint32_t *__restrict__ keys, uint32_t seg_len, const uint32_t *__restrict__ seg_len_dev,
-    uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift, uint32_t *__restrict__ hist) {
+    uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift, uint32_t dmask, uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     const SegInfo r = block_range(seg_len, seg_len_dev, seg_capacity, seg_stride);
     for (uint32_t i = r.begin + threadIdx.x; i < r.end; i += RS_THREADS)
-        atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        atomicAdd(&h[(keys[i] >> shift) & dmask], 1u);
     __syncthreads();
     // layout: hist[(seg*256 + digit) * bps + blk]
     hist[((size_t)blockIdx.y * 256 + threadIdx.x) * gridDim.x + blockIdx.x] = h[threadIdx.x];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t seg_len,
     const uint32_t *__restrict__ seg_len_dev, uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift,
-    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ dtot) {
+    uint32_t dmask, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ dtot) {
     __shared__ uint32_t run_off[256];
     __shared__ uint32_t wcnt[RS_WAVES][256];
     __shared__ uint32_t scan_tmp[256];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const uint32_t digit = (key[it] >> shift) & 255u;
+            const uint32_t digit = (key[it] >> shift) & dmask;
             unsigned long long m = __ballot(valid[it]);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             if (valid[it]) {
-                const uint32_t digit = (key[it] >> shift) & 255u;
+                const uint32_t digit = (key[it] >> shift) & dmask;
                 uint32_t pre = 0;
 #pragma unroll
                 for (int w = 0; w < RS_WAVES; ++w) pre += (w < (int)wave) ? wcnt[w][digit] : 0u;
@@ -172,6 +172,11 @@ uint32_t blocks_per_seg(uint32_t seg_capacity, uint32_t num_segs) {
     return bps;
 }
 
+uint32_t dmask_of(uint32_t p, uint32_t width, uint32_t key_bits) {
+    const uint32_t left = key_bits - p * width;
+    return (1u << (left < width ? left : width)) - 1u;
+}
+
 }  // namespace
 
 size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs) {
@@ -187,6 +192,9 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
     const uint32_t bps = blocks_per_seg(seg_capacity, num_segs);
     uint32_t *dtot = hist + (size_t)num_segs * 256 * bps;
     const uint32_t passes = (key_bits + 7) / 8;
+    // equal digit widths over the passes (13 key bits -> 7 + 6, not 8 + 5): fewer bins per pass means longer
+    // runs of neighbouring destinations in the scatter
+    const uint32_t width = passes ? (key_bits + passes - 1) / passes : 8;
     uint32_t *kin = keys_in, *vin = vals_in, *kout = keys_alt, *vout = vals_alt;
     if (passes == 0) {
         if (vals_final && vals_final != vals_in) {
@@ -204,13 +212,13 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
         uint32_t *vdst = (p == passes - 1 && vals_final) ? vals_final : (vin == vals_in ? vals_alt : vals_in);
         const dim3 grid(bps, num_segs);
         hipLaunchKernelGGL(k_radix_upsweep, grid, dim3(RS_THREADS), 0, st, kin, seg_len, seg_len_dev,
-                           seg_capacity, seg_stride, p * 8, hist);
+                           seg_capacity, seg_stride, p * width, dmask_of(p, width, key_bits), hist);
         FGS_LAUNCH_CHECK("k_radix_upsweep");
         const uint32_t rows = num_segs * 256;
         hipLaunchKernelGGL(k_radix_scan, dim3((rows + 3) / 4), dim3(256), 0, st, hist, dtot, bps, rows);
         FGS_LAUNCH_CHECK("k_radix_scan");
         hipLaunchKernelGGL(k_radix_downsweep, grid, dim3(RS_THREADS), 0, st, kin, vin, kout, vdst, seg_len,
-                           seg_len_dev, seg_capacity, seg_stride, p * 8, hist, dtot);
+                           seg_len_dev, seg_capacity, seg_stride, p * width, dmask_of(p, width, key_bits), hist, dtot);
         FGS_LAUNCH_CHECK("k_radix_downsweep");
         uint32_t *t;
         t = kin; kin = kout; kout = t;
