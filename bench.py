@@ -148,6 +148,7 @@ def main():
                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "fgs_count_pairs")
     st = R.inspect_saved(saved, dims)
     D_local = int(st["counters"][0].item())
+    U_local = int(st["counters"][2].item())  # backward work units = depth segments of FGS_SEG list entries
     pairs_local = int(pairs_dev.item())
     del saved, st
 
@@ -184,8 +185,9 @@ def main():
         # on the stream the kernels run on, over the timed region) ----
         HW = S * S
         alg_bytes = {  # ALGORITHMIC bytes per launch (DESIGN.md "Kernels"), B images per launch
-            "composite_fwd": per_gpu * (40 * HW) + 52 * D_local,
-            "composite_bwd": per_gpu * (36 * HW) + (52 + 48) * D_local,
+            # + 5 floats x 256 pixels of checkpoint per depth segment after a tile's first (written / read once)
+            "composite_fwd": per_gpu * (40 * HW) + 52 * D_local + 5120 * max(U_local - per_gpu * (S // 16) ** 2, 0),
+            "composite_bwd": per_gpu * (36 * HW) + (52 + 48) * D_local + 5120 * max(U_local - per_gpu * (S // 16) ** 2, 0),
         }
         alg_flops = {"composite_fwd": 23.0 * pairs_local, "composite_bwd": 60.0 * pairs_local}
         avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in stage.items()}
@@ -209,6 +211,7 @@ def main():
                     "unit": "TFLOP/s", "frac": round(tfl / FP32_VECTOR_PEAK_TF, 5), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms[dom], 4),
                     "algorithmic_flops_per_launch": int(alg_flops[dom]),
+                    "algorithmic_bytes_fwd": int(alg_bytes["composite_fwd"]), "algorithmic_bytes_bwd": int(alg_bytes["composite_bwd"]),
                     "flop_model": "SURVEY 8d: 23 flop per Gaussian-pixel forward, 60 backward; f32 MFMA peak == f32 vector peak",
                     "hbm": {"achieved_GBs": round(gbs, 2), "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 5),
                             "algorithmic_bytes_per_launch": int(alg_bytes[dom])},
@@ -239,7 +242,7 @@ def main():
                                    f"({per_gpu * world} global), create_dummy_saag distribution, rasterizer fwd+bwd"
                                    + (", + RCCL all-reduce of the 2.7 MB decoder-grad bucket" if world > 1 else ""),
                        "gaussians": N, "resolution": S, "images_per_gpu": per_gpu, "global_batch": per_gpu * world,
-                       "pairs_per_step": int(pairs_all), "tile_duplicates_rank0": D_local,
+                       "pairs_per_step": int(pairs_all), "tile_duplicates_rank0": D_local, "depth_segments_rank0": U_local,
                        "parallelism": f"image-wise dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -587,7 +587,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
     }
     unsigned long long *dbg = nullptr;
     const char *dbg_path = getenv("FGS_DBG_TS");  // scratch instrumentation: per-unit timeline dump
-    const uint32_t ugrid = (uint32_t)p.L.seg_capacity;
+    const uint32_t ugrid = (uint32_t)p.L.seg_capacity;  // surplus blocks exit at once (measured: free)
     if (dbg_path) { (void)hipMalloc(&dbg, (size_t)ugrid * 32); (void)hipMemsetAsync(dbg, 0, (size_t)ugrid * 32, st); }
     hipLaunchKernelGGL(k_composite_bwd, dim3(ugrid), dim3(64), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
                        (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0], p.d.background[1],

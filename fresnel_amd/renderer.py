@@ -274,6 +274,9 @@ def inspect_saved(saved: torch.Tensor, dims) -> dict:
     out["dup_ids"] = view(L.dup_ids, L.dup_capacity, torch.int32)
     out["pix_state"] = view(L.pix_state, Bn * 6 * dims.height * dims.width, torch.float32).view(
         Bn, 6, dims.height, dims.width)
+    if L.seg_capacity:  # depth segments = work units of the backward (non-phase path)
+        out["seg_off"] = view(L.seg_off, Bn * T + 1, torch.int32)
+        out["seg_tile"] = view(L.seg_tile, L.seg_capacity, torch.int32)
     return out
 
 

@@ -251,6 +251,13 @@ def test_full_size_properties_config3_shape():
     assert int((rg[:, 1] - rg[:, 0]).sum()) == D
     # duplicates == sum of per-Gaussian tile counts
     assert int(st1["tile_count"].sum()) == D
+    # depth segments (work units of the backward): ceil(len / FGS_SEG) units per tile, in tile order
+    SEG = 128
+    nseg = (rg[:, 1] - rg[:, 0] + SEG - 1) // SEG
+    U = int(st1["counters"][2])
+    assert U == int(nseg.sum()) and U == int(st1["seg_off"][-1])
+    assert np.array_equal(st1["seg_off"][:-1], np.concatenate([[0], np.cumsum(nseg)[:-1]]))
+    assert np.array_equal(st1["seg_tile"][:U], np.repeat(np.arange(rg.shape[0]), nseg))
     # colour linearity: image(c1 + c2) == image(c1) + image(c2) with black background (pre-clamp safe: colours*0.4)
     c1 = (arrs[3] * 0.4).astype(np.float32)
     c2 = (np.roll(arrs[3], 1, axis=0) * 0.4).astype(np.float32)
@@ -262,6 +269,39 @@ def test_full_size_properties_config3_shape():
     stp = _hip_stages([a[perm][None] for a in arrs], cam, S, S)
     assert np.abs(stp["image"] - st1["image"]).max() <= 1e-5
     assert np.abs(stp["depth"] - st1["depth"]).max() <= 1e-4 * np.abs(st1["depth"]).max()
+
+
+def test_long_lists_many_depth_segments_vs_oracle():
+    """Tiles whose lists span several depth segments (FGS_SEG = 128 entries): the backward restarts
+    every segment from the forward's checkpoint, so gradients must still match the oracle, which
+    walks each list in one piece.  1500 wide Gaussians over a 48x32 frame -> ~1000 entries per tile."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    N, W, H = 1500, 48, 32
+    rs = np.random.RandomState(5)
+    pos = (rs.randn(N, 3) * [0.25, 0.2, 0.3] + [0, 0, -2.0]).astype(np.float32)
+    scale = (0.25 * rs.uniform(0.5, 1.5, (N, 3))).astype(np.float32)
+    quat = rs.randn(N, 4).astype(np.float32)
+    col = rs.rand(N, 3).astype(np.float32)
+    opa = rs.uniform(0.005, 0.05, N).astype(np.float32)  # low opacity: the deep segments still matter
+    opa[::97] = 0.995                                     # a few entries where the alpha clamp binds
+    arrs = [pos, scale, quat, col, opa]
+    cam = Camera(0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+    bg = (0.2, 0.5, 0.7)
+    st = _hip_stages([a[None] for a in arrs], cam, W, H, bg)
+    lens = st["ranges"][0][:, 1] - st["ranges"][0][:, 0]
+    assert lens.max() > 4 * 128, "test must cover tiles with several depth segments"
+    r = _oracle(arrs, ocam, bg)
+    _check_integer_stages(st, 0, r, W, H)
+    gI = rs.standard_normal((3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
+    out = _hip_render(arrs, cam, W, H, bg, grads=(gI, gD))
+    assert rel_to_max(out["image"], r.image) <= TOL
+    assert rel_to_max(out["depth"], r.depth) <= TOL
+    go = orc.render_backward(r, gI, gD)
+    for k in ["positions", "scales", "rotations", "colors", "opacities"]:
+        assert rel_to_max(out["grad_" + k], go[k]) <= TOL, k
 
 
 # ------------------------------------------------------------------------------------------
