@@ -85,9 +85,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     const uint32_t wave = FWD_WAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     constexpr int NS = 4 / FWD_WAVES;  // sub-tiles per wave
-    float A[NS], Cr[NS], Cg[NS], Cb[NS], Dm[NS], Ph[NS];
+    // non-phase path: running transmittance T (w = alpha T; T -= w); phase path: accumulated alpha A
+    float A[NS], T[NS], Cr[NS], Cg[NS], Cb[NS], Dm[NS], Ph[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { A[s] = 0; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; Ph[s] = 0; }
+    for (int s = 0; s < NS; ++s) { A[s] = 0; T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; Ph[s] = 0; }
+    // this lane's column / row bit in the staged pixel bits; with two waves per tile the wave owns one sub-tile row
+    const uint32_t shx = lx, shy = 16u + ly + (NS == 4 ? 0u : 8u * wave);
+    float fx0 = (float)(c.X0 + lx), fx1 = (float)(c.X0 + lx + 8u), fy0 = (float)(c.Y0 + ly + (NS == 4 ? 0u : 8u * wave));
+    asm("" : "+v"(fx0), "+v"(fx1), "+v"(fy0));  // hoisted for good: no v_cvt in the list loop
     for (uint32_t base = c.start; base < c.end; base += FCH) {
         const uint32_t n = min((uint32_t)FCH, c.end - base);
         if (!PHASE && base != c.start && ((base - c.start) % FGS_SEG) == 0) {
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
             for (int s = 0; s < NS; ++s) {
                 const uint32_t sg = wave * NS + s;
                 ck[(0 * 4 + sg) * 64] = Cr[s]; ck[(1 * 4 + sg) * 64] = Cg[s]; ck[(2 * 4 + sg) * 64] = Cb[s];
-                ck[(3 * 4 + sg) * 64] = A[s]; ck[(4 * 4 + sg) * 64] = Dm[s];
+                ck[(3 * 4 + sg) * 64] = 1.0f - T[s]; ck[(4 * 4 + sg) * 64] = Dm[s];
             }
         }
         if (threadIdx.x < n) {
@@ -107,9 +112,15 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
             const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu, by1 = bby >> 16;
-            shm[threadIdx.x] = subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1);
-            q2.z = __uint_as_float(bx0 | ((bx1 - bx0) << 16));
-            q2.w = __uint_as_float(by0 | ((by1 - by0) << 16));
+            if (PHASE) {
+                shm[threadIdx.x] = subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1);
+                q2.z = __uint_as_float(bx0 | ((bx1 - bx0) << 16));
+                q2.w = __uint_as_float(by0 | ((by1 - by0) << 16));
+            } else {
+                uint32_t flags, bits;  // flags: touched sub-tiles (none when the opacity is negative); bits: pixel masks
+                stage_decode(c.X0, c.Y0, bbx, bby, q1.y, flags, bits);
+                q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
+            }
             sh0[threadIdx.x] = q0; sh1[threadIdx.x] = q1; sh2[threadIdx.x] = q2;
             if (PHASE) shp[threadIdx.x] = phase[gid];
         }
@@ -123,6 +134,36 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
                 for (int s = 0; s < NS; ++s) { ck[(wave * NS + s) * 64] = A[s]; ck[(4 + wave * NS + s) * 64] = Ph[s]; }
             }
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
+            if constexpr (!PHASE) {
+                // Non-phase blend.  Most list entries touch only one or two of a wave's sub-tiles, so nothing is
+                // precomputed beyond the row terms; bbox membership = the lane's column / row bit of the staged
+                // pixel bits as an all-ones / zero mask (v_bfe_i32) and-ed onto G (no compare / select).
+                const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
+                if (!(msk & (NS == 4 ? 15u : (3u << (2u * wave))))) continue;
+                const uint32_t bits = __float_as_uint(q2.z);
+#pragma unroll
+                for (int row = 0; row < NS / 2; ++row) {
+                    if (NS == 4 && !((msk >> (2 * row)) & 3u)) continue;
+                    const float dy = (NS == 4 && row) ? fy0 + 8.0f - q0.y : fy0 - q0.y;
+                    const float bdy = q0.w * dy, cyy = (q1.x * dy) * dy;
+                    const uint32_t my = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u * row, 1);
+#pragma unroll
+                    for (int col = 0; col < 2; ++col) {
+                        const int s = 2 * row + col;  // index into this wave's state
+                        const uint32_t sg = wave * NS + s;
+                        if (!((msk >> sg) & 1u)) continue;  // scalar branch: sub-tile not touched
+                        const float dx = (col ? fx1 : fx0) - q0.x;
+                        const float t = q0.z * dx + bdy;
+                        const uint32_t mk = my & (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u * col, 1);
+                        const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(t * dx + cyy)) & mk);
+                        const float alpha = fminf(G * q1.y, 0.99f);  // opacity >= 0 here: no lower clamp needed
+                        const float w = alpha * T[s];
+                        Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
+                        T[s] -= w;
+                    }
+                }
+                continue;
+            }
             const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);  // origin | extent << 16
             const float ph = PHASE ? shp[j] : 0.0f;
@@ -152,6 +193,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
             }
         }
         __syncthreads();
+    }
+    if constexpr (!PHASE) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) A[s] = 1.0f - T[s];
     }
     const size_t HW = (size_t)W * H;
 #pragma unroll
