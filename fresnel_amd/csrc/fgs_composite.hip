@@ -595,7 +595,10 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     float *ckpt = p.d.use_phase ? reinterpret_cast<float *>(saved + p.L.phase_ckpt) : nullptr;
     const uint32_t *seg_off = reinterpret_cast<const uint32_t *>(saved + p.L.seg_off);
     float *seg_ckpt = reinterpret_cast<float *>(saved + p.L.seg_ckpt);
-    const int fw = env_int("FGS_FWD_WAVES", 2);  // waves per tile: 2 measured fastest (A/B in one process)
+    // waves per tile: two halve the serial length of the longest lists (8 images: 0.65 vs 0.77 ms); with enough
+    // tiles to fill the chip several times over one wave per tile wins because the per-record LDS reads are then
+    // amortised over four sub-tile passes (32 images: 2.26 vs 2.61 ms).  FGS_FWD_WAVES overrides (A/B harness).
+    const int fw = env_int("FGS_FWD_WAVES", grid >= 24576u ? 1 : 2);
 #define FGS_FWD_LAUNCH(PH, FW)                                                                                \
     hipLaunchKernelGGL((k_composite_fwd<PH, FW>), dim3(grid), dim3(64 * FW), 0, st, (uint32_t)p.tiles,       \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
