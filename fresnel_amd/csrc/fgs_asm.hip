@@ -175,6 +175,7 @@ __global__ __launch_bounds__(64) void k_asm_splat(
     float2 *__restrict__ dw) {
     __shared__ float4 sh0[ACH], sh1[ACH], sh2[ACH], sh3[ACH];
     __shared__ uint32_t shm[ACH], she[ACH];
+    __shared__ __attribute__((aligned(16))) float red[BWD ? 13 : 1][80];  // wave_sum_transposed scratch (backward)
     const uint32_t key = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (b*P + p)*T + t
     const uint32_t bp = key / tiles, t = key - bp * tiles;
     const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
@@ -269,22 +270,13 @@ __global__ __launch_bounds__(64) void k_asm_splat(
                 }
             }
             if (BWD) {
-                wave_sum12_lane63(v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_cc[0], v_cc[1], v_cc[2], v_cs[0], v_cs[1],
-                                  v_cs[2]);
-                if (WAVE) {
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) v_dep += __shfl_xor(v_dep, o, 64);
-                }
-                if (lane == 63) {
-                    const uint32_t e = she[j];
-                    if (e < dcap) {
-                        float4 *dst = reinterpret_cast<float4 *>(grad_rows + (size_t)e * (WAVE ? 16 : FGS_GROW_FLOATS));
-                        dst[0] = make_float4(v_u, v_v, v_ca, v_cbc);
-                        dst[1] = make_float4(v_cd, v_op, v_cc[0], v_cc[1]);
-                        dst[2] = make_float4(v_cc[2], v_cs[0], v_cs[1], v_cs[2]);
-                        if (WAVE) dst[3] = make_float4(v_dep, 0.0f, 0.0f, 0.0f);
-                    }
-                }
+                constexpr int NV = WAVE ? 13 : 12;
+                float vals[NV] = {v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_cc[0], v_cc[1], v_cc[2], v_cs[0], v_cs[1], v_cs[2]};
+                if (WAVE) vals[NV - 1] = v_dep;
+                const float tot = wave_sum_transposed<NV>(red, vals, lane);
+                const uint32_t e = she[j];
+                if ((lane & 3u) == 3u && lane < 4u * NV && e < dcap)
+                    grad_rows[(size_t)e * (WAVE ? 16 : FGS_GROW_FLOATS) + (lane >> 2)] = tot;
             }
         }
         __syncthreads();

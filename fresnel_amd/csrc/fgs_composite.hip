@@ -359,30 +359,15 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             else if ((msk & 31u) == 31u) passes(std::false_type{}, std::true_type{}, std::false_type{});
             else if (msk & 16u) passes(std::false_type{}, std::false_type{}, std::false_type{});
             else passes(std::true_type{}, std::false_type{}, std::false_type{});
-            // ---- reduce the ten sums over the 64 lanes ----
-            // Through LDS, transposed: every lane parks its ten partial sums ([value][16-lane part][16 + pad]),
-            // then lane 4 k + p adds the 16 partials of part p of value k (four ds_read_b128, 15 adds), two DPP
-            // steps fold the four parts, and lanes 3, 7, .., 39 store the ten totals of this duplicate straight
-            // into its gradient row.  ~20 VALU-cycles-equivalents of plain adds instead of 20 DPP adds at 4.3
-            // cycles each; LDS instructions of one wave execute in order, so no barrier is needed.
+            // ---- reduce the ten sums over the 64 lanes (wave_sum_transposed, fgs_wave.h) and store them straight
+            // into this duplicate's gradient row: no atomics, fixed order, bitwise reproducible ----
             {
-                float *wp = &red[0][(lane >> 4) * 20u + (lane & 15u)];
-                wp[0 * 80] = v_mx; wp[1 * 80] = v_my; wp[2 * 80] = v_ca; wp[3 * 80] = v_cbc; wp[4 * 80] = v_cd;
-                wp[5 * 80] = v_op; wp[6 * 80] = v_r; wp[7 * 80] = v_g; wp[8 * 80] = v_b; wp[9 * 80] = v_d;
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 40u) {
-                    const uint32_t kk = lane >> 2;
-                    const float4 *src = reinterpret_cast<const float4 *>(&red[kk][(lane & 3u) * 20u]);
-                    const float4 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
-                    float tot = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
-                                (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-                    quad_sum1(tot);
-                    const uint32_t e = she[j];
-                    // dL/dconic = K * (sums in exp2 units); the other seven sums are already final
-                    const float scl = (kk >= 2u && kk <= 4u) ? NEG_HALF_LOG2E : 1.0f;
-                    if ((lane & 3u) == 3u && e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + kk] = tot * scl;
-                }
-                __builtin_amdgcn_wave_barrier();
+                const float vals[10] = {v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d};
+                const float tot = wave_sum_transposed<10>(red, vals, lane);
+                const uint32_t kk = lane >> 2, e = she[j];
+                // dL/dconic = K * (sums in exp2 units); the other seven sums are already final
+                const float scl = (kk >= 2u && kk <= 4u) ? NEG_HALF_LOG2E : 1.0f;
+                if ((lane & 3u) == 3u && lane < 40u && e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + kk] = tot * scl;
             }
         }
         __syncthreads();
@@ -416,6 +401,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
     __shared__ float shp[CH];
     __shared__ uint32_t she[CH];
     __shared__ float2 st[PCK][4][64];
+    __shared__ __attribute__((aligned(16))) float red[11][80];  // wave_sum_transposed scratch
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
@@ -559,15 +545,11 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
                     v_u -= dm * (2.0f * ca * dx + cbc * dy);
                     v_v -= dm * (cbc * dx + 2.0f * cd * dy);
                 }
-                wave_sum11_lane63(v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d, v_ph);
-                if (lane == 63) {
+                {
+                    const float vals[11] = {v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d, v_ph};
+                    const float tot = wave_sum_transposed<11>(red, vals, lane);
                     const uint32_t e = she[j];
-                    if (e < dcap) {
-                        float4 *dst = reinterpret_cast<float4 *>(grad_rows + (size_t)e * FGS_GROW_FLOATS);
-                        dst[0] = make_float4(v_u, v_v, v_ca, v_cbc);
-                        dst[1] = make_float4(v_cd, v_op, v_r, v_g);
-                        dst[2] = make_float4(v_b, v_d, v_ph, 0.0f);
-                    }
+                    if ((lane & 3u) == 3u && lane < 44u && e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + (lane >> 2)] = tot;
                 }
             }
         }

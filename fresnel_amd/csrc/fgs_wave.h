@@ -70,18 +70,9 @@ __device__ __forceinline__ void stage_decode(uint32_t X0, uint32_t Y0, uint32_t 
     bits = xm | (ym << 16);
 }
 
-// Lane mask (all ones / zero) of (r < extent), bb = origin | extent << 16.  The compare and the select are kept
-// ADJACENT in one asm block: a v_cndmask reading VCC straight after the v_cmp that wrote it issues in ~2.6
-// cycles on gfx950, any other VCC-reading v_cndmask (stale VCC, or VCC written by s_and_b64) in 14-23
-// (scratch/ubench/valu3.hip, valu4.hip).
-__device__ __forceinline__ uint32_t in_mask(uint32_t r, uint32_t bb) {
-    uint32_t m;
-    asm("v_cmp_lt_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:WORD_1\n\tv_cndmask_b32 %0, 0, -1, vcc"
-        : "=v"(m) : "v"(r), "v"(bb) : "vcc");
-    return m;
-}
-
-// (x <= lim) ? v : 0 with the same adjacent compare/select pairing.
+// (x <= lim) ? v : 0.  The compare and the select are kept ADJACENT in one asm block: a v_cndmask reading VCC
+// straight after the v_cmp that wrote it issues in ~2.6 cycles on gfx950, any other VCC-reading v_cndmask in
+// 14-23 (scratch/ubench/valu3.hip, valu4.hip).
 __device__ __forceinline__ float select_le(float x, float lim, float v) {
     float o;
     asm("v_cmp_le_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(o) : "v"(x), "v"(lim), "v"(v) : "vcc");
@@ -94,13 +85,28 @@ __device__ __forceinline__ void quad_sum1(float &a) {
                  "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n" : "+v"(a));
 }
 
-// Quad sums of ten values: after row_shr:1 and row_shr:2 every lane with (lane & 3) == 3 holds the
-// sum over its quad.  20 VALU instructions; the remaining 16-way sum is finished through LDS by
-// the caller (see k_composite_bwd).
-__device__ __forceinline__ void quad_sum10(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
-                                           float &a6, float &a7, float &a8, float &a9) {
-    asm volatile("s_nop 1\n" FGS_DPP10("row_shr:1 row_mask:0xf bank_mask:0xf")
-                 FGS_DPP10("row_shr:2 row_mask:0xf bank_mask:0xf") "s_nop 1\n"
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
-                   "+v"(a9));
+// Sum NV per-lane values over the 64 lanes of a wave through LDS, transposed (NV <= 16):
+//   every lane parks its NV partial sums in red[value][16-lane part][16 + 4 pad]; lane 4 k + p then adds the 16
+//   partials of part p of value k (four ds_read_b128, 15 adds) and two DPP steps fold the four parts.
+// Returns, in lanes with (lane & 3) == 3 and lane < 4 NV, the total of value lane >> 2 (other lanes: junk).
+// Cost ~10 LDS stores + 15 plain adds + 2 DPP adds per call, against NV x 6 DPP adds (4.3 issue cycles each on
+// gfx950) for a full DPP tree.  One wave's LDS instructions execute in order, so no barrier is needed; `red` is
+// private to the calling wave.
+template <int NV>
+__device__ __forceinline__ float wave_sum_transposed(float (*red)[80], const float (&v)[NV], uint32_t lane) {
+    static_assert(NV <= 16, "four lanes per value");
+    float *wp = &red[0][(lane >> 4) * 20u + (lane & 15u)];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) wp[k * 80] = v[k];
+    __builtin_amdgcn_wave_barrier();
+    float tot = 0.0f;
+    if (lane < 4u * NV) {
+        const float4 *src = reinterpret_cast<const float4 *>(&red[lane >> 2][(lane & 3u) * 20u]);
+        const float4 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
+        tot = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+              (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+        quad_sum1(tot);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return tot;
 }
