@@ -122,7 +122,8 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers) {
     p->s_vals1 = o; o = align256(o + nsort * 4);
     p->s_hist = o; o = align256(o + hist);
     p->s_bsum = o; o = align256(o + nblk * 4);
-    p->s_grows = o; o = align256(o + dcap * FGS_GROW_FLOATS * 4);
+    // gradient rows: one per duplicate; four (one per sub-tile wave) on the phase path
+    p->s_grows = o; o = align256(o + dcap * FGS_GROW_FLOATS * 4 * (d->use_phase ? 4 : 1));
     p->s_total = o;
     return FGS_OK;
 }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     float *__restrict__ pix_state, float *__restrict__ phase_ckpt, float *__restrict__ out_rgb,
     float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off, float *__restrict__ seg_ckpt) {
     constexpr int FCH = 64 * FWD_WAVES;  // records per LDS chunk (one per thread)
-    static_assert(FGS_SEG % FCH == 0, "segment boundaries must fall on chunk boundaries");
+    static_assert(PHASE || FGS_SEG % FCH == 0, "segment boundaries must fall on chunk boundaries");
     __shared__ float4 sh0[FCH], sh1[FCH], sh2[FCH];
     __shared__ float shp[FCH];
     __shared__ uint32_t shm[FCH];
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
 // entries; this kernel walks the list in REVERSE sub-chunks, re-runs the forward inside each
 // sub-chunk from its checkpoint (parking (A_{i-1}, Phi_{i-1}) per entry in LDS), then sweeps
 // the sub-chunk back-to-front with the per-pixel adjoints Abar (init -gI.bg) and Phibar.
-__global__ __launch_bounds__(64) void k_composite_bwd_phase(
+__global__ __launch_bounds__(256) void k_composite_bwd_phase(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
     uint32_t dcap, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
@@ -401,28 +401,34 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
     __shared__ float shp[CH];
     __shared__ uint32_t she[CH];
     __shared__ float2 st[PCK][4][64];
-    __shared__ __attribute__((aligned(16))) float red[11][80];  // wave_sum_transposed scratch
+    __shared__ __attribute__((aligned(16))) float red4[4][11][80];  // wave_sum_transposed scratch, one per wave
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
-    const uint32_t lane = threadIdx.x;
+    // FOUR waves per tile, wave w owns the 8x8 sub-tile w and writes its OWN gradient row per list entry
+    // (row 4 e + w; k_project_bwd sums four rows per duplicate): the recurrence is a long serial chain per
+    // pixel (cos / sin / divide per entry, forward re-run + reverse sweep), so this path is latency-bound and
+    // four independent waves per tile cut the critical path ~4x without any cross-wave reduction.
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const size_t HW = (size_t)W * H;
-    float gr[4], gg[4], gb[4], gd[4], Abar[4], Pbar[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
-        gr[s] = gg[s] = gb[s] = gd[s] = 0.0f;
-        Abar[s] = 0.0f; Pbar[s] = 0.0f;
+    const uint32_t sx = c.X0 + 8u * (wave & 1u), sy = c.Y0 + 8u * (wave >> 1);
+    const uint32_t px = sx + lx, py = sy + ly;
+    float (*red)[80] = red4[wave];
+    float gr, gg, gb, gd, Abar, Pbar;
+    {
+        gr = gg = gb = gd = 0.0f;
+        Abar = 0.0f; Pbar = 0.0f;
         if (px < W && py < H) {
             const size_t o = (size_t)py * W + px;
             const float *ps = pix_state + (size_t)c.b * 6 * HW + o;
             const float Tf = 1.0f - ps[3 * HW];
             const float pr = ps[0] + Tf * bg0, pg = ps[HW] + Tf * bg1, pb = ps[2 * HW] + Tf * bg2;
             const float *gi = g_rgb + (size_t)c.b * 3 * HW + o;
-            gr[s] = (pr >= 0.0f && pr <= 1.0f) ? gi[0] : 0.0f;
-            gg[s] = (pg >= 0.0f && pg <= 1.0f) ? gi[HW] : 0.0f;
-            gb[s] = (pb >= 0.0f && pb <= 1.0f) ? gi[2 * HW] : 0.0f;
-            gd[s] = g_depth[(size_t)c.b * HW + o];
-            Abar[s] = -(gr[s] * bg0 + gg[s] * bg1 + gb[s] * bg2);  // d/dA of (1 - A) * bg
+            gr = (pr >= 0.0f && pr <= 1.0f) ? gi[0] : 0.0f;
+            gg = (pg >= 0.0f && pg <= 1.0f) ? gi[HW] : 0.0f;
+            gb = (pb >= 0.0f && pb <= 1.0f) ? gi[2 * HW] : 0.0f;
+            gd = g_depth[(size_t)c.b * HW + o];
+            Abar = -(gr * bg0 + gg * bg1 + gb * bg2);  // d/dA of (1 - A) * bg
         }
     }
     const uint32_t total = c.end - c.start;
@@ -430,16 +436,17 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
     for (uint32_t ci = nchunks; ci-- > 0;) {
         const uint32_t base = c.start + ci * CH;
         const uint32_t n = min((uint32_t)CH, c.end - base);
-        if (lane < n) {
-            const uint32_t gid = dup_ids[base + lane];
+        if (threadIdx.x < n) {
+            const uint32_t lane_s = threadIdx.x;
+            const uint32_t gid = dup_ids[base + lane_s];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
             const float4 q2 = r[2];
-            sh0[lane] = r[0]; sh1[lane] = r[1]; sh2[lane] = q2;
-            shp[lane] = phase[gid];
+            sh0[lane_s] = r[0]; sh1[lane_s] = r[1]; sh2[lane_s] = q2;
+            shp[lane_s] = phase[gid];
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
             const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
             const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE;
-            she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
+            she[lane_s] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
         }
         __syncthreads();
         const uint32_t nsub = (n + PCK - 1) / PCK;
@@ -448,9 +455,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
             const uint32_t m = min((uint32_t)PCK, n - j0);
             const size_t slot = (size_t)(c.start / PCK) + (ci * CH + j0) / PCK + c.tile;
             const float *ck = phase_ckpt + slot * 512 + lane;
-            float Af[4], Pf[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { Af[s] = ck[s * 64]; Pf[s] = ck[(4 + s) * 64]; }
+            float Af = ck[wave * 64], Pf = ck[(4 + wave) * 64];
             // ---- forward re-run of the sub-chunk: park (A_{i-1}, Phi_{i-1}) ----
             for (uint32_t k = 0; k < m; ++k) {
                 const uint32_t j = j0 + k;
@@ -459,25 +464,21 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
                 const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
                 const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
                 const float ph = shp[j];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const uint32_t sx = c.X0 + 8u * (s & 1), sy = c.Y0 + 8u * (s >> 1);
-                    if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) continue;
-                    st[k][s][lane] = make_float2(Af[s], Pf[s]);
-                    const uint32_t px = sx + lx, py = sy + ly;
+                if (!(x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u)) {
+                    st[k][wave][lane] = make_float2(Af, Pf);
                     const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
                     const float dx = (float)px - q0.x, dy = (float)py - q0.y;
                     const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
                     float alpha = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E) * q1.y;
-                    float pd = fabsf(ph - Pf[s]);
+                    float pd = fabsf(ph - Pf);
                     pd = fminf(pd, 1.0f - pd);
                     alpha *= (1.0f - amp) + amp * __cosf(pd * PHASE_KAPPA);
                     alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
                     alpha = in ? alpha : 0.0f;
-                    const float w = alpha * (1.0f - Af[s]);
-                    Af[s] += w;
-                    const float pc = w / fmaxf(Af[s], 1e-6f);
-                    Pf[s] = in ? (Pf[s] * (1.0f - pc) + ph * pc) : Pf[s];
+                    const float w = alpha * (1.0f - Af);
+                    Af += w;
+                    const float pc = w / fmaxf(Af, 1e-6f);
+                    Pf = in ? (Pf * (1.0f - pc) + ph * pc) : Pf;
                 }
             }
             // ---- reverse sweep of the sub-chunk ----
@@ -491,13 +492,15 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
                 const float ph = shp[j];
                 float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0,
                       v_ph = 0;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const uint32_t sx = c.X0 + 8u * (s & 1), sy = c.Y0 + 8u * (s >> 1);
-                    if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) continue;
-                    const float2 sv = st[k][s][lane];
+                const uint32_t e = she[j];
+                if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) {
+                    // sub-tile not touched: this wave's row of the duplicate is all zeros
+                    if (lane < 12u && e < dcap) grad_rows[((size_t)e * 4 + wave) * FGS_GROW_FLOATS + lane] = 0.0f;
+                    continue;
+                }
+                {
+                    const float2 sv = st[k][wave][lane];
                     const float Aprev = sv.x, Pprev = sv.y;
-                    const uint32_t px = sx + lx, py = sy + ly;
                     const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
                     const float dx = (float)px - q0.x, dy = (float)py - q0.y;
                     const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
@@ -514,20 +517,20 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
                     const float Aic = fmaxf(Ai, 1e-6f);
                     const float rA = __builtin_amdgcn_rcpf(Aic);
                     const float pc = w * rA;
-                    const float Pb = in ? Pbar[s] : 0.0f;
+                    const float Pb = in ? Pbar : 0.0f;
                     v_ph += Pb * pc;
                     const float pcbar = Pb * dphi;
                     // d pc/d w, direct (1/A_i) plus through A_i (-w/A_i^2), equals A_{i-1}/A_i^2: kept in that
                     // cancellation-free form (the two parts cancel to ~0 for a pixel's first contribution)
-                    float Ab = Abar[s];
-                    float wbar = Ab + (gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y);
+                    float Ab = Abar;
+                    float wbar = Ab + (gr * q1.z + gg * q1.w + gb * q2.x + gd * q2.y);
                     if (Ai >= 1e-6f) {
                         wbar += pcbar * Aprev * rA * rA;
                         Ab -= pcbar * w * rA * rA;
                     } else {
                         wbar += pcbar * rA;
                     }
-                    v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
+                    v_r += w * gr; v_g += w * gg; v_b += w * gb; v_d += w * gd;
                     const float abar = wbar * T;
                     Ab -= wbar * alpha;
                     const float rbar = (in && raw >= 0.0f && raw <= 0.99f) ? abar : 0.0f;
@@ -537,8 +540,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
                     const float sg = (dphi > 0.0f) ? 1.0f : ((dphi < 0.0f) ? -1.0f : 0.0f);
                     v_ph += pd0bar * sg;
                     if (in) {
-                        Pbar[s] = Pb * (1.0f - pc) - pd0bar * sg;
-                        Abar[s] = Ab;
+                        Pbar = Pb * (1.0f - pc) - pd0bar * sg;
+                        Abar = Ab;
                     }
                     const float dm = -0.5f * (rbar * op * inter) * G;
                     v_ca += dm * dx * dx; v_cbc += dm * dx * dy; v_cd += dm * dy * dy;
@@ -548,8 +551,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd_phase(
                 {
                     const float vals[11] = {v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d, v_ph};
                     const float tot = wave_sum_transposed<11>(red, vals, lane);
-                    const uint32_t e = she[j];
-                    if ((lane & 3u) == 3u && lane < 44u && e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + (lane >> 2)] = tot;
+                    if ((lane & 3u) == 3u && lane < 44u && e < dcap)
+                        grad_rows[((size_t)e * 4 + wave) * FGS_GROW_FLOATS + (lane >> 2)] = tot;
                 }
             }
         }
@@ -587,7 +590,9 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
                        p.d.background[1], p.d.background[2], p.d.phase_amplitude, tile_order, ranges, dup_ids, \
                        rec, phase, pix, ckpt, out_rgb, out_depth, seg_off, seg_ckpt)
     if (p.d.use_phase) {
-        if (fw == 1) FGS_FWD_LAUNCH(true, 1); else FGS_FWD_LAUNCH(true, 2);
+        // the phase recurrence is latency-bound (serial cos / divide chain per pixel): one wave per sub-tile
+        const int pw = env_int("FGS_FWD_WAVES", 4);
+        if (pw == 1) FGS_FWD_LAUNCH(true, 1); else if (pw == 2) FGS_FWD_LAUNCH(true, 2); else FGS_FWD_LAUNCH(true, 4);
     } else {
         if (fw == 1) FGS_FWD_LAUNCH(false, 1); else FGS_FWD_LAUNCH(false, 2);
     }
@@ -601,7 +606,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
     (void)g_phase;  // dL/dphase travels in the gradient rows and is written by k_project_bwd
     const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
     if (p.d.use_phase) {
-        hipLaunchKernelGGL(k_composite_bwd_phase, dim3(grid), dim3(64), 0, st, (uint32_t)p.tiles,
+        hipLaunchKernelGGL(k_composite_bwd_phase, dim3(grid), dim3(256), 0, st, (uint32_t)p.tiles,
                            (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],
                            p.d.background[1], p.d.background[2], p.d.phase_amplitude, (uint32_t)p.L.dup_capacity,
                            reinterpret_cast<const uint32_t *>(saved + p.L.tile_order),

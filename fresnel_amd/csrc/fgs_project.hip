@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const float *__restrict__ grad_rows, float *__restrict__ g_pos, float *__restrict__ g_scale,
     float *__restrict__ g_quat, float *__restrict__ g_color, float *__restrict__ g_opacity,
     float *__restrict__ g_phase, const float *__restrict__ color, const float *__restrict__ phase,
-    int32_t phase_channels) {
+    int32_t phase_channels, uint32_t rows_per_dup) {
     // four lanes per Gaussian: lane `sub` sums rows sub, sub+4, ... (neighbouring lanes read
     // neighbouring 48-byte rows), then two quad shuffles combine the partial sums in a fixed order
     const int32_t tid = blockIdx.x * 256 + threadIdx.x;
@@ -190,8 +190,9 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     constexpr int ROWF = MODE == 2 ? 16 : FGS_GROW_FLOATS;
     float acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (live) {
-        const uint32_t cnt = tile_count[idx], off = dup_off[idx];
-        for (uint32_t k = sub; k < cnt && off + k < dcap; k += 4) {
+        // rows_per_dup gradient rows per duplicate (4 on the phase path: one per sub-tile wave), contiguous
+        const uint32_t cnt = tile_count[idx] * rows_per_dup, off = dup_off[idx] * rows_per_dup;
+        for (uint32_t k = sub; k < cnt && off + k < dcap * rows_per_dup; k += 4) {
             const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * ROWF);
             const float4 a = r[0], bq = r[1], cq = r[2];
             if (MODE == 2) acc[12] += r[3].x;
@@ -372,7 +373,8 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
                        reinterpret_cast<const uint32_t *>(saved + p.L.order),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                       g_quat, g_color, g_opacity, g_phase, nullptr, nullptr, p.d.use_phase ? 0 : 1);
+                       g_quat, g_color, g_opacity, g_phase, nullptr, nullptr, p.d.use_phase ? 0 : 1,
+                       p.d.use_phase ? 4u : 1u);
     FGS_LAUNCH_CHECK("k_project_bwd");
     return FGS_OK;
 }
@@ -391,7 +393,7 @@ int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float 
                            reinterpret_cast<const uint32_t *>(saved + p.L.order),
                            reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                            reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                           g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels);
+                           g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u);
         FGS_LAUNCH_CHECK("k_wave_project_bwd");
         return FGS_OK;
     }
@@ -401,7 +403,7 @@ int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float 
                        reinterpret_cast<const uint32_t *>(saved + p.L.order),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                       g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels);
+                       g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u);
     FGS_LAUNCH_CHECK("k_asm_project_bwd");
     return FGS_OK;
 }
