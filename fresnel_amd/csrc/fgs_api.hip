@@ -55,7 +55,7 @@ void fgs_stage_end(int stage, hipStream_t st) {
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers) {
+int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     if (!d || !p) { fgs_set_error("null dims"); return FGS_EINVAL; }
     if (d->batch < 1 || d->num_gaussians < 1 || d->width < 1 || d->height < 1 || d->width > 32768 ||
         d->height > 32768 || !(d->max_radius > 0.0f) || (d->num_cameras != 1 && d->num_cameras != d->batch)) {
@@ -98,13 +98,14 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers) {
     if (d->use_phase) o = align256(o + (dcap / FGS_PHASE_CKPT + B * p->tiles + 2) * 8 * 64 * 4);
     p->s_layer = o;
     if (layers > 1) o = align256(o + B * N * 4);
-    const size_t ucap = dcap / FGS_SEG + B * p->tiles;
+    const size_t ucap = dcap / FGS_SEG + B * layers * p->tiles;
     L.seg_off = o; L.seg_tile = o; L.seg_ckpt = o; L.seg_capacity = 0;
-    if (layers == 1 && !d->use_phase) {
+    if (!d->use_phase) {
         L.seg_capacity = ucap;
-        L.seg_off = o; o = align256(o + (B * p->tiles + 1) * 4);
+        L.seg_off = o; o = align256(o + (B * layers * p->tiles + 1) * 4);
         L.seg_tile = o; o = align256(o + ucap * 4);
-        L.seg_ckpt = o; o = align256(o + ucap * 5 * 256 * 4);
+        L.seg_ckpt = o;
+        if (segment_ckpt && layers == 1) o = align256(o + ucap * 5 * 256 * 4);
     }
     L.total_bytes = o;
     L.dup_capacity = dcap;

@@ -99,7 +99,7 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     for (int i = 0; i < 3; ++i) d.background[i] = a->background[i];
     d.use_phase = 0; d.phase_amplitude = 0.0f; d.num_cameras = a->num_cameras;
     p->a = *a;
-    const int rc = fgs_make_plan(&d, &p->base, a->num_planes);
+    const int rc = fgs_make_plan(&d, &p->base, a->num_planes, false);
     if (rc) return rc;
     const size_t B = a->batch, P = a->num_planes, HW = (size_t)a->width * a->height;
     p->HW = HW;
@@ -172,15 +172,27 @@ __global__ __launch_bounds__(64) void k_asm_splat(
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
     const uint32_t *__restrict__ dup_off, float2 *__restrict__ field, float *__restrict__ grad_rows,
-    float2 *__restrict__ dw) {
+    float2 *__restrict__ dw, const uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg_off,
+    const uint32_t *__restrict__ seg_tile) {
     __shared__ float4 sh0[ACH], sh1[ACH], sh2[ACH], sh3[ACH];
     __shared__ uint32_t shm[ACH], she[ACH];
     __shared__ __attribute__((aligned(16))) float red[BWD ? 13 : 1][80];  // wave_sum_transposed scratch (backward)
-    const uint32_t key = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (b*P + p)*T + t
+    // Forward: one block per (image, plane, tile), longest lists first.  Backward: the splat carries no state
+    // along a list, so the work unit is a depth segment of FGS_SEG list entries (unit list of k_tile_order;
+    // the grid is sized from the capacity, surplus blocks leave at once) -- balanced however uneven the lists.
+    uint32_t key, seg = 0;
+    if (BWD) {
+        if (blockIdx.x >= counters[2]) return;
+        key = seg_tile[blockIdx.x];
+        seg = blockIdx.x - seg_off[key];
+    } else {
+        key = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (b*P + p)*T + t
+    }
     const uint32_t bp = key / tiles, t = key - bp * tiles;
     const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
     const uint32_t X0 = tx * FGS_TILE, Y0 = ty * FGS_TILE;
-    const uint32_t start = ranges[2 * key], end = ranges[2 * key + 1];
+    const uint32_t start = ranges[2 * key] + seg * FGS_SEG;
+    const uint32_t end = BWD ? min(ranges[2 * key + 1], start + FGS_SEG) : ranges[2 * key + 1];
     const uint32_t lane = threadIdx.x, lx = lane & 7u, ly = lane >> 3;
     const size_t HW = (size_t)W * H;
     float2 *fbase = field + (size_t)bp * 3 * HW;  // [b][p][c][y][x]
@@ -630,7 +642,7 @@ int make_wave_plan(const FgsWaveDims *w, WavePlan *p) {
     for (int i = 0; i < 3; ++i) d.background[i] = w->background[i];
     d.num_cameras = w->num_cameras;
     p->w = *w;
-    const int rc = fgs_make_plan(&d, &p->base, 1);
+    const int rc = fgs_make_plan(&d, &p->base, 1, false);
     if (rc) return rc;
     const size_t B = w->batch, HW = (size_t)w->width * w->height;
     p->HW = HW;
@@ -697,7 +709,8 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
                        reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, (float2 *)nullptr);
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, (float2 *)nullptr,
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     FGS_LAUNCH_CHECK("k_asm_splat");
     if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
@@ -768,7 +781,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     FGS_LAUNCH_CHECK("k_asm_accumulate_bwd");
     // adjoint of the forward FFT is the unnormalised inverse FFT
     if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
-    const uint32_t grid = (uint32_t)B * P * p.base.tiles;
+    const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units
     float *rows = reinterpret_cast<float *>(sc + p.base.s_grows);
     hipLaunchKernelGGL((k_asm_splat<true, false>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
@@ -777,7 +790,10 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
                        reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows, (float2 *)nullptr);
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows, (float2 *)nullptr,
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.counters),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_tile));
     FGS_LAUNCH_CHECK("k_asm_splat_bwd");
     fgs_stage_end(ST_COMPOSITE_BWD, st);
     fgs_stage_begin(ST_PROJECT_BWD, st);
@@ -824,7 +840,8 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
                        reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, dw);
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, dw,
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     FGS_LAUNCH_CHECK("k_wave_splat");
     hipError_t e = hipMemsetAsync(scal, 0, (size_t)B * 4 * sizeof(float), st);
     if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
@@ -870,14 +887,17 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
     hipLaunchKernelGGL(k_wave_output_bwd2, gpix, dim3(256), 0, st, HW, p.w.background[0], p.w.background[1],
                        p.w.background[2], field, dw, scal, g_rgb, g_depth, gfield, gdw);
     FGS_LAUNCH_CHECK("k_wave_output_bwd2");
-    const uint32_t grid = (uint32_t)B * p.base.tiles;
+    const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units
     hipLaunchKernelGGL((k_asm_splat<true, true>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, 1u, (uint32_t)W, (uint32_t)H, (uint32_t)p.base.L.dup_capacity,
                        p.w.phase_channels, reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
                        reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), gfield, rows, gdw);
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), gfield, rows, gdw,
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.counters),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_tile));
     FGS_LAUNCH_CHECK("k_wave_splat_bwd");
     fgs_stage_end(ST_COMPOSITE_BWD, st);
     fgs_stage_begin(ST_PROJECT_BWD, st);

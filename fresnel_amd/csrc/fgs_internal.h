@@ -31,7 +31,9 @@ struct FgsPlan {
     size_t s_grows;           // float [Dcap][12]: per-duplicate gradient rows (composite bwd -> reduce)
 };
 
-int fgs_make_plan(const FgsDims *dims, FgsPlan *plan, int layers = 1);
+// `segment_ckpt`: reserve the per-segment forward checkpoints of the tile-based compositing path (the splat
+// renderers cut their lists into the same depth segments but carry no state between them)
+int fgs_make_plan(const FgsDims *dims, FgsPlan *plan, int layers = 1, bool segment_ckpt = true);
 void fgs_set_error(const char *fmt, ...);
 
 #define FGS_LAUNCH_CHECK(what)                                              \
