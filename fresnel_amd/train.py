@@ -67,6 +67,13 @@ class TrainingConfig:  # subset of TGD:97-162 that this path uses; same names an
     use_phase_blending: bool = False
     phase_amplitude: float = 0.25
     use_wave_rendering: bool = False  # WaveFieldRenderer (TGD:178, 1891-1897); --use_qsr implies it
+    # spectral / stencil losses after the renderer (TGD:191, 225-229; fresnel_amd/losses.py)
+    wave_equation_weight: float = 0.0
+    wavelength: float = 0.05
+    use_phase_retrieval_loss: bool = False
+    phase_retrieval_weight: float = 0.1
+    use_frequency_loss: bool = False
+    frequency_loss_weight: float = 0.1
     device: str = "cuda" if torch.cuda.is_available() else "cpu"
     log_interval: int = 10
     save_interval: int = 10
@@ -115,8 +122,32 @@ def compute_losses(rendered, target, rendered_depth, target_depth, cfg: Training
                        (target_depth - target_depth.mean()) / td_std)
         d["depth"] = float(dl.detach())
         total = total + cfg.depth_weight * dl
+    if cfg.wave_equation_weight > 0:  # TGD:957-964
+        from .losses import wave_equation_loss
+        we = wave_equation_loss(rendered, cfg.wavelength, pixel_spacing=1.0 / cfg.image_size)
+        d["wave_eq"] = float(we.detach())
+        total = total + cfg.wave_equation_weight * we
+    if cfg.use_phase_retrieval_loss and target_depth is not None:  # TGD:972-983
+        pr = _loss_module("phase", cfg)(rendered, target, target_depth)
+        d["phase_retrieval"] = float(pr.detach())
+        total = total + cfg.phase_retrieval_weight * pr
+    if cfg.use_frequency_loss:  # TGD:990-996
+        fq = _loss_module("freq", cfg)(rendered, target)
+        d["frequency"] = float(fq.detach())
+        total = total + cfg.frequency_loss_weight * fq
     d["total"] = float(total.detach())
     return total, d
+
+
+_LOSS_MODULES: Dict[str, torch.nn.Module] = {}
+
+
+def _loss_module(kind: str, cfg: TrainingConfig):
+    """One PhaseRetrievalLoss / FrequencyDomainLoss per process (TGD:1683-1690 builds them once)."""
+    if kind not in _LOSS_MODULES:
+        from .losses import FrequencyDomainLoss, PhaseRetrievalLoss
+        _LOSS_MODULES[kind] = PhaseRetrievalLoss(wavelength=cfg.wavelength) if kind == "phase" else FrequencyDomainLoss()
+    return _LOSS_MODULES[kind]
 
 
 def default_renderer_factory(cfg: TrainingConfig, device):
@@ -237,6 +268,12 @@ def main(argv=None):
     ap.add_argument("--phase_amplitude", type=float, default=c.phase_amplitude)
     ap.add_argument("--use_wave_rendering", action="store_true", help="WaveFieldRenderer (TGD:1469)")
     ap.add_argument("--use_qsr", action="store_true", help="macro flag: implies --use_wave_rendering (TGD:1550-1553)")
+    ap.add_argument("--wave_equation_weight", type=float, default=c.wave_equation_weight, help="TGD:1483")
+    ap.add_argument("--wavelength", type=float, default=c.wavelength)
+    ap.add_argument("--use_phase_retrieval_loss", action="store_true", help="TGD:1494 (--use_qsr implies it, TGD:1553)")
+    ap.add_argument("--phase_retrieval_weight", type=float, default=c.phase_retrieval_weight)
+    ap.add_argument("--use_frequency_loss", action="store_true", help="TGD:1498")
+    ap.add_argument("--frequency_loss_weight", type=float, default=c.frequency_loss_weight)
     ap.add_argument("--resume", default=None)
     ap.add_argument("--renderer", default="hip", choices=["hip"],
                     help="only the HIP rasterizer ships; there is no CPU fallback")
@@ -255,6 +292,10 @@ def main(argv=None):
                          num_fresnel_zones=a.use_fresnel_zones or a.num_fresnel_zones,
                          use_phase_blending=a.use_phase_blending, phase_amplitude=a.phase_amplitude,
                          use_wave_rendering=a.use_wave_rendering or a.use_qsr,
+                         wave_equation_weight=a.wave_equation_weight, wavelength=a.wavelength,
+                         use_phase_retrieval_loss=a.use_phase_retrieval_loss or a.use_qsr,
+                         phase_retrieval_weight=a.phase_retrieval_weight,
+                         use_frequency_loss=a.use_frequency_loss, frequency_loss_weight=a.frequency_loss_weight,
                          device=f"cuda:{local_rank}", seed=a.seed)
     dp = DPContext(device=torch.device(cfg.device))
     try:

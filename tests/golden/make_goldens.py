@@ -18,6 +18,8 @@ Cases:
   G8 AngularSpectrumPropagator 64x64 known answers
   G9 ASMWaveFieldRenderer N=256 @128x128, scalar and (N,3) phases, grads incl. wavelengths
   G10 WaveFieldRenderer N=256 @128x128, scalar and (N,3) phases, image + depth + grads
+  G11 FFT / stencil losses on a rendered batch: PhaseRetrievalLoss, FrequencyDomainLoss,
+      wave_equation_loss -- values and input gradients on (2,3,48,40) batches
 
 Upstream gradients gI ~ N(0,1), gD ~ N(0,0.01) come from numpy's frozen legacy
 RandomState(seed) so tests can regenerate them bit-exactly; they are stored too.
@@ -389,9 +391,56 @@ def wave_goldens():
         save(rec, f"G10_wave256_128_{tag}.npz")
 
 
+def loss_goldens():
+    """G11.  scripts/training/train_gaussian_decoder.py imports torchvision at module level, which this image
+    lacks, so the module cannot be imported whole.  Only the three definitions under test are taken from the
+    reference file (parsed with `ast`, compiled and executed in a namespace that holds what they use: torch,
+    nn, F, Tuple) -- the reference's own code runs, nothing of it is stored."""
+    import ast
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from typing import Tuple
+    path = os.path.join(REF, "training", "train_gaussian_decoder.py")
+    tree = ast.parse(open(path).read())
+    want = {"PhaseRetrievalLoss", "FrequencyDomainLoss", "wave_equation_loss"}
+    body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in want]
+    assert {n.name for n in body} == want
+    ns = dict(torch=torch, nn=nn, F=F, Tuple=Tuple)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    rs = np.random.RandomState(1111)
+    Bn, H, W = 2, 48, 40
+    rendered = rs.uniform(0.0, 1.0, (Bn, 3, H, W)).astype(np.float32)
+    rendered[0, :, :4, :4] = 0.0  # exercises the 1e-8 amplitude clamp
+    target = rs.uniform(0.0, 1.0, (Bn, 3, H, W)).astype(np.float32)
+    depth = rs.uniform(0.2, 3.0, (Bn, H, W)).astype(np.float32)
+    rec = dict(rendered=rendered, target=target, depth=depth)
+
+    def run(tag, fn, *arrs):
+        ts = [torch.tensor(a, requires_grad=True) for a in arrs]
+        loss = fn(*ts)
+        loss.backward()
+        rec[tag + "_loss"] = np.float32(loss.item())
+        for i, t in enumerate(ts):
+            rec[f"{tag}_grad{i}"] = t.grad.numpy()
+
+    run("phase", lambda r, t, d: ns["PhaseRetrievalLoss"](wavelength=0.05, focal_depth=0.5)(r, t, d), rendered, target, depth)
+    wl = torch.tensor(0.0635)
+    run("phase_wl", lambda r, t, d: ns["PhaseRetrievalLoss"]()(r, t, d.unsqueeze(1), wavelength=wl), rendered, target, depth)
+    run("freq", lambda r, t: ns["FrequencyDomainLoss"](cutoff=0.1, high_weight=2.0)(r, t), rendered, target)
+    run("freq_c25", lambda r, t: ns["FrequencyDomainLoss"](cutoff=0.25, high_weight=0.5)(r, t), rendered, target)
+    run("helm", lambda u: ns["wave_equation_loss"](u, 0.05), rendered)
+    run("helm3", lambda u: ns["wave_equation_loss"](u, 0.0635, pixel_spacing=1.0 / 128.0), depth)
+    for k, v in META.items():
+        rec["meta_" + k] = np.array(v)
+    save(rec, "G11_losses_48x40.npz")
+
+
 if __name__ == "__main__":
     if "--wave-only" in sys.argv:
         wave_goldens()
+    elif "--losses-only" in sys.argv:
+        loss_goldens()
     else:
         main()
         wave_goldens()
+        loss_goldens()
