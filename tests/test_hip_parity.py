@@ -304,6 +304,33 @@ def test_long_lists_many_depth_segments_vs_oracle():
         assert rel_to_max(out["grad_" + k], go[k]) <= TOL, k
 
 
+@pytest.mark.parametrize("use_phase", [False, True])
+def test_forward_waves_per_tile_variants_agree(use_phase, monkeypatch):
+    """The forward picks 1, 2 or 4 waves per tile from the launch size (one wave per tile for >= 24576
+    tiles, four on the phase path).  Every variant walks a pixel's list in the same order with the same
+    arithmetic, so image, depth and -- through the saved state and checkpoints -- all gradients must be
+    bitwise identical whichever is forced (FGS_FWD_WAVES is read at every launch).  On the phase path the
+    compiler contracts the cosine / divide chain differently per instantiation: agreement to 1e-5 of max."""
+    from fresnel_amd.renderer import Camera
+    N, S = 3000, 96
+    arrs = list(synth_aniso(N, 9))
+    cam = Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+    rs = np.random.RandomState(4)
+    gI = rs.standard_normal((3, S, S)).astype(np.float32)
+    gD = (rs.standard_normal((S, S)) * 0.1).astype(np.float32)
+    phases = rs.uniform(0, 1, N).astype(np.float32) if use_phase else None
+    outs = []
+    for fw in (["1", "2", "4"] if use_phase else ["1", "2"]):
+        monkeypatch.setenv("FGS_FWD_WAVES", fw)
+        outs.append(_hip_render(arrs, cam, S, S, (0.1, 0.2, 0.3), phases=phases, use_phase=use_phase, grads=(gI, gD)))
+    for o in outs[1:]:
+        for k in outs[0]:
+            if use_phase:
+                assert rel_to_max(o[k], outs[0][k]) <= 1e-5, k
+            else:
+                assert np.array_equal(outs[0][k], o[k]), k
+
+
 # ------------------------------------------------------------------------------------------
 # Phase-blending path (BASELINE config 4: --use_fresnel_zones 8 --use_phase_blending)
 # ------------------------------------------------------------------------------------------
