@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--images-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--saturation-skip", action="store_true",
+                    help="NOT the default and not the headline: FgsDims.saturation_skip=1 (stop compositing sub-tiles whose "
+                         "accumulated alpha reached 1.0f); value still counts the reference's pairs, see DESIGN.md")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a 1-GPU box")
     args = ap.parse_args()
@@ -112,7 +115,7 @@ def main():
     leaves = [t.requires_grad_(True) for t in (pos, scale, quat, col, opa)]
     cam = R.Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
     cam_t = R.pack_cameras(cam, device)
-    cfg = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, args.workload == "config4", 0.25)
+    cfg = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, args.workload == "config4", 0.25, saturation_skip=args.saturation_skip)
     asm = None
     if args.workload == "config5":
         asm = R.ASMWaveFieldRenderer(S, S).to(device)
@@ -243,7 +246,7 @@ def main():
                                    + (", + RCCL all-reduce of the 2.7 MB decoder-grad bucket" if world > 1 else ""),
                        "gaussians": N, "resolution": S, "images_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "pairs_per_step": int(pairs_all), "tile_duplicates_rank0": D_local, "depth_segments_rank0": U_local,
-                       "parallelism": f"image-wise dp{world}"},
+                       "saturation_skip": bool(args.saturation_skip), "parallelism": f"image-wise dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

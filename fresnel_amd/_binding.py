@@ -29,7 +29,7 @@ class FgsDims(ctypes.Structure):
                 ("width", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("max_radius", ctypes.c_float), ("background", ctypes.c_float * 3),
                 ("use_phase", ctypes.c_int32), ("phase_amplitude", ctypes.c_float),
-                ("num_cameras", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("num_cameras", ctypes.c_int32), ("saturation_skip", ctypes.c_int32)]
 
 
 class FgsSavedLayout(ctypes.Structure):
@@ -115,7 +115,7 @@ def check(rc, what):
 
 
 def make_dims(batch, num_gaussians, width, height, max_radius=64.0, background=(0.0, 0.0, 0.0),
-              use_phase=False, phase_amplitude=0.25, num_cameras=1):
+              use_phase=False, phase_amplitude=0.25, num_cameras=1, saturation_skip=False):
     d = FgsDims()
     d.batch, d.num_gaussians, d.width, d.height = int(batch), int(num_gaussians), int(width), int(height)
     d.max_radius = float(max_radius)
@@ -124,7 +124,7 @@ def make_dims(batch, num_gaussians, width, height, max_radius=64.0, background=(
     d.use_phase = 1 if use_phase else 0
     d.phase_amplitude = float(phase_amplitude)
     d.num_cameras = int(num_cameras)
-    d.reserved = 0
+    d.saturation_skip = 1 if saturation_skip else 0
     return d
 
 

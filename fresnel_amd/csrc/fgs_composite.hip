@@ -26,6 +26,7 @@
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr float FGS_SATURATION_EPS = 2.98023223876953125e-8f;  // 2^-25: 1 - T rounds to 1.0f below it
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;  // exp(-m/2) = exp2(m * this)
 constexpr float PHASE_KAPPA = 2.0f * 3.14159f;              // DR:642 uses the literal 3.14159
 constexpr int CH = 64;                                      // records per LDS chunk (one per lane)
@@ -68,13 +69,13 @@ __device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x,
 // compares, no scalar bit-field decoding).  The scalar unit is shared by the CU's four SIMDs and
 // was the co-bottleneck of the first version (SQ_INSTS_SALU 313 M vs SQ_INSTS_VALU 587 M).
 
-template <bool PHASE, int FWD_WAVES>
+template <bool PHASE, int FWD_WAVES, bool SKIP>
 __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
     float *__restrict__ pix_state, float *__restrict__ phase_ckpt, float *__restrict__ out_rgb,
-    float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off, float *__restrict__ seg_ckpt) {
+    float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off, float *__restrict__ seg_ckpt, float t_eps) {
     constexpr int FCH = 64 * FWD_WAVES;  // records per LDS chunk (one per thread)
     static_assert(PHASE || FGS_SEG % FCH == 0, "segment boundaries must fall on chunk boundaries");
     __shared__ float4 sh0[FCH], sh1[FCH], sh2[FCH];
@@ -91,6 +92,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     for (int s = 0; s < NS; ++s) { A[s] = 0; T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; Ph[s] = 0; }
     // this lane's column / row bit in the staged pixel bits; with two waves per tile the wave owns one sub-tile row
     const uint32_t shx = lx, shy = 16u + ly + (NS == 4 ? 0u : 8u * wave);
+    uint32_t alive = 15u;  // sub-tiles still being composited (saturation_skip)
+    uint32_t live_segments = (c.end - c.start + FGS_SEG - 1) / FGS_SEG;
     float fx0 = (float)(c.X0 + lx), fx1 = (float)(c.X0 + lx + 8u), fy0 = (float)(c.Y0 + ly + (NS == 4 ? 0u : 8u * wave));
     asm("" : "+v"(fx0), "+v"(fx1), "+v"(fy0));  // hoisted for good: no v_cvt in the list loop
     for (uint32_t base = c.start; base < c.end; base += FCH) {
@@ -104,6 +107,20 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
                 ck[(0 * 4 + sg) * 64] = Cr[s]; ck[(1 * 4 + sg) * 64] = Cg[s]; ck[(2 * 4 + sg) * 64] = Cb[s];
                 ck[(3 * 4 + sg) * 64] = 1.0f - T[s]; ck[(4 * 4 + sg) * 64] = Dm[s];
             }
+        }
+        if (SKIP && ((base - c.start) % FGS_SEG) == 0) {
+            // FgsDims.saturation_skip: at every segment boundary, sub-tiles whose transmittance (as the backward
+            // will see it, 1 - A) is below t_eps for all 64 pixels stop being composited; when the whole tile is
+            // saturated the list walk ends and the number of live segments is left for the backward
+            uint32_t aw = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float acc = 1.0f - T[s];
+                asm("" : "+v"(acc));  // keep 1 - (1 - T): what the checkpoint stores, not T itself
+                if (__ballot(1.0f - acc >= t_eps) != 0ull) aw |= 1u << (wave * NS + s);
+            }
+            alive = aw;
+            if (!__syncthreads_or(aw != 0u)) { live_segments = (base - c.start) / FGS_SEG; break; }
         }
         if (threadIdx.x < n) {
             const uint32_t gid = dup_ids[base + threadIdx.x];
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
                 // Non-phase blend.  Most list entries touch only one or two of a wave's sub-tiles, so nothing is
                 // precomputed beyond the row terms; bbox membership = the lane's column / row bit of the staged
                 // pixel bits as an all-ones / zero mask (v_bfe_i32) and-ed onto G (no compare / select).
-                const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
+                const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w)) & (SKIP ? alive : 15u);
                 if (!(msk & (NS == 4 ? 15u : (3u << (2u * wave))))) continue;
                 const uint32_t bits = __float_as_uint(q2.z);
 #pragma unroll
@@ -197,6 +214,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     if constexpr (!PHASE) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) A[s] = 1.0f - T[s];
+        // live-segment count for the backward, parked in the (otherwise unused) checkpoint slot of segment 0
+        if (SKIP && threadIdx.x == 0 && c.end > c.start)
+            reinterpret_cast<uint32_t *>(seg_ckpt + (size_t)seg_off[c.tile] * (5 * 256))[0] = live_segments;
     }
     const size_t HW = (size_t)W * H;
 #pragma unroll
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     const uint32_t *__restrict__ seg_tile, const float *__restrict__ seg_ckpt, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const uint32_t *__restrict__ dup_off,
     const float *__restrict__ pix_state, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
-    float *__restrict__ grad_rows, unsigned long long *__restrict__ dbg_ts) {
+    float *__restrict__ grad_rows, unsigned long long *__restrict__ dbg_ts, float t_eps) {
     const unsigned long long dbg_t0 = dbg_ts ? wall_clock64() : 0ull;
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
@@ -252,6 +272,26 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const size_t HW = (size_t)W * H;
+    if (t_eps > 0.0f) {
+        // FgsDims.saturation_skip: the forward stopped walking this tile's list after `live` segments (count
+        // parked in the checkpoint slot of segment 0); the entries of a dead segment get all-zero gradient rows
+        const uint32_t live = reinterpret_cast<const uint32_t *>(seg_ckpt + (size_t)seg_off[unit_tile] * (5 * 256))[0];
+        if (seg >= live) {
+            for (uint32_t i = c.start + lane; i < c.end; i += 64) {
+                const uint32_t gid = dup_ids[i];
+                const float4 q2 = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS)[2];
+                const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
+                const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
+                const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE;
+                const uint32_t e = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
+                if (e < dcap) {
+                    float4 *row = reinterpret_cast<float4 *>(grad_rows + (size_t)e * FGS_GROW_FLOATS);
+                    row[0] = row[1] = row[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+            return;
+        }
+    }
     // T: running transmittance (w = alpha T, T -= w: one instruction less per pixel than T = 1 - A, A += w)
     // S: T_fin (gI.bg) + sum over not-yet-visited w q
     float gr[4], gg[4], gb[4], gd[4], S[4], T[4];
@@ -283,6 +323,13 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
         }
     }
     const uint32_t shx = lx, shy = 16u + ly;  // this lane's column / row bit in the staged pixel bits
+    uint32_t alive = 0x3Fu;  // sub-tiles still composited (bits 0-3) | the two flag bits
+    if (t_eps > 0.0f) {
+        alive = 0x30u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (__ballot(T[s] >= t_eps) != 0ull) alive |= 1u << s;  // T = 1 - A of the checkpoint, as in the forward
+    }
     float fx0 = (float)(c.X0 + lx), fy0 = (float)(c.Y0 + ly);
     asm("" : "+v"(fx0), "+v"(fy0));  // hoisted for good: no v_cvt in the list loop
     for (uint32_t base = c.start; base < c.end; base += CH) {
@@ -305,7 +352,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-            const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));  // stage_decode flags
+            const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w)) & alive;  // stage_decode flags
             const uint32_t bits = __float_as_uint(q2.z);                                // stage_decode pixel bits
             const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;  // conic pre-multiplied by K = -log2(e)/2
             // terms shared by the sub-tiles of a column / row, formed once per list entry
@@ -580,21 +627,24 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     float *ckpt = p.d.use_phase ? reinterpret_cast<float *>(saved + p.L.phase_ckpt) : nullptr;
     const uint32_t *seg_off = reinterpret_cast<const uint32_t *>(saved + p.L.seg_off);
     float *seg_ckpt = reinterpret_cast<float *>(saved + p.L.seg_ckpt);
+    const float t_eps = (p.d.saturation_skip && !p.d.use_phase) ? FGS_SATURATION_EPS : 0.0f;
     // waves per tile: two halve the serial length of the longest lists (8 images: 0.65 vs 0.77 ms); with enough
     // tiles to fill the chip several times over one wave per tile wins because the per-record LDS reads are then
     // amortised over four sub-tile passes (32 images: 2.26 vs 2.61 ms).  FGS_FWD_WAVES overrides (A/B harness).
     const int fw = env_int("FGS_FWD_WAVES", grid >= 24576u ? 1 : 2);
-#define FGS_FWD_LAUNCH(PH, FW)                                                                                \
-    hipLaunchKernelGGL((k_composite_fwd<PH, FW>), dim3(grid), dim3(64 * FW), 0, st, (uint32_t)p.tiles,       \
+#define FGS_FWD_LAUNCH(PH, FW, SK)                                                                            \
+    hipLaunchKernelGGL((k_composite_fwd<PH, FW, SK>), dim3(grid), dim3(64 * FW), 0, st, (uint32_t)p.tiles,   \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
                        p.d.background[1], p.d.background[2], p.d.phase_amplitude, tile_order, ranges, dup_ids, \
-                       rec, phase, pix, ckpt, out_rgb, out_depth, seg_off, seg_ckpt)
+                       rec, phase, pix, ckpt, out_rgb, out_depth, seg_off, seg_ckpt, t_eps)
     if (p.d.use_phase) {
         // the phase recurrence is latency-bound (serial cos / divide chain per pixel): one wave per sub-tile
         const int pw = env_int("FGS_FWD_WAVES", 4);
-        if (pw == 1) FGS_FWD_LAUNCH(true, 1); else if (pw == 2) FGS_FWD_LAUNCH(true, 2); else FGS_FWD_LAUNCH(true, 4);
+        if (pw == 1) FGS_FWD_LAUNCH(true, 1, false); else if (pw == 2) FGS_FWD_LAUNCH(true, 2, false); else FGS_FWD_LAUNCH(true, 4, false);
+    } else if (t_eps > 0.0f) {  // FgsDims.saturation_skip: separate instantiation, the default path carries no trace of it
+        if (fw == 1) FGS_FWD_LAUNCH(false, 1, true); else FGS_FWD_LAUNCH(false, 2, true);
     } else {
-        if (fw == 1) FGS_FWD_LAUNCH(false, 1); else FGS_FWD_LAUNCH(false, 2);
+        if (fw == 1) FGS_FWD_LAUNCH(false, 1, false); else FGS_FWD_LAUNCH(false, 2, false);
     }
 #undef FGS_FWD_LAUNCH
     FGS_LAUNCH_CHECK("k_composite_fwd");
@@ -636,7 +686,8 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
                        reinterpret_cast<const float *>(saved + p.L.rec),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const float *>(saved + p.L.pix_state), g_rgb, g_depth,
-                       reinterpret_cast<float *>(scratch + p.s_grows), dbg);
+                       reinterpret_cast<float *>(scratch + p.s_grows), dbg,
+                       p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f);
     if (dbg) {
         (void)hipStreamSynchronize(st);
         std::vector<unsigned long long> h((size_t)ugrid * 4);

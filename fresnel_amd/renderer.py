@@ -107,7 +107,8 @@ def _stream_handle():
 class _Cfg:
     """Static (non-tensor) configuration of one renderer call."""
 
-    def __init__(self, width, height, background, max_radius, use_phase, phase_amplitude):
+    def __init__(self, width, height, background, max_radius, use_phase, phase_amplitude, saturation_skip=False):
+        self.saturation_skip = bool(saturation_skip)
         self.width, self.height = int(width), int(height)
         self.background = tuple(float(b) for b in background)
         self.max_radius = float(max_radius)
@@ -133,7 +134,7 @@ def forward_raw(positions, scales, rotations, colors, opacities, phases, cam_ten
     cam_tensor = cam_tensor.contiguous().float()
     dims = B.make_dims(Bn, N, cfg.width, cfg.height, cfg.max_radius, cfg.background,
                        use_phase=ph is not None, phase_amplitude=cfg.phase_amplitude,
-                       num_cameras=cam_tensor.shape[0])
+                       num_cameras=cam_tensor.shape[0], saturation_skip=getattr(cfg, "saturation_skip", False))
     saved_bytes, scratch_bytes = B.workspace_bytes(dims)
     with torch.cuda.device(dev):
         saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
@@ -190,13 +191,15 @@ class GaussianRenderer(torch.autograd.Function):
 
 def render_batch(positions, scales, rotations, colors, opacities, cameras, width, height,
                  background=(0.0, 0.0, 0.0), max_radius=64, phases=None, use_phase_blending=False,
-                 phase_amplitude=0.25, cam_tensor=None):
+                 phase_amplitude=0.25, cam_tensor=None, saturation_skip=False):
     """Functional batched entry point: tensors are (B,N,.); cameras is one Camera (shared by
-    the batch, as in the reference's training loop TGD:1209-1223) or a list of B Cameras."""
+    the batch, as in the reference's training loop TGD:1209-1223) or a list of B Cameras.
+    `saturation_skip` (off by default = the reference's behaviour, every list entry composited): stop
+    compositing 8x8 sub-tiles whose accumulated alpha has reached 1.0f (FgsDims.saturation_skip)."""
     if cam_tensor is None:
         cam_tensor = pack_cameras(cameras, positions.device)
     cfg = _Cfg(width, height, background, max_radius, use_phase_blending and phases is not None,
-               phase_amplitude)
+               phase_amplitude, saturation_skip)
     return GaussianRenderer.apply(positions, scales, rotations, colors, opacities, phases, cam_tensor, cfg)
 
 
@@ -212,8 +215,10 @@ class TileBasedRenderer(nn.Module):
 
     def __init__(self, image_width: int, image_height: int,
                  background: Tuple[float, float, float] = (0.0, 0.0, 0.0), max_radius: int = 64,
-                 use_phase_blending: bool = False, phase_amplitude: float = 0.25):
+                 use_phase_blending: bool = False, phase_amplitude: float = 0.25,
+                 saturation_skip: bool = False):
         super().__init__()
+        self.saturation_skip = saturation_skip  # extension, off by default (see render_batch)
         self.width = image_width
         self.height = image_height
         self.background = torch.tensor(background)  # plain tensor, as in DR:447
@@ -247,7 +252,7 @@ class TileBasedRenderer(nn.Module):
             return (img, depth) if return_depth else img
         img, depth = render_batch(positions, scales, rotations, colors, opacities, camera, self.width,
                                   self.height, bg, self.max_radius, phases if use_phase else None,
-                                  use_phase, self.phase_amplitude)
+                                  use_phase, self.phase_amplitude, saturation_skip=self.saturation_skip)
         if not batched:
             img, depth = img[0], depth[0]
         if return_depth:

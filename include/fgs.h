@@ -46,7 +46,11 @@ typedef struct FgsDims {
     int32_t use_phase;      /* use_phase_blending && phases given        DR:629     */
     float phase_amplitude;  /*                                            DR:442    */
     int32_t num_cameras;    /* 1 (shared, TGD:1209-1223) or B                       */
-    int32_t reserved;
+    int32_t saturation_skip; /* 0 (default): every list entry is composited, like the reference (no early-out).
+                                1: at every FGS_SEG-th list entry, 8x8 sub-tiles whose transmittance has fallen
+                                below 2^-25 for all their pixels (accumulated alpha == 1.0f in fp32) stop being
+                                composited, forward and backward; what is dropped is < 3e-8 * |colour| per pixel.
+                                Blend path only (ignored with use_phase).                                      */
 } FgsDims;
 
 /* Camera record on the DEVICE: FGS_CAMERA_FLOATS floats per camera (Camera, DR:27-52):
