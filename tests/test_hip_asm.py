@@ -170,3 +170,57 @@ def test_wave_batched_ragged_vs_oracle():
         assert rel_to_max(out["depth"][b], r["depth"]) <= TOL
         for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
             assert rel_to_max(out["grad_" + k][b], r["grad_" + k]) <= TOL, (b, k)
+
+
+def _wide(N, seed):
+    rs = np.random.RandomState(seed)
+    pos = (rs.randn(N, 3) * [0.25, 0.2, 0.3] + [0, 0, -2.0]).astype(np.float32)
+    scale = (0.25 * rs.uniform(0.5, 1.5, (N, 3))).astype(np.float32)
+    quat = rs.randn(N, 4).astype(np.float32)
+    col = rs.rand(N, 3).astype(np.float32)
+    opa = rs.uniform(0.05, 0.6, N).astype(np.float32)
+    return pos, scale, quat, col, opa
+
+
+def test_wave_long_lists_many_segments_vs_oracle():
+    """Tile lists of ~1000 entries: the splat backward runs as depth-segment work units (FGS_SEG = 128
+    entries each, no state carried between them) and must still reproduce the oracle's gradients."""
+    from oracle import asm_oracle, fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    W, H, N = 48, 32, 1200
+    bg = (0.2, 0.1, 0.05)
+    arrs = [a[None] for a in _wide(N, 21)]
+    rs = np.random.RandomState(22)
+    phases = (rs.random_sample((1, N)) * 2 * np.pi).astype(np.float32)
+    gI = rs.standard_normal((1, 3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((1, H, W)) * 0.1).astype(np.float32)
+    cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    out = _hip_wave(arrs, phases, cam, W, H, bg, grads=(gI, gD))
+    r = asm_oracle.render_wave(*[a[0] for a in arrs], phases[0], ocam, bg=bg, grad_out=gI[0], grad_depth=gD[0])
+    assert np.abs(out["image"][0] - r["image"]).max() <= TOL
+    assert rel_to_max(out["depth"][0], r["depth"]) <= TOL
+    for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
+        assert rel_to_max(out["grad_" + k][0], r["grad_" + k]) <= TOL, k
+
+
+def test_asm_long_lists_many_segments_vs_oracle():
+    """Same for the angular-spectrum path with only two depth planes (long per-plane lists)."""
+    from oracle import asm_oracle, fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    W, H, N = 48, 32, 1200
+    bg = (0.1, 0.05, 0.2)
+    arrs = [a[None] for a in _wide(N, 31)]
+    rs = np.random.RandomState(32)
+    phases = (rs.random_sample((1, N, 3)) * 2 * np.pi).astype(np.float32)
+    wl = np.array([0.07, 0.052, 0.043], np.float32)
+    gI = rs.standard_normal((1, 3, H, W)).astype(np.float32)
+    cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    kw = dict(num_depth_planes=2, depth_range=(1.0, 3.0), focal_depth=0.7, pixel_pitch=1.0 / 200.0)
+    out = _hip_asm(arrs, phases, wl, cam, W, H, bg, gI=gI, **kw)
+    r = asm_oracle.render(*[a[0] for a in arrs], phases[0], wl, ocam, bg=bg, num_planes=2, depth_range=(1.0, 3.0),
+                          focal_depth=0.7, pixel_pitch=1.0 / 200.0, grad_out=gI[0])
+    assert np.abs(out["image"][0] - r["image"]).max() <= TOL
+    for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
+        assert rel_to_max(out["grad_" + k][0], r["grad_" + k]) <= TOL, k
