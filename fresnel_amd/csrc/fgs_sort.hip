@@ -163,7 +163,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
 }
 
 uint32_t blocks_per_seg(uint32_t seg_capacity, uint32_t num_segs) {
-    // aim at >= 4 blocks per CU over the chip, <= 1024 per segment, >= 1024 keys per block
+    // <= 1024 blocks per segment, >= 1024 keys per block (measured on the 6.9 M-key tile sort: 256 / 512 / 1024 /
+    // 2048 / 4096 blocks -> 0.217 / 0.160 / 0.148 / 0.166 / 0.198 ms)
     uint32_t bps = (seg_capacity + 1023) / 1024;
     uint32_t cap = 1024;
     if (num_segs > 1) cap = 64;
