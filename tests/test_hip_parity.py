@@ -271,6 +271,23 @@ def test_full_size_properties_config3_shape():
     assert np.abs(stp["depth"] - st1["depth"]).max() <= 1e-4 * np.abs(st1["depth"]).max()
 
 
+def test_backward_is_bitwise_reproducible_at_config3_size():
+    """No atomics anywhere on the gradient path (one row per (tile, Gaussian) duplicate, fixed-order sums):
+    two runs of forward + backward on BASELINE config-3's per-GPU shape give bit-identical gradients."""
+    from fresnel_amd.renderer import Camera
+    N, S = 32768, 512
+    arrs = list(synth_saag(N, 123))
+    cam = Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+    rs = np.random.RandomState(6)
+    gI = rs.standard_normal((3, S, S)).astype(np.float32)
+    gD = (rs.standard_normal((S, S)) * 0.1).astype(np.float32)
+    a = _hip_render(arrs, cam, S, S, (0.0, 0.0, 0.0), grads=(gI, gD))
+    b = _hip_render(arrs, cam, S, S, (0.0, 0.0, 0.0), grads=(gI, gD))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+        assert np.isfinite(a[k]).all(), k
+
+
 def test_long_lists_many_depth_segments_vs_oracle():
     """Tiles whose lists span several depth segments (FGS_SEG = 128 entries): the backward restarts
     every segment from the forward's checkpoint, so gradients must still match the oracle, which
