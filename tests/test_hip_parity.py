@@ -271,6 +271,34 @@ def test_full_size_properties_config3_shape():
     assert np.abs(stp["depth"] - st1["depth"]).max() <= 1e-4 * np.abs(st1["depth"]).max()
 
 
+def test_negative_and_saturating_opacities_vs_oracle():
+    """alpha = clamp(G * opacity, 0, 0.99) (DR:646): a negative opacity contributes nothing and gets zero
+    gradients (the kernels drop such records at staging time), opacities above 0.98 take the clamped path,
+    opacity exactly 0 is a live record with a non-zero opacity gradient."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    N, W, H = 600, 80, 64
+    arrs = list(synth_aniso(N, 33, opacity_max=1.2))
+    arrs[4][::5] = -np.abs(arrs[4][::5]) - 0.05  # negative
+    arrs[4][1::7] = 0.0                           # exactly zero
+    arrs[4][2::11] = 0.985                        # between the no-clamp threshold (0.98) and the clamp (0.99)
+    cam = Camera(0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+    bg = (0.4, 0.1, 0.3)
+    r = _oracle(arrs, ocam, bg)
+    rs = np.random.RandomState(34)
+    gI = rs.standard_normal((3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
+    out = _hip_render(arrs, cam, W, H, bg, grads=(gI, gD))
+    go = orc.render_backward(r, gI, gD)
+    assert rel_to_max(out["image"], r.image) <= TOL and rel_to_max(out["depth"], r.depth) <= TOL
+    for k in ["positions", "scales", "rotations", "colors", "opacities"]:
+        assert rel_to_max(out["grad_" + k], go[k]) <= TOL, k
+    neg = arrs[4] < 0
+    for k in ["positions", "scales", "rotations", "colors", "opacities"]:
+        assert not np.any(out["grad_" + k][neg]), k  # exactly zero, as in the reference's clamp backward
+
+
 def test_backward_is_bitwise_reproducible_at_config3_size():
     """No atomics anywhere on the gradient path (one row per (tile, Gaussian) duplicate, fixed-order sums):
     two runs of forward + backward on BASELINE config-3's per-GPU shape give bit-identical gradients."""
