@@ -57,17 +57,18 @@ __device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x,
 }
 
 
-// Forward: TWO waves per tile (wave w owns sub-tiles 2w and 2w+1, i.e. the upper / lower half of
-// the tile).  The forward has no cross-lane reduction, so splitting a tile over two waves is free
-// and halves the serial length of the longest lists -- with 8 images per GPU the launch is
-// otherwise limited by its few longest tiles.  Both waves share the LDS-staged chunk.
-
-// The blend loops keep scalar work to ~2 instructions per sub-tile: each record's bbox is decoded
-// at staging time (per lane, parallel over the chunk) into a 4-bit touched-sub-tile mask
-// (subtile_mask, fgs_wave.h) and re-packed as origin | extent << 16, so the per-pixel membership
-// test is (px - x0) < wx && (py - y0) < wy in unsigned arithmetic (two SDWA subtracts + two SDWA
-// compares, no scalar bit-field decoding).  The scalar unit is shared by the CU's four SIMDs and
-// was the co-bottleneck of the first version (SQ_INSTS_SALU 313 M vs SQ_INSTS_VALU 587 M).
+// Forward.  FWD_WAVES waves per tile: 2 on the blend path (wave w owns sub-tiles 2w and 2w+1, the upper /
+// lower half of the tile: the forward has no cross-lane reduction, so the split is free and halves the serial
+// length of the longest lists), 1 when the launch has enough tiles to fill the chip several times over, 4 on the
+// phase path (latency-bound recurrence).  All waves of a block share the LDS-staged chunk of the list.
+//
+// Per-record work is decided once, at staging time, in parallel over the chunk.  Blend path: stage_decode
+// (fgs_wave.h) leaves a flags word (touched sub-tiles, ...) and 32 pixel bits; in the list loop a lane turns its
+// column / row bit into an all-ones / zero mask with v_bfe_i32 and and-s it onto G -- no per-pixel compare /
+// select (issue costs: DESIGN.md section 4).  Phase path: 4-bit touched-sub-tile mask (subtile_mask) and the bbox
+// re-packed as origin | extent << 16 for unsigned SDWA compares.  The scalar unit is shared by a CU's four
+// SIMDs and was the co-bottleneck of the first version (SQ_INSTS_SALU 313 M vs SQ_INSTS_VALU 587 M).
+// SKIP: FgsDims.saturation_skip (separate instantiation).
 
 template <bool PHASE, int FWD_WAVES, bool SKIP>
 __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
@@ -246,10 +247,13 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
 // based transmittance recovery, no saved per-pair state).
 //
 // Gradient accumulation is atomic-free and deterministic: each lane sums its (up to four)
-// pixels' contributions to the ten per-Gaussian gradients, the wave reduces them with DPP, and
-// lane 63 stores ONE 48-byte row at the duplicate's emission slot (dup_off[gaussian] + index
-// of this tile inside the Gaussian's tile rectangle).  A Gaussian's rows are contiguous and
-// k_project_bwd sums them in a fixed order.
+// pixels' contributions to the ten per-Gaussian sums, the wave adds them up through LDS in a fixed
+// order (wave_sum_transposed, fgs_wave.h) and ten lanes store ONE 48-byte row at the duplicate's
+// emission slot (dup_off[gaussian] + index of this tile inside the Gaussian's tile rectangle).  A
+// Gaussian's rows are contiguous and k_project_bwd sums them in a fixed order.
+//
+// Work unit = (tile, depth segment of FGS_SEG list entries): the unit restarts from the forward's
+// per-pixel checkpoint in front of its segment, so units are independent and of bounded length.
 __global__ __launch_bounds__(64) void k_composite_bwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, uint32_t dcap,
     const uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg_off,
