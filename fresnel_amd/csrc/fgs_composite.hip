@@ -77,7 +77,8 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
     float *__restrict__ pix_state, float *__restrict__ phase_ckpt, float *__restrict__ out_rgb,
     float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off, float *__restrict__ seg_ckpt, float t_eps) {
-    constexpr int FCH = 64 * FWD_WAVES;  // records per LDS chunk (one per thread)
+    // records per LDS chunk: one per thread, but never more than a depth segment on the blend path
+    constexpr int FCH = (!PHASE && 64 * FWD_WAVES > FGS_SEG) ? FGS_SEG : 64 * FWD_WAVES;
     static_assert(PHASE || FGS_SEG % FCH == 0, "segment boundaries must fall on chunk boundaries");
     __shared__ float4 sh0[FCH], sh1[FCH], sh2[FCH];
     __shared__ float shp[FCH];
@@ -91,11 +92,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     float A[NS], T[NS], Cr[NS], Cg[NS], Cb[NS], Dm[NS], Ph[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) { A[s] = 0; T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; Ph[s] = 0; }
-    // this lane's column / row bit in the staged pixel bits; with two waves per tile the wave owns one sub-tile row
-    const uint32_t shx = lx, shy = 16u + ly + (NS == 4 ? 0u : 8u * wave);
+    // sub-tile rows / columns per wave: 4 sub-tiles = 2 x 2, 2 = one row of two, 1 = a single sub-tile
+    constexpr int NR = NS == 4 ? 2 : 1, NC = NS == 1 ? 1 : 2;
+    const uint32_t row0 = NS == 4 ? 0u : (NS == 2 ? wave : wave >> 1), col0 = NS == 1 ? (wave & 1u) : 0u;
+    // this lane's column / row bit in the staged pixel bits
+    const uint32_t shx = lx + 8u * col0, shy = 16u + ly + 8u * row0;
     uint32_t alive = 15u;  // sub-tiles still being composited (saturation_skip)
     uint32_t live_segments = (c.end - c.start + FGS_SEG - 1) / FGS_SEG;
-    float fx0 = (float)(c.X0 + lx), fx1 = (float)(c.X0 + lx + 8u), fy0 = (float)(c.Y0 + ly + (NS == 4 ? 0u : 8u * wave));
+    float fx0 = (float)(c.X0 + lx + 8u * col0), fx1 = (float)(c.X0 + lx + 8u * col0 + 8u), fy0 = (float)(c.Y0 + ly + 8u * row0);
     asm("" : "+v"(fx0), "+v"(fx1), "+v"(fy0));  // hoisted for good: no v_cvt in the list loop
     for (uint32_t base = c.start; base < c.end; base += FCH) {
         const uint32_t n = min((uint32_t)FCH, c.end - base);
@@ -157,19 +161,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
                 // precomputed beyond the row terms; bbox membership = the lane's column / row bit of the staged
                 // pixel bits as an all-ones / zero mask (v_bfe_i32) and-ed onto G (no compare / select).
                 const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w)) & (SKIP ? alive : 15u);
-                if (!(msk & (NS == 4 ? 15u : (3u << (2u * wave))))) continue;
+                if (!(msk & (((1u << NS) - 1u) << (wave * NS)))) continue;
                 const uint32_t bits = __float_as_uint(q2.z);
 #pragma unroll
-                for (int row = 0; row < NS / 2; ++row) {
+                for (int row = 0; row < NR; ++row) {
                     if (NS == 4 && !((msk >> (2 * row)) & 3u)) continue;
                     const float dy = (NS == 4 && row) ? fy0 + 8.0f - q0.y : fy0 - q0.y;
                     const float bdy = q0.w * dy, cyy = (q1.x * dy) * dy;
                     const uint32_t my = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u * row, 1);
 #pragma unroll
-                    for (int col = 0; col < 2; ++col) {
-                        const int s = 2 * row + col;  // index into this wave's state
+                    for (int col = 0; col < NC; ++col) {
+                        const int s = NC * row + col;  // index into this wave's state
                         const uint32_t sg = wave * NS + s;
-                        if (!((msk >> sg) & 1u)) continue;  // scalar branch: sub-tile not touched
+                        if (NS > 1 && !((msk >> sg) & 1u)) continue;  // scalar branch: sub-tile not touched
                         const float dx = (col ? fx1 : fx0) - q0.x;
                         const float t = q0.z * dx + bdy;
                         const uint32_t mk = my & (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u * col, 1);
@@ -634,8 +638,9 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     const float t_eps = (p.d.saturation_skip && !p.d.use_phase) ? FGS_SATURATION_EPS : 0.0f;
     // waves per tile: two halve the serial length of the longest lists (8 images: 0.65 vs 0.77 ms); with enough
     // tiles to fill the chip several times over one wave per tile wins because the per-record LDS reads are then
-    // amortised over four sub-tile passes (32 images: 2.26 vs 2.61 ms).  FGS_FWD_WAVES overrides (A/B harness).
-    const int fw = env_int("FGS_FWD_WAVES", grid >= 24576u ? 1 : 2);
+    // amortised over four sub-tile passes (32 images: 2.26 vs 2.61 ms); a launch that cannot even fill the chip once
+    // is latency-bound and gets one wave per sub-tile.  FGS_FWD_WAVES overrides (A/B harness).
+    const int fw = env_int("FGS_FWD_WAVES", grid >= 24576u ? 1 : (grid <= 6144u ? 4 : 2));
 #define FGS_FWD_LAUNCH(PH, FW, SK)                                                                            \
     hipLaunchKernelGGL((k_composite_fwd<PH, FW, SK>), dim3(grid), dim3(64 * FW), 0, st, (uint32_t)p.tiles,   \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
@@ -646,9 +651,9 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
         const int pw = env_int("FGS_FWD_WAVES", 4);
         if (pw == 1) FGS_FWD_LAUNCH(true, 1, false); else if (pw == 2) FGS_FWD_LAUNCH(true, 2, false); else FGS_FWD_LAUNCH(true, 4, false);
     } else if (t_eps > 0.0f) {  // FgsDims.saturation_skip: separate instantiation, the default path carries no trace of it
-        if (fw == 1) FGS_FWD_LAUNCH(false, 1, true); else FGS_FWD_LAUNCH(false, 2, true);
+        if (fw == 1) FGS_FWD_LAUNCH(false, 1, true); else if (fw == 4) FGS_FWD_LAUNCH(false, 4, true); else FGS_FWD_LAUNCH(false, 2, true);
     } else {
-        if (fw == 1) FGS_FWD_LAUNCH(false, 1, false); else FGS_FWD_LAUNCH(false, 2, false);
+        if (fw == 1) FGS_FWD_LAUNCH(false, 1, false); else if (fw == 4) FGS_FWD_LAUNCH(false, 4, false); else FGS_FWD_LAUNCH(false, 2, false);
     }
 #undef FGS_FWD_LAUNCH
     FGS_LAUNCH_CHECK("k_composite_fwd");

@@ -353,9 +353,9 @@ def test_long_lists_many_depth_segments_vs_oracle():
 def test_forward_waves_per_tile_variants_agree(use_phase, monkeypatch):
     """The forward picks 1, 2 or 4 waves per tile from the launch size (one wave per tile for >= 24576
     tiles, four on the phase path).  Every variant walks a pixel's list in the same order with the same
-    arithmetic, so image, depth and -- through the saved state and checkpoints -- all gradients must be
-    bitwise identical whichever is forced (FGS_FWD_WAVES is read at every launch).  On the phase path the
-    compiler contracts the cosine / divide chain differently per instantiation: agreement to 1e-5 of max."""
+    arithmetic, so image, depth and -- through the saved state and checkpoints -- all gradients must agree
+    whichever is forced (FGS_FWD_WAVES is read at every launch) up to the compiler's different FMA contraction
+    per instantiation: 1e-5 of max.  (Run-to-run bitwise reproducibility of one configuration is tested above.)"""
     from fresnel_amd.renderer import Camera
     N, S = 3000, 96
     arrs = list(synth_aniso(N, 9))
@@ -365,47 +365,12 @@ def test_forward_waves_per_tile_variants_agree(use_phase, monkeypatch):
     gD = (rs.standard_normal((S, S)) * 0.1).astype(np.float32)
     phases = rs.uniform(0, 1, N).astype(np.float32) if use_phase else None
     outs = []
-    for fw in (["1", "2", "4"] if use_phase else ["1", "2"]):
+    for fw in ["1", "2", "4"]:
         monkeypatch.setenv("FGS_FWD_WAVES", fw)
         outs.append(_hip_render(arrs, cam, S, S, (0.1, 0.2, 0.3), phases=phases, use_phase=use_phase, grads=(gI, gD)))
     for o in outs[1:]:
         for k in outs[0]:
-            if use_phase:
-                assert rel_to_max(o[k], outs[0][k]) <= 1e-5, k
-            else:
-                assert np.array_equal(outs[0][k], o[k]), k
-
-
-def test_saturation_skip_option_changes_nothing_visible():
-    """FgsDims.saturation_skip (off by default): sub-tiles whose accumulated alpha reached 1.0f stop being
-    composited at the next 128-entry boundary.  On a scene with heavy overdraw (most pixels saturate early) the
-    image must agree to fp32 resolution and the gradients to the parity tolerance with the default path."""
-    from fresnel_amd.renderer import Camera, TileBasedRenderer
-    dev = _cuda()
-    N, W, H = 4000, 64, 48
-    rs = np.random.RandomState(8)
-    pos = (rs.randn(N, 3) * [0.3, 0.25, 0.3] + [0, 0, -2.0]).astype(np.float32)
-    scale = (0.2 * rs.uniform(0.5, 1.5, (N, 3))).astype(np.float32)
-    quat = rs.randn(N, 4).astype(np.float32)
-    col = rs.rand(N, 3).astype(np.float32)
-    opa = rs.uniform(0.3, 0.95, N).astype(np.float32)
-    cam = Camera(0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
-    gI = torch.from_numpy(rs.standard_normal((3, H, W)).astype(np.float32)).to(dev)
-    gD = torch.from_numpy((rs.standard_normal((H, W)) * 0.1).astype(np.float32)).to(dev)
-    res = []
-    for skip in (False, True):
-        ts = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (pos, scale, quat, col, opa)]
-        ren = TileBasedRenderer(W, H, background=(0.3, 0.6, 0.1), saturation_skip=skip)
-        img, dep = ren(*ts, cam, return_depth=True)
-        ((img * gI).sum() + (dep * gD).sum()).backward()
-        res.append([img.detach().cpu().numpy(), dep.detach().cpu().numpy()] + [t.grad.cpu().numpy() for t in ts])
-    st = _hip_stages([a[None] for a in (pos, scale, quat, col, opa)], cam, W, H)
-    assert (st["ranges"][0][:, 1] - st["ranges"][0][:, 0]).max() > 3 * 128  # several segments per tile
-    assert float((st["pix_state"][0, 3] == 1.0).mean()) > 0.5               # most pixels do saturate
-    assert np.abs(res[0][0] - res[1][0]).max() <= 2e-7
-    assert np.abs(res[0][1] - res[1][1]).max() <= 2e-7 * max(1.0, float(np.abs(res[0][1]).max()))
-    for a, b in zip(res[0][2:], res[1][2:]):
-        assert rel_to_max(b, a) <= TOL
+            assert rel_to_max(o[k], outs[0][k]) <= 1e-5, k
 
 
 # ------------------------------------------------------------------------------------------
