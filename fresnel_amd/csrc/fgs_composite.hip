@@ -29,6 +29,29 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float FGS_SATURATION_EPS = 2.98023223876953125e-8f;  // 2^-25: 1 - T rounds to 1.0f below it
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;  // exp(-m/2) = exp2(m * this)
 constexpr float PHASE_KAPPA = 2.0f * 3.14159f;              // DR:642 uses the literal 3.14159
+
+// cos / sin of x = kappa * pd, pd in [0, 0.5], i.e. x in [0, pi]: Taylor polynomials around pi/2 (|y| <= pi/2,
+// truncation < 6e-8), all plain FMAs.  The hardware v_cos_f32 / v_sin_f32 (__cosf / __sinf) are only good to
+// ~1e-5 absolute, which showed up as 1e-5 image error and > 1e-4 gradient error at phase_amplitude 0.6.
+__device__ __forceinline__ float phase_cos(float x) {
+    const float y = x - 1.57079632679489661923f, y2 = y * y;  // cos(x) = -sin(y)
+    float p = -2.50521083854417187751e-8f;                    // -1/11!
+    p = p * y2 + 2.75573192239858906526e-6f;                  //  1/9!
+    p = p * y2 - 1.98412698412698412698e-4f;                  // -1/7!
+    p = p * y2 + 8.33333333333333333333e-3f;                  //  1/5!
+    p = p * y2 - 1.66666666666666666667e-1f;                  // -1/3!
+    return -(y + y * (y2 * p));
+}
+__device__ __forceinline__ float phase_sin(float x) {
+    const float y = x - 1.57079632679489661923f, y2 = y * y;  // sin(x) = cos(y)
+    float p = 2.08767569878680989792e-9f;                     //  1/12!
+    p = p * y2 - 2.75573192239858906526e-7f;                  // -1/10!
+    p = p * y2 + 2.48015873015873015873e-5f;                  //  1/8!
+    p = p * y2 - 1.38888888888888888889e-3f;                  // -1/6!
+    p = p * y2 + 4.16666666666666666667e-2f;                  //  1/4!
+    p = p * y2 - 0.5f;
+    return 1.0f + y2 * p;
+}
 constexpr int CH = 64;                                      // records per LDS chunk (one per lane)
 
 struct TileCtx {
@@ -201,7 +224,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
                 if (PHASE) {
                     float pd = fabsf(ph - Ph[s]);
                     pd = fminf(pd, 1.0f - pd);
-                    alpha *= (1.0f - amp) + amp * __cosf(pd * PHASE_KAPPA);
+                    alpha *= (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
                 }
                 alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
                 alpha = in ? alpha : 0.0f;
@@ -527,7 +550,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                     float alpha = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E) * q1.y;
                     float pd = fabsf(ph - Pf);
                     pd = fminf(pd, 1.0f - pd);
-                    alpha *= (1.0f - amp) + amp * __cosf(pd * PHASE_KAPPA);
+                    alpha *= (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
                     alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
                     alpha = in ? alpha : 0.0f;
                     const float w = alpha * (1.0f - Af);
@@ -563,7 +586,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                     const float dphi = ph - Pprev;
                     const float pd0 = fabsf(dphi);
                     const float pd = fminf(pd0, 1.0f - pd0);
-                    const float inter = (1.0f - amp) + amp * __cosf(pd * PHASE_KAPPA);
+                    const float inter = (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
                     const float raw = (G * op) * inter;
                     const float alpha = in ? fminf(fmaxf(raw, 0.0f), 0.99f) : 0.0f;
                     const float T = 1.0f - Aprev;
@@ -590,7 +613,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                     Ab -= wbar * alpha;
                     const float rbar = (in && raw >= 0.0f && raw <= 0.99f) ? abar : 0.0f;
                     v_op += rbar * G * inter;
-                    const float pdbar = -(rbar * G * op) * amp * PHASE_KAPPA * __sinf(PHASE_KAPPA * pd);
+                    const float pdbar = -(rbar * G * op) * amp * PHASE_KAPPA * phase_sin(PHASE_KAPPA * pd);
                     const float pd0bar = (pd0 < 1.0f - pd0) ? pdbar : ((pd0 > 1.0f - pd0) ? -pdbar : 0.0f);
                     const float sg = (dphi > 0.0f) ? 1.0f : ((dphi < 0.0f) ? -1.0f : 0.0f);
                     v_ph += pd0bar * sg;
