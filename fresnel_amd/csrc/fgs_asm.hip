@@ -87,7 +87,7 @@ int run_fft(int H, int W, int batch, float2 *data, int dir, void *work, hipStrea
 
 int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     if (!a) { fgs_set_error("null dims"); return FGS_EINVAL; }
-    if (a->num_planes < 2 || a->num_planes > 64 || (a->phase_channels != 1 && a->phase_channels != 3) ||
+    if (a->num_planes < 1 || a->num_planes > 64 || (a->phase_channels != 1 && a->phase_channels != 3) ||
         !(a->pixel_pitch > 0.0f)) {
         fgs_set_error("invalid ASM dims: planes=%d phase_channels=%d pitch=%g", a->num_planes, a->phase_channels,
                       (double)a->pixel_pitch);
@@ -135,6 +135,7 @@ __device__ __forceinline__ float fftfreq(int k, int n, float inv_nd) {
 
 // depth planes: torch.linspace(near, far, P), DR:1106
 __device__ __forceinline__ float plane_depth(int k, int P, float near_, float far_) {
+    if (P == 1) return near_;  // torch.linspace(near, far, 1) = [near]
     const float step = (far_ - near_) / (float)(P - 1);
     return (k < P / 2) ? near_ + step * (float)k : far_ - step * (float)(P - 1 - k);
 }

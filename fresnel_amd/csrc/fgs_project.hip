@@ -355,7 +355,7 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
                        reinterpret_cast<float *>(saved + p.L.rec),
                        reinterpret_cast<uint32_t *>(saved + p.L.depth_key),
                        reinterpret_cast<uint32_t *>(saved + p.L.tile_count),
-                       num_planes > 0 ? reinterpret_cast<uint32_t *>(saved + p.s_layer) : nullptr, num_planes,
+                       num_planes > 1 ? reinterpret_cast<uint32_t *>(saved + p.s_layer) : nullptr, num_planes,  // one plane: layer 0
                        plane_near, plane_far);
     FGS_LAUNCH_CHECK("k_project");
     return FGS_OK;

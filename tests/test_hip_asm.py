@@ -224,3 +224,25 @@ def test_asm_long_lists_many_segments_vs_oracle():
     assert np.abs(out["image"][0] - r["image"]).max() <= TOL
     for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
         assert rel_to_max(out["grad_" + k][0], r["grad_" + k]) <= TOL, k
+
+
+def test_asm_single_depth_plane_vs_oracle():
+    """num_depth_planes = 1: torch.linspace(near, far, 1) = [near] (DR:1106), every Gaussian lands on it."""
+    from oracle import asm_oracle, fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    W, H, N = 64, 40, 150
+    bg = (0.1, 0.05, 0.2)
+    rs = np.random.RandomState(41)
+    arrs = [a[None] for a in synth_aniso(N, 42, opacity_max=0.9, smin=0.03, smax=0.1)]
+    phases = (rs.random_sample((1, N)) * 2 * np.pi).astype(np.float32)
+    wl = np.array([0.0635, 0.05, 0.041], np.float32)
+    gI = rs.standard_normal((1, 3, H, W)).astype(np.float32)
+    cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    kw = dict(num_depth_planes=1, depth_range=(0.4, 2.0), focal_depth=0.9, pixel_pitch=1.0 / 256.0)
+    out = _hip_asm(arrs, phases, wl, cam, W, H, bg, gI=gI, **kw)
+    r = asm_oracle.render(*[a[0] for a in arrs], phases[0], wl, ocam, bg=bg, num_planes=1, depth_range=(0.4, 2.0),
+                          focal_depth=0.9, pixel_pitch=1.0 / 256.0, grad_out=gI[0])
+    assert np.abs(out["image"][0] - r["image"]).max() <= TOL
+    for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
+        assert rel_to_max(out["grad_" + k][0], r["grad_" + k]) <= TOL, k
