@@ -234,19 +234,60 @@ __global__ __launch_bounds__(256) void k_project_bwd(
         if (phase_channels != 3) g_phase[idx] = gph;
     }
     if (depth_key[idx] != 0xFFFFFFFFu) {
-        const float *__restrict__ V = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
-        const float p[3] = {pos[3 * idx], pos[3 * idx + 1], pos[3 * idx + 2]};
-        const float s[3] = {scale[3 * idx], scale[3 * idx + 1], scale[3 * idx + 2]};
+        // Projection adjoint in DOUBLE precision, recomputing the projection from the fp32 inputs.  The kernel is
+        // bound by the gradient-row reads, so this costs nothing measurable, and it keeps the chain through the
+        // regularised 2x2 covariance inverse accurate for needle / disc Gaussians (scale ratios of 100:1 and
+        // more), where an fp32 chain -- this one earlier, and the reference's autograd -- loses all digits.
+        const float *__restrict__ Vf = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
+        double V[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) V[i][j] = Vf[4 * i + j];
+        const double fx = Vf[16], fy = Vf[17];
+        const double p[3] = {pos[3 * idx], pos[3 * idx + 1], pos[3 * idx + 2]};
+        const double s[3] = {scale[3 * idx], scale[3 * idx + 1], scale[3 * idx + 2]};
         const float4 q4 = reinterpret_cast<const float4 *>(quat)[idx];
-        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float fx = V[16], fy = V[17];
-        Proj o;
-        project_one(V, fx, fy, V[18], V[19], p, s, q, o);
-        const float ar = o.a + 1e-4f, dr = o.d + 1e-4f;
-        const float rdet = 1.0f / (ar * dr - o.b * o.c);
-        const float Y[2][2] = {{dr * rdet, -o.b * rdet}, {-o.c * rdet, ar * rdet}};
-        const float GY[2][2] = {{g_conic[0], g_conic[1]}, {g_conic[1], g_conic[2]}};
-        float tmp[2][2], G2[2][2];
+        const double q0[4] = {q4.x, q4.y, q4.z, q4.w};
+        const double xc = V[0][0] * p[0] + V[0][1] * p[1] + V[0][2] * p[2] + V[0][3];
+        const double yc = V[1][0] * p[0] + V[1][1] * p[1] + V[1][2] * p[2] + V[1][3];
+        const double zc = V[2][0] * p[0] + V[2][1] * p[1] + V[2][2] * p[2] + V[2][3];
+        const double nrm = sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
+        const double nn = nrm < 1e-12 ? 1e-12 : nrm;
+        const double w = q0[0] / nn, x = q0[1] / nn, y = q0[2] / nn, z = q0[3] / nn;
+        const double R[3][3] = {{1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * x * z + 2 * w * y},
+                                {2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x},
+                                {2 * x * z - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y}};
+        double Rc[3][3], M[3][3], S[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Rc[i][j] = V[i][0] * R[0][j] + V[i][1] * R[1][j] + V[i][2] * R[2][j];
+                M[i][j] = Rc[i][j] * s[j];
+            }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) S[i][j] = M[i][0] * M[j][0] + M[i][1] * M[j][1] + M[i][2] * M[j][2];
+        const double az = fabs(zc);
+        const double sg = (double)sgnf((float)zc + 1e-8f);  // same sign convention as the fp32 forward
+        const double zs = (az < 0.01 ? 0.01 : az) * sg, z2 = zs * zs, z3 = z2 * zs;
+        const double J[2][3] = {{fx / (-zs), 0.0, fx * xc / z2}, {0.0, fy / zs, fy * yc / z2}};
+        double T[2][3], C2[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) T[i][j] = J[i][0] * S[0][j] + J[i][1] * S[1][j] + J[i][2] * S[2][j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) C2[i][j] = T[i][0] * J[j][0] + T[i][1] * J[j][1] + T[i][2] * J[j][2];
+        const double ar = C2[0][0] + (double)1e-4f, dr = C2[1][1] + (double)1e-4f, cb = C2[0][1], cc = C2[1][0];
+        const double rdet = 1.0 / (ar * dr - cb * cc);
+        const double Y[2][2] = {{dr * rdet, -cb * rdet}, {-cc * rdet, ar * rdet}};
+        const double GY[2][2] = {{g_conic[0], g_conic[1]}, {g_conic[1], g_conic[2]}};
+        double tmp[2][2], G2[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -255,14 +296,13 @@ __global__ __launch_bounds__(256) void k_project_bwd(
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) G2[i][j] = -(tmp[i][0] * Y[j][0] + tmp[i][1] * Y[j][1]);
-        const float J[2][3] = {{o.J00, 0.0f, o.J02}, {0.0f, o.J11, o.J12}};
         // dL/dSigma = J^T G2 J
-        float GS[3][3];
+        double GS[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                float acc = 0.0f;
+                double acc = 0.0;
 #pragma unroll
                 for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
@@ -270,72 +310,69 @@ __global__ __launch_bounds__(256) void k_project_bwd(
                 GS[i][j] = acc;
             }
         // dL/dJ = G2 (J S^T) + G2^T (J S)
-        float JS[2][3], JSt[2][3];
+        double JS[2][3], JSt[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                JS[i][j] = J[i][0] * o.S[0][j] + J[i][1] * o.S[1][j] + J[i][2] * o.S[2][j];
-                JSt[i][j] = J[i][0] * o.S[j][0] + J[i][1] * o.S[j][1] + J[i][2] * o.S[j][2];
+                JS[i][j] = J[i][0] * S[0][j] + J[i][1] * S[1][j] + J[i][2] * S[2][j];
+                JSt[i][j] = J[i][0] * S[j][0] + J[i][1] * S[j][1] + J[i][2] * S[j][2];
             }
-        float GJ[2][3];
+        double GJ[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 GJ[i][j] = (G2[i][0] * JSt[0][j] + G2[i][1] * JSt[1][j]) + (G2[0][i] * JS[0][j] + G2[1][i] * JS[1][j]);
-        float gu = g_mean[0], gv = g_mean[1];
+        double gu = g_mean[0], gv = g_mean[1];
         if (MODE == 0 && phase_channels) {
             // MODE 0 reuses `phase_channels` as a flag: slots 0/1 of the rows hold the first moments
             // M = sum dm' (dx, dy) in exp2 units (k_composite_bwd); dL/d(u,v) = -K conic_sym M, K = -log2(e)/2
-            const float kc = 0.72134752044448170368f, cbc = Y[0][1] + Y[1][0];
-            gu = kc * (2.0f * Y[0][0] * g_mean[0] + cbc * g_mean[1]);
-            gv = kc * (cbc * g_mean[0] + 2.0f * Y[1][1] * g_mean[1]);
+            const double kc = 0.72134752044448170368, cbc = Y[0][1] + Y[1][0];
+            gu = kc * (2.0 * Y[0][0] * (double)g_mean[0] + cbc * (double)g_mean[1]);
+            gv = kc * (cbc * (double)g_mean[0] + 2.0 * Y[1][1] * (double)g_mean[1]);
         }
-        const float zs = o.zs, z2 = o.z2, z3 = o.z2 * o.zs;
-        const float gxc = GJ[0][2] * fx / z2 + gu * (-fx / zs);
-        const float gyc = GJ[1][2] * fy / z2 + gv * (fy / zs);
-        const float gzs = GJ[0][0] * fx / z2 + GJ[0][2] * (-2.0f * fx * o.xc / z3) + GJ[1][1] * (-fy / z2) +
-                          GJ[1][2] * (-2.0f * fy * o.yc / z3) + gu * (fx * o.xc / z2) + gv * (-fy * o.yc / z2);
-        const float dzs = (fabsf(o.zc) >= 0.01f ? sgnf(o.zc) : 0.0f) * sgnf(o.zc + 1e-8f);
-        const float gpc[3] = {gxc, gyc, gzs * dzs - g_depth};
+        const double gxc = GJ[0][2] * fx / z2 + gu * (-fx / zs);
+        const double gyc = GJ[1][2] * fy / z2 + gv * (fy / zs);
+        const double gzs = GJ[0][0] * fx / z2 + GJ[0][2] * (-2.0 * fx * xc / z3) + GJ[1][1] * (-fy / z2) +
+                           GJ[1][2] * (-2.0 * fy * yc / z3) + gu * (fx * xc / z2) + gv * (-fy * yc / z2);
+        const double dzs = (az >= 0.01 ? (double)sgnf((float)zc) : 0.0) * sg;
+        const double gpc[3] = {gxc, gyc, gzs * dzs - (double)g_depth};
 #pragma unroll
-        for (int j = 0; j < 3; ++j) gp[j] = V[j] * gpc[0] + V[4 + j] * gpc[1] + V[8 + j] * gpc[2];
+        for (int j = 0; j < 3; ++j) gp[j] = (float)(V[0][j] * gpc[0] + V[1][j] * gpc[1] + V[2][j] * gpc[2]);
         // Sigma = M M^T -> dM = (GS + GS^T) M ; M = Rc diag(s)
-        float GRc[3][3];
+        double GRc[3][3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float acc = 0.0f;
+            double acc = 0.0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                float gm = 0.0f;
+                double gm = 0.0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) gm += (GS[i][k] + GS[k][i]) * o.M[k][j];
-                acc += gm * o.Rc[i][j];
+                for (int k = 0; k < 3; ++k) gm += (GS[i][k] + GS[k][i]) * M[k][j];
+                acc += gm * Rc[i][j];
                 GRc[i][j] = gm * s[j];
             }
-            gs[j] = acc;
+            gs[j] = (float)acc;
         }
-        float GR[3][3];
+        double GR[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) GR[i][j] = V[i] * GRc[0][j] + V[4 + i] * GRc[1][j] + V[8 + i] * GRc[2][j];
-        const float w = o.w, x = o.x, y = o.y, z = o.z;
-        float gh[4];
+            for (int j = 0; j < 3; ++j) GR[i][j] = V[0][i] * GRc[0][j] + V[1][i] * GRc[1][j] + V[2][i] * GRc[2][j];
+        double gh[4];
         gh[0] = -2 * z * GR[0][1] + 2 * y * GR[0][2] + 2 * z * GR[1][0] - 2 * x * GR[1][2] - 2 * y * GR[2][0] + 2 * x * GR[2][1];
         gh[1] = 2 * y * GR[0][1] + 2 * z * GR[0][2] + 2 * y * GR[1][0] - 4 * x * GR[1][1] - 2 * w * GR[1][2] + 2 * z * GR[2][0] + 2 * w * GR[2][1] - 4 * x * GR[2][2];
         gh[2] = -4 * y * GR[0][0] + 2 * x * GR[0][1] + 2 * w * GR[0][2] + 2 * x * GR[1][0] + 2 * z * GR[1][2] - 2 * w * GR[2][0] + 2 * z * GR[2][1] - 4 * y * GR[2][2];
         gh[3] = -4 * z * GR[0][0] - 2 * w * GR[0][1] + 2 * x * GR[0][2] + 2 * w * GR[1][0] - 4 * z * GR[1][1] + 2 * y * GR[1][2] + 2 * x * GR[2][0] + 2 * y * GR[2][1];
-        const float qh[4] = {w, x, y, z};
-        if (o.nrm >= 1e-12f) {
-            const float dot = qh[0] * gh[0] + qh[1] * gh[1] + qh[2] * gh[2] + qh[3] * gh[3];
-            const float rn = 1.0f / o.nrm;
+        const double qh[4] = {w, x, y, z};
+        if (nrm >= 1e-12) {
+            const double dot = qh[0] * gh[0] + qh[1] * gh[1] + qh[2] * gh[2] + qh[3] * gh[3];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gq[i] = (gh[i] - qh[i] * dot) * rn;
+            for (int i = 0; i < 4; ++i) gq[i] = (float)((gh[i] - qh[i] * dot) / nrm);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gq[i] = gh[i] * 1e12f;
+            for (int i = 0; i < 4; ++i) gq[i] = (float)(gh[i] * 1e12);
         }
     }
     g_pos[3 * idx] = gp[0]; g_pos[3 * idx + 1] = gp[1]; g_pos[3 * idx + 2] = gp[2];
