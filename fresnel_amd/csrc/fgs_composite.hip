@@ -266,6 +266,149 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     }
 }
 
+// Depth-split forward of the blend path.  Alpha compositing is associative: a list cut into parts can be
+// composited part by part from T = 1 and the partial results composed afterwards,
+//     (C, T) o (C', T') = (C + T C', T T').
+// NP waves per tile; wave p composites list part p (a whole number of FGS_SEG segments, ALL FOUR sub-tiles per
+// lane), staging its own 64-record chunks in wave-private LDS -- no block barrier inside the list walk.  Compared
+// with splitting a tile by sub-tile rows (k_composite_fwd) every list entry is read from LDS by ONE wave instead of
+// all of them and its row terms are formed once, at the same serial length per wave.
+// Checkpoints: a wave stores its LOCAL state at the segment boundaries inside its part.  After the walk wave 0
+// composes the parts in order and leaves the ABSOLUTE state in the checkpoint slot of every part's first segment;
+// the backward unit of a later segment of part p > 0 re-bases its local checkpoint with that slot
+// (k_composite_bwd, `fwd_parts`).  Hand-over between the waves goes through the checkpoint slots themselves
+// (the slot of the next part's first segment; the last part uses the tile's slot 0, which nothing else reads).
+struct BlendState { float Cr, Cg, Cb, T, D; };
+__device__ __forceinline__ BlendState compose(const BlendState &a, const BlendState &b) {
+    return {a.Cr + a.T * b.Cr, a.Cg + a.T * b.Cg, a.Cb + a.T * b.Cb, a.T * b.T, a.D + a.T * b.D};
+}
+__device__ __forceinline__ void ckpt_store(float *ck, const BlendState &v) {  // [5][4][64] slot, this lane's cell
+    ck[0] = v.Cr; ck[256] = v.Cg; ck[2 * 256] = v.Cb; ck[3 * 256] = 1.0f - v.T; ck[4 * 256] = v.D;
+}
+__device__ __forceinline__ BlendState ckpt_load(const float *ck) {
+    return {ck[0], ck[256], ck[2 * 256], 1.0f - ck[3 * 256], ck[4 * 256]};
+}
+
+template <int NP>
+__global__ __launch_bounds__(64 * NP) void k_blend_fwd_parts(
+    uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2,
+    const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
+    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, float *__restrict__ pix_state,
+    float *__restrict__ out_rgb, float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off,
+    float *__restrict__ seg_ckpt) {
+    __shared__ float4 sh0[NP][64], sh1[NP][64], sh2[NP][64];
+    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const uint32_t nseg = (c.end - c.start + FGS_SEG - 1) / FGS_SEG;
+    const uint32_t spp = (nseg + NP - 1) / NP;  // segments per part
+    const uint32_t first_seg = wave * spp;
+    const bool active = first_seg < nseg;
+    const uint32_t pstart = c.start + first_seg * FGS_SEG;
+    const uint32_t pend = active ? min(c.end, pstart + spp * FGS_SEG) : pstart;
+    float *slot0 = seg_ckpt + (size_t)seg_off[c.tile] * (5 * 256) + lane;  // + s * 64 per sub-tile
+    float T[4], Cr[4], Cg[4], Cb[4], Dm[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; }
+    const uint32_t shx = lx, shy = 16u + ly;
+    float fx0 = (float)(c.X0 + lx), fx1 = (float)(c.X0 + lx + 8u), fy0 = (float)(c.Y0 + ly);
+    asm("" : "+v"(fx0), "+v"(fx1), "+v"(fy0));
+    for (uint32_t base = pstart; base < pend; base += 64) {
+        const uint32_t n = min(64u, pend - base);
+        if (base != pstart && ((base - c.start) % FGS_SEG) == 0) {  // LOCAL state in front of this segment
+            float *ck = slot0 + (size_t)((base - c.start) / FGS_SEG) * (5 * 256);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ckpt_store(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
+        }
+        if (lane < n) {
+            const uint32_t gid = dup_ids[base + lane];
+            const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
+            float4 q0 = r[0], q1 = r[1], q2 = r[2];
+            q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
+            uint32_t flags, bits;
+            stage_decode(c.X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, bits);
+            q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
+            sh0[wave][lane] = q0; sh1[wave][lane] = q1; sh2[wave][lane] = q2;
+        }
+        __builtin_amdgcn_wave_barrier();  // wave-private LDS: one wave's LDS instructions execute in order
+        for (uint32_t j = 0; j < n; ++j) {
+            const float4 q0 = sh0[wave][j], q1 = sh1[wave][j], q2 = sh2[wave][j];
+            const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w)) & 15u;
+            if (!msk) continue;
+            const uint32_t bits = __float_as_uint(q2.z);
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                if (!((msk >> (2 * row)) & 3u)) continue;
+                const float dy = row ? fy0 + 8.0f - q0.y : fy0 - q0.y;
+                const float bdy = q0.w * dy, cyy = (q1.x * dy) * dy;
+                const uint32_t my = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u * row, 1);
+#pragma unroll
+                for (int col = 0; col < 2; ++col) {
+                    const int s = 2 * row + col;
+                    if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
+                    const float dx = (col ? fx1 : fx0) - q0.x;
+                    const float t = q0.z * dx + bdy;
+                    const uint32_t mk = my & (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u * col, 1);
+                    const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(t * dx + cyy)) & mk);
+                    const float alpha = fminf(G * q1.y, 0.99f);  // opacity >= 0 here: no lower clamp needed
+                    const float w = alpha * T[s];
+                    Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
+                    T[s] -= w;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- hand the part results over and compose them (wave 0) ----
+    const uint32_t last = nseg ? (nseg - 1) / spp : 0u;
+    if (NP > 1 && nseg > spp) {  // more than one part
+        if (active && wave != 0) {
+            float *ck = (wave == last) ? slot0 : slot0 + (size_t)((wave + 1) * spp) * (5 * 256);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ckpt_store(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (wave != 0) return;
+        // wave 0: its own result is the absolute state in front of part 1
+        {
+            float *ck = slot0 + (size_t)spp * (5 * 256);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ckpt_store(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
+        }
+        for (uint32_t pp = 1; pp <= last; ++pp) {
+            const float *src = (pp == last) ? slot0 : slot0 + (size_t)((pp + 1) * spp) * (5 * 256);
+            float *dst = slot0 + (size_t)((pp + 1) * spp) * (5 * 256);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const BlendState acc = compose(BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]}, ckpt_load(src + s * 64));
+                Cr[s] = acc.Cr; Cg[s] = acc.Cg; Cb[s] = acc.Cb; T[s] = acc.T; Dm[s] = acc.D;
+                if (pp != last) ckpt_store(dst + s * 64, acc);
+            }
+        }
+    } else if (wave != 0) {
+        return;
+    }
+    const size_t HW = (size_t)W * H;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
+        if (px < W && py < H) {
+            const size_t o = (size_t)py * W + px;
+            float *ps = pix_state + (size_t)c.b * 6 * HW + o;
+            const float Tf = T[s];
+            ps[0] = Cr[s]; ps[HW] = Cg[s]; ps[2 * HW] = Cb[s]; ps[3 * HW] = 1.0f - Tf; ps[4 * HW] = Dm[s];
+            ps[5 * HW] = 0.0f;
+            float *img = out_rgb + (size_t)c.b * 3 * HW + o;
+            img[0] = fminf(fmaxf(Cr[s] + Tf * bg0, 0.0f), 1.0f);
+            img[HW] = fminf(fmaxf(Cg[s] + Tf * bg1, 0.0f), 1.0f);
+            img[2 * HW] = fminf(fmaxf(Cb[s] + Tf * bg2, 0.0f), 1.0f);
+            out_depth[(size_t)c.b * HW + o] = Dm[s];
+        }
+    }
+}
+
 // Backward, front-to-back.  For pixel p and Gaussian i:
 //   dL/dalpha_i = T_i q_i - S_i / (1 - alpha_i),  q_i = gI.c_i + gD d_i,
 //   S_i = T_fin (gI.bg) + sum_{j>i} w_j q_j = T_fin (gI.bg) + Total - sum_{j<=i} w_j q_j,
@@ -287,7 +430,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     const uint32_t *__restrict__ seg_tile, const float *__restrict__ seg_ckpt, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const uint32_t *__restrict__ dup_off,
     const float *__restrict__ pix_state, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
-    float *__restrict__ grad_rows, unsigned long long *__restrict__ dbg_ts, float t_eps) {
+    float *__restrict__ grad_rows, unsigned long long *__restrict__ dbg_ts, float t_eps, uint32_t fwd_parts) {
     const unsigned long long dbg_t0 = dbg_ts ? wall_clock64() : 0ull;
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
@@ -298,6 +441,12 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     const uint32_t unit_tile = seg_tile[blockIdx.x];
     const uint32_t seg = blockIdx.x - seg_off[unit_tile];
     TileCtx c = tile_ctx_of(unit_tile, tiles, tiles_x, ranges);
+    uint32_t rebase_seg = seg;  // first segment of this segment's list part if its checkpoint is part-local
+    if (fwd_parts > 1) {
+        const uint32_t nseg = (c.end - c.start + FGS_SEG - 1) / FGS_SEG;
+        const uint32_t spp = (nseg + fwd_parts - 1) / fwd_parts, first = seg / spp * spp;
+        if (first != 0) rebase_seg = first;
+    }
     c.start += seg * FGS_SEG;
     c.end = min(c.end, c.start + FGS_SEG);
     const uint32_t lane = threadIdx.x;
@@ -347,10 +496,16 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
         }
         if (seg) {
             // restart from the forward's state in front of this segment: T, and S minus the part of Total that
-            // belongs to the list entries before it
-            const float *ck = seg_ckpt + (size_t)blockIdx.x * (5 * 256) + s * 64 + lane;
-            T[s] = 1.0f - ck[3 * 256];
-            S[s] -= gr[s] * ck[0] + gg[s] * ck[256] + gb[s] * ck[2 * 256] + gd[s] * ck[4 * 256];
+            // belongs to the list entries before it.  After a depth-split forward (k_blend_fwd_parts, fwd_parts
+            // waves per tile) the checkpoint of a segment inside part p > 0 is local to that part and is re-based
+            // with the absolute state kept in the slot of the part's first segment.
+            BlendState st = ckpt_load(seg_ckpt + (size_t)blockIdx.x * (5 * 256) + s * 64 + lane);
+            if (rebase_seg != seg) {
+                const size_t slot = (size_t)blockIdx.x - seg + rebase_seg;
+                st = compose(ckpt_load(seg_ckpt + slot * (5 * 256) + s * 64 + lane), st);
+            }
+            T[s] = st.T;
+            S[s] -= gr[s] * st.Cr + gg[s] * st.Cg + gb[s] * st.Cb + gd[s] * st.D;
         }
     }
     const uint32_t shx = lx, shy = 16u + ly;  // this lane's column / row bit in the staged pixel bits
@@ -647,6 +802,18 @@ static int env_int(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+// Number of list parts of the depth-split forward (0 = k_composite_fwd).  Forward and backward launchers must
+// agree: a function of the plan (and of FGS_FWD_PARTS, an A/B switch that must not change between a forward
+// and its backward).  Measured (fwd ms): 8 images x 1024 tiles: rows-split 0.642, 2 parts 0.586, 4 parts 0.588;
+// config 2 (4096 tiles): 0.169 / 0.167 / 0.134; 32 images: one wave per tile 2.215, 1 part 2.173, 2 parts 2.27.
+static int fwd_parts_of(const FgsPlan &p) {
+    if (p.d.use_phase || p.d.saturation_skip) return 0;
+    const int forced = env_int("FGS_FWD_PARTS", -1);
+    if (forced >= 0) return forced;
+    const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
+    return grid >= 24576u ? 1 : 4;
+}
+
 int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, float *out_rgb,
                              float *out_depth, hipStream_t st) {
     const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
@@ -664,6 +831,17 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     // amortised over four sub-tile passes (32 images: 2.26 vs 2.61 ms); a launch that cannot even fill the chip once
     // is latency-bound and gets one wave per sub-tile.  FGS_FWD_WAVES overrides (A/B harness).
     const int fw = env_int("FGS_FWD_WAVES", grid >= 24576u ? 1 : (grid <= 6144u ? 4 : 2));
+    if (const int np = fwd_parts_of(p)) {
+#define FGS_PARTS_LAUNCH(NP)                                                                                  \
+    hipLaunchKernelGGL((k_blend_fwd_parts<NP>), dim3(grid), dim3(64 * NP), 0, st, (uint32_t)p.tiles,          \
+                       (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
+                       p.d.background[1], p.d.background[2], tile_order, ranges, dup_ids, rec, pix, out_rgb,  \
+                       out_depth, seg_off, seg_ckpt)
+        if (np == 1) FGS_PARTS_LAUNCH(1); else if (np == 2) FGS_PARTS_LAUNCH(2); else FGS_PARTS_LAUNCH(4);
+#undef FGS_PARTS_LAUNCH
+        FGS_LAUNCH_CHECK("k_blend_fwd_parts");
+        return FGS_OK;
+    }
 #define FGS_FWD_LAUNCH(PH, FW, SK)                                                                            \
     hipLaunchKernelGGL((k_composite_fwd<PH, FW, SK>), dim3(grid), dim3(64 * FW), 0, st, (uint32_t)p.tiles,   \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
@@ -719,7 +897,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const float *>(saved + p.L.pix_state), g_rgb, g_depth,
                        reinterpret_cast<float *>(scratch + p.s_grows), dbg,
-                       p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f);
+                       p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f, (uint32_t)(fwd_parts_of(p) == 1 ? 0 : fwd_parts_of(p)));
     if (dbg) {
         (void)hipStreamSynchronize(st);
         std::vector<unsigned long long> h((size_t)ugrid * 4);

@@ -350,12 +350,13 @@ def test_long_lists_many_depth_segments_vs_oracle():
 
 
 @pytest.mark.parametrize("use_phase", [False, True])
-def test_forward_waves_per_tile_variants_agree(use_phase, monkeypatch):
-    """The forward picks 1, 2 or 4 waves per tile from the launch size (one wave per tile for >= 24576
-    tiles, four on the phase path).  Every variant walks a pixel's list in the same order with the same
-    arithmetic, so image, depth and -- through the saved state and checkpoints -- all gradients must agree
-    whichever is forced (FGS_FWD_WAVES is read at every launch) up to the compiler's different FMA contraction
-    per instantiation: 1e-5 of max.  (Run-to-run bitwise reproducibility of one configuration is tested above.)"""
+def test_forward_variants_agree(use_phase, monkeypatch):
+    """The forward picks its work split from the launch size.  Blend path: the depth-split kernel with 1, 2 or 4
+    list parts per tile (FGS_FWD_PARTS; partial results composed with (C,T)o(C',T') = (C + T C', T T'), the
+    backward re-bases part-local checkpoints) or the row-split kernel (FGS_FWD_PARTS=0, FGS_FWD_WAVES 1/2/4).
+    Phase path: 1, 2 or 4 waves per tile.  All variants must agree on image, depth and -- through the saved
+    state and checkpoints -- on every gradient, to 1e-5 of max (composition order and FMA contraction differ).
+    The list is long enough for several parts: ~3000 entries over 36 tiles."""
     from fresnel_amd.renderer import Camera
     N, S = 3000, 96
     arrs = list(synth_aniso(N, 9))
@@ -364,9 +365,12 @@ def test_forward_waves_per_tile_variants_agree(use_phase, monkeypatch):
     gI = rs.standard_normal((3, S, S)).astype(np.float32)
     gD = (rs.standard_normal((S, S)) * 0.1).astype(np.float32)
     phases = rs.uniform(0, 1, N).astype(np.float32) if use_phase else None
+    variants = [dict(FGS_FWD_WAVES=w) for w in "124"] if use_phase else (
+        [dict(FGS_FWD_PARTS=p) for p in "124"] + [dict(FGS_FWD_PARTS="0", FGS_FWD_WAVES=w) for w in "124"])
     outs = []
-    for fw in ["1", "2", "4"]:
-        monkeypatch.setenv("FGS_FWD_WAVES", fw)
+    for env in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         outs.append(_hip_render(arrs, cam, S, S, (0.1, 0.2, 0.3), phases=phases, use_phase=use_phase, grads=(gI, gD)))
     for o in outs[1:]:
         for k in outs[0]:
