@@ -1,7 +1,7 @@
 """Collect the round profile (scratch/profile_round.sh) into the files committed under profiles/."""
 import sys, glob, csv, collections, json, shutil, os
 root = sys.argv[1]
-KEYS = ('k_composite_bwd', 'k_composite_fwd', 'k_project_bwd', 'k_radix_downsweep', 'k_radix_upsweep', 'k_dup_emit', 'k_tile_order')
+KEYS = ('k_composite_bwd', 'k_blend_fwd_parts', 'k_composite_fwd', 'k_project_bwd', 'k_radix_downsweep', 'k_radix_upsweep', 'k_dup_emit', 'k_tile_order')
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(lambda: collections.defaultdict(set))
 dur = collections.defaultdict(list)
 for f in glob.glob(root + '/g*/**/*counter_collection.csv', recursive=True):
@@ -23,7 +23,7 @@ out = {"note": "rocprofv3 --pmc passes (FETCH_SIZE+GRBM_GUI_ACTIVE | WRITE_SIZE 
                "config 3, 8 images; values are per launch; hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled per "
                "MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B); gather-style reads are uncalibrated, treat the read side as an "
                "upper bound.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles.", "kernels": []}
-alg = {'k_composite_fwd': bench['roofline'].get('algorithmic_bytes_fwd'), 'k_composite_bwd': bench['roofline'].get('algorithmic_bytes_bwd')}
+alg = {'k_blend_fwd_parts': bench['roofline'].get('algorithmic_bytes_fwd'), 'k_composite_fwd': bench['roofline'].get('algorithmic_bytes_fwd'), 'k_composite_bwd': bench['roofline'].get('algorithmic_bytes_bwd')}
 for k in KEYS:
     if k not in acc: continue
     row = {"kernel": k}
