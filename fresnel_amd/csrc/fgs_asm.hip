@@ -28,6 +28,7 @@ namespace {
 
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;
 constexpr int ACH = 64;
+constexpr int ASM_FWD_PARTS = 4;  // list parts (waves) per (image, plane, tile) in the forward splat
 constexpr int ST_ASM = ST_COMPOSITE_FWD;  // stage timers: ASM stages are accounted as "composite"
 
 struct AsmPlan {
@@ -168,15 +169,20 @@ __global__ __launch_bounds__(256) void k_asm_transfer(int W, int H, int P, float
 // WAVE = true (WaveFieldRenderer, DR:832-891): a single layer, and additionally the amplitude-weighted
 // depth sums (sum a*depth, sum a) in `dw`; gradient rows are 16 floats wide (slot 12 = dL/ddepth).
 template <bool BWD, bool WAVE>
-__global__ __launch_bounds__(64) void k_asm_splat(
+__global__ __launch_bounds__(BWD ? 64 : 64 * ASM_FWD_PARTS) void k_asm_splat(
     uint32_t tiles, uint32_t tiles_x, uint32_t P, uint32_t W, uint32_t H, uint32_t dcap, int phase_channels,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
     const uint32_t *__restrict__ dup_off, float2 *__restrict__ field, float *__restrict__ grad_rows,
     float2 *__restrict__ dw, const uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg_off,
     const uint32_t *__restrict__ seg_tile) {
-    __shared__ float4 sh0[ACH], sh1[ACH], sh2[ACH], sh3[ACH];
-    __shared__ uint32_t shm[ACH], she[ACH];
+    // Forward: the splat is a plain sum, so the list is cut into NP parts, one per wave (own LDS staging, no block
+    // barrier in the walk) and the partial fields are added in part order at the end -- the launch is latency-bound
+    // by its longest lists.  Backward: one wave per depth-segment unit.
+    constexpr int NP = BWD ? 1 : ASM_FWD_PARTS;
+    __shared__ float4 sh0[NP * ACH], sh1[NP * ACH], sh2[NP * ACH], sh3[NP * ACH];
+    __shared__ uint32_t shm[NP * ACH], she[BWD ? ACH : 1];
+    __shared__ float part[BWD ? 1 : (NP - 1) * (WAVE ? 32 : 24) * 64];
     __shared__ __attribute__((aligned(16))) float red[BWD ? 13 : 1][80];  // wave_sum_transposed scratch (backward)
     // Forward: one block per (image, plane, tile), longest lists first.  Backward: the splat carries no state
     // along a list, so the work unit is a depth segment of FGS_SEG list entries (unit list of k_tile_order;
@@ -192,9 +198,16 @@ __global__ __launch_bounds__(64) void k_asm_splat(
     const uint32_t bp = key / tiles, t = key - bp * tiles;
     const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
     const uint32_t X0 = tx * FGS_TILE, Y0 = ty * FGS_TILE;
-    const uint32_t start = ranges[2 * key] + seg * FGS_SEG;
-    const uint32_t end = BWD ? min(ranges[2 * key + 1], start + FGS_SEG) : ranges[2 * key + 1];
-    const uint32_t lane = threadIdx.x, lx = lane & 7u, ly = lane >> 3;
+    const uint32_t lane = threadIdx.x & 63u, lx = lane & 7u, ly = lane >> 3;
+    const uint32_t wave = NP > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
+    const uint32_t wofs = wave * ACH;  // this wave's slice of the staging arrays
+    uint32_t start = ranges[2 * key] + seg * FGS_SEG;
+    uint32_t end = BWD ? min(ranges[2 * key + 1], start + FGS_SEG) : ranges[2 * key + 1];
+    if (NP > 1) {  // this wave's part of the list (whole chunks)
+        const uint32_t per = ((end - start + NP * ACH - 1) / (NP * ACH)) * ACH;
+        start = min(end, start + wave * per);
+        end = min(end, start + per);
+    }
     const size_t HW = (size_t)W * H;
     float2 *fbase = field + (size_t)bp * 3 * HW;  // [b][p][c][y][x]
     float re[4][3], im[4][3];  // FWD: accumulators.  BWD: field gradient at this lane's pixels
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(64) void k_asm_splat(
             const float4 q0 = r[0], q1 = r[1], q2 = r[2];
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
             const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu, by1 = bby >> 16;
-            shm[lane] = subtile_mask(X0, Y0, bx0, bx1, by0, by1);
+            shm[wofs + lane] = subtile_mask(X0, Y0, bx0, bx1, by0, by1);
             if (BWD) {
                 const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
                 she[lane] = dup_off[gid] + (ty - ty0) * (tx1 - tx0 + 1) + (tx - tx0);
@@ -238,16 +251,16 @@ __global__ __launch_bounds__(64) void k_asm_splat(
                 sincosf(ph, &sn, &co);
                 cc[c] = col[c] * co; cs[c] = col[c] * sn;
             }
-            sh0[lane] = make_float4(q0.x, q0.y, q0.z, q0.w);                       // u, v, ca, cbc
-            sh1[lane] = make_float4(q1.x, q1.y, __uint_as_float(bx0 | ((bx1 - bx0) << 16)),
+            sh0[wofs + lane] = make_float4(q0.x, q0.y, q0.z, q0.w);                       // u, v, ca, cbc
+            sh1[wofs + lane] = make_float4(q1.x, q1.y, __uint_as_float(bx0 | ((bx1 - bx0) << 16)),
                                     __uint_as_float(by0 | ((by1 - by0) << 16)));   // cd, op, bbx', bby'
-            sh2[lane] = make_float4(cc[0], cc[1], cc[2], cs[0]);
-            sh3[lane] = make_float4(cs[1], cs[2], q2.y, 0.0f);  // .z = depth (WAVE)
+            sh2[wofs + lane] = make_float4(cc[0], cc[1], cc[2], cs[0]);
+            sh3[wofs + lane] = make_float4(cs[1], cs[2], q2.y, 0.0f);  // .z = depth (WAVE)
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // wave-private staging: one wave's LDS instructions execute in order
         for (uint32_t j = 0; j < n; ++j) {
-            const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j], q3 = sh3[j];
-            const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
+            const float4 q0 = sh0[wofs + j], q1 = sh1[wofs + j], q2 = sh2[wofs + j], q3 = sh3[wofs + j];
+            const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[wofs + j]);
             const uint32_t bbx = __float_as_uint(q1.z), bby = __float_as_uint(q1.w);
             const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;
             const float cc[3] = {q2.x, q2.y, q2.z}, cs[3] = {q2.w, q3.x, q3.y};
@@ -292,7 +305,31 @@ __global__ __launch_bounds__(64) void k_asm_splat(
                     grad_rows[(size_t)e * (WAVE ? 16 : FGS_GROW_FLOATS) + (lane >> 2)] = tot;
             }
         }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!BWD && NP > 1) {
+        // add the partial fields in part order (wave 0 = part 0 accumulates parts 1, 2, ...): deterministic
+        constexpr int NF = WAVE ? 32 : 24;
+        if (wave != 0) {
+            float *pp = part + ((size_t)(wave - 1) * NF) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { pp[(s * 6 + c) * 64] = re[s][c]; pp[(s * 6 + 3 + c) * 64] = im[s][c]; }
+                if (WAVE) { pp[(24 + 2 * s) * 64] = wd[s]; pp[(25 + 2 * s) * 64] = ww[s]; }
+            }
+        }
         __syncthreads();
+        if (wave != 0) return;
+        for (int w = 1; w < NP; ++w) {
+            const float *pp = part + ((size_t)(w - 1) * NF) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { re[s][c] += pp[(s * 6 + c) * 64]; im[s][c] += pp[(s * 6 + 3 + c) * 64]; }
+                if (WAVE) { wd[s] += pp[(24 + 2 * s) * 64]; ww[s] += pp[(25 + 2 * s) * 64]; }
+            }
+        }
     }
     if (!BWD) {
 #pragma unroll
@@ -703,7 +740,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     float2 *total = reinterpret_cast<float2 *>(sv + p.v_total);
     float *scal = reinterpret_cast<float *>(sv + p.v_scal);
     const uint32_t grid = (uint32_t)B * P * p.base.tiles;
-    hipLaunchKernelGGL((k_asm_splat<false, false>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+    hipLaunchKernelGGL((k_asm_splat<false, false>), dim3(grid), dim3(64 * ASM_FWD_PARTS), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
                        (uint32_t)p.base.L.dup_capacity, a.phase_channels,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
@@ -835,7 +872,7 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
     float2 *dw = reinterpret_cast<float2 *>(sv + p.v_dw);
     float *scal = reinterpret_cast<float *>(sv + p.v_scal);
     const uint32_t grid = (uint32_t)B * p.base.tiles;
-    hipLaunchKernelGGL((k_asm_splat<false, true>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+    hipLaunchKernelGGL((k_asm_splat<false, true>), dim3(grid), dim3(64 * ASM_FWD_PARTS), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, 1u, (uint32_t)W, (uint32_t)H, (uint32_t)p.base.L.dup_capacity,
                        p.w.phase_channels, reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
