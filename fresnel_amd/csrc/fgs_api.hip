@@ -111,7 +111,10 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     L.dup_capacity = dcap;
     L.tiles_x = tx; L.tiles_y = ty;
 
-    const size_t nsort = dcap > B * N ? dcap : B * N;
+    size_t nsort = dcap > B * N ? dcap : B * N;
+    // the direct binning keeps its [B][tiles][ceil(N / FGS_BIN_G)] count matrix in the first sort buffer
+    const size_t bin_words = B * (size_t)layers * p->tiles * ((N + FGS_BIN_G - 1) / FGS_BIN_G);
+    if (bin_words > nsort) nsort = bin_words;
     const size_t nblk = (B * N + 255) / 256;
     size_t hist = fgs_radix_hist_bytes((uint32_t)N, (uint32_t)B);
     const size_t hist2 = fgs_radix_hist_bytes((uint32_t)dcap, 1);

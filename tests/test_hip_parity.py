@@ -271,6 +271,41 @@ def test_full_size_properties_config3_shape():
     assert np.abs(stp["depth"] - st1["depth"]).max() <= 1e-4 * np.abs(st1["depth"]).max()
 
 
+def test_direct_binning_equals_radix_binning():
+    """Two list builders: the counting sort straight from the bboxes (default for a single layer and <= 4096 tiles
+    per image) and the emit + stable radix sort path (kept for the layered ASM keys and larger frames).  Both must
+    produce bit-identical lists, ranges and duplicate offsets.  (FGS_BIN_RADIX is read once per process, so the
+    radix variant runs in a child process.)"""
+    import subprocess, sys, os, tempfile
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from helpers import synth_aniso
+from fresnel_amd import renderer as R
+from fresnel_amd.renderer import Camera
+N, W, H = 4000, 200, 136
+arrs = [np.stack([a, b]) for a, b in zip(synth_aniso(N, 61, smax=0.2), synth_aniso(N, 62, smax=0.05))]
+ts = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+cfg = R._Cfg(W, H, (0, 0, 0), 64, False, 0.25)
+img, dep, saved, dims, _ = R.forward_raw(*ts, None, R.pack_cameras(Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H), ts[0].device), cfg)
+torch.cuda.synchronize()
+st = R.inspect_saved(saved, dims)
+D = int(st['counters'][0])
+np.savez(sys.argv[1], D=D, dup_ids=st['dup_ids'][:D].cpu().numpy(), ranges=st['ranges'].cpu().numpy(),
+         seg_off=st['seg_off'].cpu().numpy(), image=img.cpu().numpy())
+"""
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for radix in ("0", "1"):
+            path = os.path.join(td, f"bin{radix}.npz")
+            env = dict(os.environ, FGS_BIN_RADIX=radix)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            outs.append(dict(np.load(path)))
+    assert int(outs[0]["D"]) == int(outs[1]["D"]) and int(outs[0]["D"]) > 20000
+    for k in ("dup_ids", "ranges", "seg_off", "image"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 def test_negative_and_saturating_opacities_vs_oracle():
     """alpha = clamp(G * opacity, 0, 0.99) (DR:646): a negative opacity contributes nothing and gets zero
     gradients (the kernels drop such records at staging time), opacities above 0.98 take the clamped path,
