@@ -365,40 +365,39 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, uint32_t *
     }
     if (!seg_off && !lens) return;
     // One sweep over the tiles scans (list length, depth segments) packed in 64 bits: ranges (direct binning) and
-    // the depth-segment units.
-    if (threadIdx.x == 0) carry64 = 0;
-    __syncthreads();
+    // the depth-segment units.  Every thread owns a run of consecutive tiles, so the block needs ONE scan (a wave
+    // scan and sixteen wave sums) however many tiles there are.
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < ntiles; base += 1024) {
-        const uint32_t t = base + threadIdx.x;
-        const uint32_t len = t < ntiles ? len_of(t) : 0u;
-        const uint32_t n = (len + FGS_SEG - 1) / FGS_SEG;
-        const unsigned long long v = ((unsigned long long)len << 32) | n;
-        unsigned long long x = v;  // inclusive scan inside the wave
+    const uint32_t per = (ntiles + 1023) / 1024, t0 = threadIdx.x * per, t1 = min(ntiles, t0 + per);
+    unsigned long long v = 0;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t len = len_of(t);
+        v += ((unsigned long long)len << 32) | ((len + FGS_SEG - 1) / FGS_SEG);
+    }
+    unsigned long long x = v;  // inclusive scan inside the wave
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long y = __shfl_up(x, o, 64);
-            if (lane >= (uint32_t)o) x += y;
-        }
-        if (lane == 63) wsum64[wave] = x;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long run = 0;
-            for (int i = 0; i < 16; ++i) { const unsigned long long h = wsum64[i]; wsum64[i] = run; run += h; }
-        }
-        __syncthreads();
-        const unsigned long long off64 = carry64 + wsum64[wave] + x - v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long y = __shfl_up(x, o, 64);
+        if (lane >= (uint32_t)o) x += y;
+    }
+    if (lane == 63) wsum64[wave] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 16; ++i) { const unsigned long long h = wsum64[i]; wsum64[i] = run; run += h; }
+        carry64 = run;
+    }
+    __syncthreads();
+    unsigned long long off64 = wsum64[wave] + x - v;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t len = len_of(t), n = (len + FGS_SEG - 1) / FGS_SEG;
         const uint32_t off = (uint32_t)off64, lstart = (uint32_t)(off64 >> 32);
-        if (t < ntiles) {
-            if (lens) { ranges[2 * t] = lstart; ranges[2 * t + 1] = lstart + len; }
-            if (seg_off) {
-                seg_off[t] = off;
-                for (uint32_t k = 0; k < n; ++k) seg_tile[off + k] = t;
-            }
+        if (lens) { ranges[2 * t] = lstart; ranges[2 * t + 1] = lstart + len; }
+        if (seg_off) {
+            seg_off[t] = off;
+            for (uint32_t k = 0; k < n; ++k) seg_tile[off + k] = t;
         }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry64 = off64 + v;
-        __syncthreads();
+        off64 += ((unsigned long long)len << 32) | n;
     }
     if (threadIdx.x == 0 && seg_off) { seg_off[ntiles] = (uint32_t)carry64; counters[2] = (uint32_t)carry64; }
 }
