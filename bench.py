@@ -190,7 +190,7 @@ def main():
         alg_bytes = {  # ALGORITHMIC bytes per launch (DESIGN.md "Kernels"), B images per launch
             # + 5 floats x 256 pixels of checkpoint per depth segment after a tile's first (written / read once)
             "composite_fwd": per_gpu * (40 * HW) + 52 * D_local + 5120 * max(U_local - per_gpu * (S // 16) ** 2, 0),
-            "composite_bwd": per_gpu * (36 * HW) + (52 + 48) * D_local + 5120 * max(U_local - per_gpu * (S // 16) ** 2, 0),
+            "composite_bwd": per_gpu * (36 * HW) + (52 + 40) * D_local + 5120 * max(U_local - per_gpu * (S // 16) ** 2, 0),
         }
         alg_flops = {"composite_fwd": 23.0 * pairs_local, "composite_bwd": 60.0 * pairs_local}
         avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in stage.items()}

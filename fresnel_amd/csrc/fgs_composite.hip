@@ -465,8 +465,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                 const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE;
                 const uint32_t e = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
                 if (e < dcap) {
-                    float4 *row = reinterpret_cast<float4 *>(grad_rows + (size_t)e * FGS_GROW_FLOATS);
-                    row[0] = row[1] = row[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    float2 *row = reinterpret_cast<float2 *>(grad_rows + (size_t)e * FGS_BLEND_ROW_FLOATS);
+                    row[0] = row[1] = row[2] = row[3] = row[4] = make_float2(0.0f, 0.0f);
                 }
             }
             return;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                 const uint32_t kk = lane >> 2, e = she[j];
                 // dL/dconic = K * (sums in exp2 units); the other seven sums are already final
                 const float scl = (kk >= 2u && kk <= 4u) ? NEG_HALF_LOG2E : 1.0f;
-                if ((lane & 3u) == 3u && lane < 40u && e < dcap) grad_rows[(size_t)e * FGS_GROW_FLOATS + kk] = tot * scl;
+                if ((lane & 3u) == 3u && lane < 40u && e < dcap) grad_rows[(size_t)e * FGS_BLEND_ROW_FLOATS + kk] = tot * scl;
             }
         }
         __syncthreads();

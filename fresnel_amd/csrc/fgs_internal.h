@@ -12,6 +12,7 @@
 // gradient-row field indices (scratch.grows): one 12-float row per (tile, Gaussian) duplicate
 enum { G_U = 0, G_V, G_CA, G_CBC, G_CD, G_OP, G_CR, G_CG, G_CB, G_DEPTH, G_PHASE, G_PAD1 };
 #define FGS_GROW_FLOATS 12
+#define FGS_BLEND_ROW_FLOATS 10  /* gradient rows of the (non-phase) blend backward: exactly its ten sums */
 #define FGS_BIN_G 256  /* depth ranks per block of the direct binning (fgs_bin.hip) */
 enum { R_U = 0, R_V, R_CA, R_CBC, R_CD, R_OP, R_CR, R_CG, R_CB, R_DEPTH, R_BBX, R_BBY };
 

@@ -192,6 +192,15 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     if (live) {
         // rows_per_dup gradient rows per duplicate (4 on the phase path: one per sub-tile wave), contiguous
         const uint32_t cnt = tile_count[idx] * rows_per_dup, off = dup_off[idx] * rows_per_dup;
+        if (MODE == 0 && phase_channels) {
+            // blend path: 10-float rows (first moments, conic, opacity, colour, depth -- nothing else is summed)
+            for (uint32_t k = sub; k < cnt && off + k < dcap; k += 4) {
+                const float2 *r = reinterpret_cast<const float2 *>(grad_rows + (size_t)(off + k) * FGS_BLEND_ROW_FLOATS);
+                const float2 a = r[0], bq = r[1], cq = r[2], dq = r[3], eq = r[4];
+                acc[0] += a.x; acc[1] += a.y; acc[2] += bq.x; acc[3] += bq.y; acc[4] += cq.x;
+                acc[5] += cq.y; acc[6] += dq.x; acc[7] += dq.y; acc[8] += eq.x; acc[9] += eq.y;
+            }
+        } else
         for (uint32_t k = sub; k < cnt && off + k < dcap * rows_per_dup; k += 4) {
             const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * ROWF);
             const float4 a = r[0], bq = r[1], cq = r[2];
