@@ -141,8 +141,14 @@ def saved_layout(dims):
     return L
 
 
-def stage_timing_enable(on=True):
-    check(load().fgs_stage_timing_enable(1 if on else 0), "fgs_stage_timing_enable")
+def stage_timing_enable(on=True, stages=None):
+    """on=True: every stage; stages=[names]: only those (each event pair costs a few microseconds of stream time)."""
+    mask = 1 if on else 0
+    if on and stages is not None:
+        mask = 0
+        for name in stages:
+            mask |= 1 << (STAGES.index(name) + 1)
+    check(load().fgs_stage_timing_enable(mask), "fgs_stage_timing_enable")
 
 
 def stage_timing_read():

@@ -21,7 +21,7 @@ void fgs_set_error(const char *fmt, ...) {
 namespace {
 struct StageRec { int stage; hipEvent_t a, b; };
 std::mutex g_tm;
-bool g_timing = false;
+unsigned g_timing = 0;  // bit (stage) set: that stage is bracketed by events
 std::vector<StageRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open[FGS_NUM_STAGES];
@@ -34,7 +34,7 @@ hipEvent_t take_event() {
 }  // namespace
 
 void fgs_stage_begin(int stage, hipStream_t st) {
-    if (!g_timing) return;
+    if (!((g_timing >> stage) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_tm);
     hipEvent_t e = take_event();
     if (!e) return;
@@ -43,7 +43,7 @@ void fgs_stage_begin(int stage, hipStream_t st) {
 }
 
 void fgs_stage_end(int stage, hipStream_t st) {
-    if (!g_timing) return;
+    if (!((g_timing >> stage) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_tm);
     if (!g_open[stage]) return;
     hipEvent_t e = take_event();
@@ -138,7 +138,8 @@ const char *fgs_last_error(void) { return g_err; }
 
 int fgs_stage_timing_enable(int enable) {
     std::lock_guard<std::mutex> lk(g_tm);
-    g_timing = enable != 0;
+    // 0: off; 1: every stage; otherwise bit (stage + 1) selects individual stages
+    g_timing = enable == 1 ? ~0u : ((unsigned)enable >> 1);
     return FGS_OK;
 }
 

@@ -185,7 +185,9 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
  * fgs_stage_timing_read synchronises on the recorded events, ADDS the elapsed milliseconds per
  * stage to ms[FGS_NUM_STAGES] and the number of launches to count[FGS_NUM_STAGES], and clears
  * the record.  Stage order: project, depth_sort, dup_emit, tile_sort, tile_ranges,
- * composite_fwd, composite_bwd, project_bwd. */
+ * composite_fwd, composite_bwd, project_bwd.
+ * enable: 0 = off, 1 = all stages, otherwise a mask with bit (stage + 1) per selected stage -- every event
+ * pair costs a few microseconds of stream time, so a benchmark times only the kernel it reports. */
 #define FGS_NUM_STAGES 8
 int fgs_stage_timing_enable(int enable);
 int fgs_stage_timing_read(float *ms, int32_t *count);
