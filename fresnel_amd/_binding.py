@@ -41,7 +41,7 @@ class FgsSavedLayout(ctypes.Structure):
                 ("dup_capacity", ctypes.c_size_t),
                 ("tiles_x", ctypes.c_int32), ("tiles_y", ctypes.c_int32),
                 ("seg_off", ctypes.c_size_t), ("seg_tile", ctypes.c_size_t), ("seg_ckpt", ctypes.c_size_t),
-                ("seg_capacity", ctypes.c_size_t)]
+                ("seg_capacity", ctypes.c_size_t), ("seg_len", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class FgsAsmDims(ctypes.Structure):

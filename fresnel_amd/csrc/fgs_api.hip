@@ -17,6 +17,7 @@ void fgs_set_error(const char *fmt, ...) {
 
 // ---- per-stage event timers -------------------------------------------------------------
 #include <mutex>
+#include <stdlib.h>
 #include <vector>
 namespace {
 struct StageRec { int stage; hipEvent_t a, b; };
@@ -98,7 +99,13 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     if (d->use_phase) o = align256(o + (dcap / FGS_PHASE_CKPT + B * p->tiles + 2) * 8 * 64 * 4);
     p->s_layer = o;
     if (layers > 1) o = align256(o + B * N * 4);
-    const size_t ucap = dcap / FGS_SEG + B * layers * p->tiles;
+    // depth-segment length: shorter segments = more, shorter backward work units; pays off when the launch would
+    // not fill the chip a few times over (config 2: -5 %, config 5: -3 %), costs 1 % at config 3's size.  The
+    // row-split forward used for saturation_skip stages 128 records per chunk and needs 128.
+    const char *fp = getenv("FGS_FWD_PARTS");  // A/B switch: the row-split forward (0) also needs 128
+    L.seg_len = (B * N <= 200000 && !d->saturation_skip && !(fp && atoi(fp) == 0)) ? 64 : FGS_SEG;
+    L.reserved = 0;
+    const size_t ucap = dcap / L.seg_len + B * layers * p->tiles;
     L.seg_off = o; L.seg_tile = o; L.seg_ckpt = o; L.seg_capacity = 0;
     if (!d->use_phase) {
         L.seg_capacity = ucap;

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(BWD ? 64 : 64 * ASM_FWD_PARTS) void k_asm_splat(
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
     const uint32_t *__restrict__ dup_off, float2 *__restrict__ field, float *__restrict__ grad_rows,
     float2 *__restrict__ dw, const uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg_off,
-    const uint32_t *__restrict__ seg_tile) {
+    const uint32_t *__restrict__ seg_tile, uint32_t seg_len) {
     // Forward: the splat is a plain sum, so the list is cut into NP parts, one per wave (own LDS staging, no block
     // barrier in the walk) and the partial fields are added in part order at the end -- the launch is latency-bound
     // by its longest lists.  Backward: one wave per depth-segment unit.
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(BWD ? 64 : 64 * ASM_FWD_PARTS) void k_asm_splat(
     const uint32_t lane = threadIdx.x & 63u, lx = lane & 7u, ly = lane >> 3;
     const uint32_t wave = NP > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     const uint32_t wofs = wave * ACH;  // this wave's slice of the staging arrays
-    uint32_t start = ranges[2 * key] + seg * FGS_SEG;
-    uint32_t end = BWD ? min(ranges[2 * key + 1], start + FGS_SEG) : ranges[2 * key + 1];
+    uint32_t start = ranges[2 * key] + seg * seg_len;
+    uint32_t end = BWD ? min(ranges[2 * key + 1], start + seg_len) : ranges[2 * key + 1];
     if (NP > 1) {  // this wave's part of the list (whole chunks)
         const uint32_t per = ((end - start + NP * ACH - 1) / (NP * ACH)) * ACH;
         start = min(end, start + wave * per);
@@ -748,7 +748,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
                        reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, (float2 *)nullptr,
-                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
     FGS_LAUNCH_CHECK("k_asm_splat");
     if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
@@ -831,7 +831,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows, (float2 *)nullptr,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.counters),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_tile));
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_tile), (uint32_t)p.base.L.seg_len);
     FGS_LAUNCH_CHECK("k_asm_splat_bwd");
     fgs_stage_end(ST_COMPOSITE_BWD, st);
     fgs_stage_begin(ST_PROJECT_BWD, st);
@@ -879,7 +879,7 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
                        reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, dw,
-                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
     FGS_LAUNCH_CHECK("k_wave_splat");
     hipError_t e = hipMemsetAsync(scal, 0, (size_t)B * 4 * sizeof(float), st);
     if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
@@ -935,7 +935,7 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), gfield, rows, gdw,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.counters),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_tile));
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_tile), (uint32_t)p.base.L.seg_len);
     FGS_LAUNCH_CHECK("k_wave_splat_bwd");
     fgs_stage_end(ST_COMPOSITE_BWD, st);
     fgs_stage_begin(ST_PROJECT_BWD, st);

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, uint32_t *
                                                      const uint32_t *__restrict__ lens,
                                                      uint32_t *__restrict__ tile_order,
                                                      uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_tile,
-                                                     uint32_t *__restrict__ counters) {
+                                                     uint32_t *__restrict__ counters, uint32_t seg_len) {
     __shared__ uint32_t hist[64];
     __shared__ uint32_t maxc;
     __shared__ unsigned long long wsum64[16];
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, uint32_t *
     unsigned long long v = 0;
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t len = len_of(t);
-        v += ((unsigned long long)len << 32) | ((len + FGS_SEG - 1) / FGS_SEG);
+        v += ((unsigned long long)len << 32) | ((len + seg_len - 1) / seg_len);
     }
     unsigned long long x = v;  // inclusive scan inside the wave
 #pragma unroll
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, uint32_t *
     __syncthreads();
     unsigned long long off64 = wsum64[wave] + x - v;
     for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t len = len_of(t), n = (len + FGS_SEG - 1) / FGS_SEG;
+        const uint32_t len = len_of(t), n = (len + seg_len - 1) / seg_len;
         const uint32_t off = (uint32_t)off64, lstart = (uint32_t)(off64 >> 32);
         if (lens) { ranges[2 * t] = lstart; ranges[2 * t + 1] = lstart + len; }
         if (seg_off) {
@@ -472,7 +472,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         fgs_stage_end(ST_DUP_EMIT, st);
         fgs_stage_begin(ST_TILE_RANGES, st);
         hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ntiles_all, ranges, lens, tile_order, seg_off,
-                           seg_tile, counters);
+                           seg_tile, counters, (uint32_t)p.L.seg_len);
         FGS_LAUNCH_CHECK("k_tile_order");
         fgs_stage_end(ST_TILE_RANGES, st);
         fgs_stage_begin(ST_TILE_SORT, st);
@@ -508,7 +508,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     hipLaunchKernelGGL(k_tile_ranges, dim3(rgrid), dim3(256), 0, st, counters, ks, ranges);
     FGS_LAUNCH_CHECK("k_tile_ranges");
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ntiles_all, ranges, (const uint32_t *)nullptr,
-                       tile_order, seg_off, seg_tile, counters);
+                       tile_order, seg_off, seg_tile, counters, (uint32_t)p.L.seg_len);
     FGS_LAUNCH_CHECK("k_tile_order");
     fgs_stage_end(ST_TILE_RANGES, st);
     return FGS_OK;

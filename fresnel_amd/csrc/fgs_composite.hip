@@ -295,18 +295,18 @@ __global__ __launch_bounds__(64 * NP) void k_blend_fwd_parts(
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, float *__restrict__ pix_state,
     float *__restrict__ out_rgb, float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off,
-    float *__restrict__ seg_ckpt) {
+    float *__restrict__ seg_ckpt, uint32_t seg_len) {
     __shared__ float4 sh0[NP][64], sh1[NP][64], sh2[NP][64];
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    const uint32_t nseg = (c.end - c.start + FGS_SEG - 1) / FGS_SEG;
+    const uint32_t nseg = (c.end - c.start + seg_len - 1) / seg_len;
     const uint32_t spp = (nseg + NP - 1) / NP;  // segments per part
     const uint32_t first_seg = wave * spp;
     const bool active = first_seg < nseg;
-    const uint32_t pstart = c.start + first_seg * FGS_SEG;
-    const uint32_t pend = active ? min(c.end, pstart + spp * FGS_SEG) : pstart;
+    const uint32_t pstart = c.start + first_seg * seg_len;
+    const uint32_t pend = active ? min(c.end, pstart + spp * seg_len) : pstart;
     float *slot0 = seg_ckpt + (size_t)seg_off[c.tile] * (5 * 256) + lane;  // + s * 64 per sub-tile
     float T[4], Cr[4], Cg[4], Cb[4], Dm[4];
 #pragma unroll
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(64 * NP) void k_blend_fwd_parts(
     asm("" : "+v"(fx0), "+v"(fx1), "+v"(fy0));
     for (uint32_t base = pstart; base < pend; base += 64) {
         const uint32_t n = min(64u, pend - base);
-        if (base != pstart && ((base - c.start) % FGS_SEG) == 0) {  // LOCAL state in front of this segment
-            float *ck = slot0 + (size_t)((base - c.start) / FGS_SEG) * (5 * 256);
+        if (base != pstart && ((base - c.start) % seg_len) == 0) {  // LOCAL state in front of this segment
+            float *ck = slot0 + (size_t)((base - c.start) / seg_len) * (5 * 256);
 #pragma unroll
             for (int s = 0; s < 4; ++s) ckpt_store(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
         }
@@ -430,7 +430,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     const uint32_t *__restrict__ seg_tile, const float *__restrict__ seg_ckpt, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const uint32_t *__restrict__ dup_off,
     const float *__restrict__ pix_state, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
-    float *__restrict__ grad_rows, unsigned long long *__restrict__ dbg_ts, float t_eps, uint32_t fwd_parts) {
+    float *__restrict__ grad_rows, unsigned long long *__restrict__ dbg_ts, float t_eps, uint32_t fwd_parts,
+    uint32_t seg_len) {
     const unsigned long long dbg_t0 = dbg_ts ? wall_clock64() : 0ull;
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
@@ -443,12 +444,12 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     TileCtx c = tile_ctx_of(unit_tile, tiles, tiles_x, ranges);
     uint32_t rebase_seg = seg;  // first segment of this segment's list part if its checkpoint is part-local
     if (fwd_parts > 1) {
-        const uint32_t nseg = (c.end - c.start + FGS_SEG - 1) / FGS_SEG;
+        const uint32_t nseg = (c.end - c.start + seg_len - 1) / seg_len;
         const uint32_t spp = (nseg + fwd_parts - 1) / fwd_parts, first = seg / spp * spp;
         if (first != 0) rebase_seg = first;
     }
-    c.start += seg * FGS_SEG;
-    c.end = min(c.end, c.start + FGS_SEG);
+    c.start += seg * seg_len;
+    c.end = min(c.end, c.start + seg_len);
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const size_t HW = (size_t)W * H;
@@ -836,7 +837,7 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     hipLaunchKernelGGL((k_blend_fwd_parts<NP>), dim3(grid), dim3(64 * NP), 0, st, (uint32_t)p.tiles,          \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
                        p.d.background[1], p.d.background[2], tile_order, ranges, dup_ids, rec, pix, out_rgb,  \
-                       out_depth, seg_off, seg_ckpt)
+                       out_depth, seg_off, seg_ckpt, (uint32_t)p.L.seg_len)
         if (np == 1) FGS_PARTS_LAUNCH(1); else if (np == 2) FGS_PARTS_LAUNCH(2); else FGS_PARTS_LAUNCH(4);
 #undef FGS_PARTS_LAUNCH
         FGS_LAUNCH_CHECK("k_blend_fwd_parts");
@@ -897,7 +898,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const float *>(saved + p.L.pix_state), g_rgb, g_depth,
                        reinterpret_cast<float *>(scratch + p.s_grows), dbg,
-                       p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f, (uint32_t)(fwd_parts_of(p) == 1 ? 0 : fwd_parts_of(p)));
+                       p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f, (uint32_t)(fwd_parts_of(p) == 1 ? 0 : fwd_parts_of(p)), (uint32_t)p.L.seg_len);
     if (dbg) {
         (void)hipStreamSynchronize(st);
         std::vector<unsigned long long> h((size_t)ugrid * 4);

@@ -32,7 +32,8 @@ extern "C" {
 #define FGS_EUNSUPPORTED (-3)
 
 #define FGS_TILE 16        /* tile edge in pixels */
-#define FGS_SEG 128        /* list entries per backward work unit (depth segment of a tile's list) */
+#define FGS_SEG 128        /* largest depth segment: list entries per backward work unit; a call uses
+                              FgsSavedLayout.seg_len (64 for small problems, else FGS_SEG)            */
 #define FGS_PHASE_CKPT 8   /* list entries between (A, Phi) checkpoints on the phase path */
 #define FGS_CAMERA_FLOATS 24
 
@@ -86,7 +87,10 @@ typedef struct FgsSavedLayout {
     size_t seg_tile;   /* uint32 [Ucap]: (image,tile) of each unit; segment index = unit - seg_off    */
     size_t seg_ckpt;   /* float  [Ucap][5][4][64]: per-pixel C_r,C_g,C_b,A,D of the tile at the START
                                           of each unit with segment index >= 1 (written by the forward) */
-    size_t seg_capacity; /* Ucap = Dcap / FGS_SEG + B*T                                             */
+    size_t seg_capacity; /* Ucap = Dcap / seg_len + B*T                                             */
+    int32_t seg_len;     /* list entries per depth segment for these dims: 64 when B*N <= 200 000 (more,
+                            shorter work units for launches that would not fill the chip), else 128   */
+    int32_t reserved;
 } FgsSavedLayout;
 
 /* Sizes of the two caller-provided device buffers.  `saved` must stay untouched between

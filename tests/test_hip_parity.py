@@ -252,7 +252,8 @@ def test_full_size_properties_config3_shape():
     # duplicates == sum of per-Gaussian tile counts
     assert int(st1["tile_count"].sum()) == D
     # depth segments (work units of the backward): ceil(len / FGS_SEG) units per tile, in tile order
-    SEG = 128
+    SEG = int(st1["layout"].seg_len)
+    assert SEG in (64, 128)
     nseg = (rg[:, 1] - rg[:, 0] + SEG - 1) // SEG
     U = int(st1["counters"][2])
     assert U == int(nseg.sum()) and U == int(st1["seg_off"][-1])
@@ -352,7 +353,7 @@ def test_backward_is_bitwise_reproducible_at_config3_size():
 
 
 def test_long_lists_many_depth_segments_vs_oracle():
-    """Tiles whose lists span several depth segments (FGS_SEG = 128 entries): the backward restarts
+    """Tiles whose lists span several depth segments (64 entries each at this size): the backward restarts
     every segment from the forward's checkpoint, so gradients must still match the oracle, which
     walks each list in one piece.  1500 wide Gaussians over a 48x32 frame -> ~1000 entries per tile."""
     from oracle import fgs_oracle as orc
@@ -372,6 +373,7 @@ def test_long_lists_many_depth_segments_vs_oracle():
     st = _hip_stages([a[None] for a in arrs], cam, W, H, bg)
     lens = st["ranges"][0][:, 1] - st["ranges"][0][:, 0]
     assert lens.max() > 4 * 128, "test must cover tiles with several depth segments"
+    assert int(st["layout"].seg_len) == 64  # small problem: the shorter segments
     r = _oracle(arrs, ocam, bg)
     _check_integer_stages(st, 0, r, W, H)
     gI = rs.standard_normal((3, H, W)).astype(np.float32)
