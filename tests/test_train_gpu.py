@@ -33,3 +33,20 @@ def test_harness_wave_and_phase_renderers(tmp_path):
         assert len(hist) == 1 and "total" in hist[0] and hist[0]["total"] == hist[0]["total"]
         for p in model.parameters():
             assert torch.isfinite(p).all()
+
+
+
+def test_harness_spectral_losses_with_wave_renderer(tmp_path):
+    """SURVEY 8f N1 + N2 inside the harness: WaveFieldRenderer with the phase-retrieval, frequency-domain and
+    Helmholtz losses switched on (torch.fft on the GPU = rocFFT).  The epoch losses carry the three extra terms,
+    everything stays finite."""
+    from fresnel_amd.train import TrainingConfig, run_training
+    cfg = TrainingConfig(batch_size=2, epochs=1, lr=2e-3, image_size=64, feature_size=6, feature_dim=16,
+                         gaussians_per_patch=4, device="cuda:0", steps_per_epoch=3, save_interval=100,
+                         output_dir=str(tmp_path), log_interval=1000, use_wave_rendering=True,
+                         use_phase_retrieval_loss=True, use_frequency_loss=True, wave_equation_weight=1e-12)
+    model, hist = run_training(cfg, log=lambda *a: None)
+    assert len(hist) == 1 and {"phase_retrieval", "frequency", "wave_eq"} <= set(hist[0])
+    assert all(v == v and abs(v) < float("inf") for v in hist[0].values())
+    for p in model.parameters():
+        assert torch.isfinite(p).all()
