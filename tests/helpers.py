@@ -54,3 +54,21 @@ def synth_aniso(N, seed, opacity_max=1.0, spread=0.5, zmean=-2.0, smin=0.01, sma
     color = rs.random_sample((N, 3)).astype(np.float32)
     opacity = (rs.random_sample(N) * opacity_max).astype(np.float32)
     return pos, scale, quat, color, opacity
+
+
+def synth_decoder_like(N, seed):
+    """SURVEY §8(d) second distribution ("decoder-like", what an untrained DirectPatchDecoder emits,
+    reference scripts/models/gaussian_decoder_models.py:740-948): grid x,y in linspace(-1,1,s) with
+    s = floor(sqrt(N)), z = -2 - 2 U(0,1), scale ~ U(.13,.16), random unit quaternions.  Returns s*s Gaussians."""
+    rs = np.random.RandomState(seed)
+    s = int(np.floor(np.sqrt(N)))
+    lin = np.linspace(-1.0, 1.0, s)
+    gx, gy = np.meshgrid(lin, lin, indexing="xy")
+    M = s * s
+    pos = np.stack([gx.ravel(), gy.ravel(), -2.0 - 2.0 * rs.random_sample(M)], 1).astype(np.float32)
+    scale = (0.13 + 0.03 * rs.random_sample((M, 3))).astype(np.float32)
+    quat = rs.standard_normal((M, 4))
+    quat = (quat / np.linalg.norm(quat, axis=1, keepdims=True)).astype(np.float32)
+    color = rs.random_sample((M, 3)).astype(np.float32)
+    opacity = (0.4 + 0.2 * rs.random_sample(M)).astype(np.float32)
+    return pos, scale, quat, color, opacity
