@@ -7,17 +7,20 @@
 
 One "step" = one forward + backward pass of the rasterizer (project, depth sort, tile binning,
 composite, composite backward, projection backward) over one batch of synthetic images that is
-already resident in HBM, plus -- for N > 1 -- the RCCL all-reduce of the decoder-gradient
+already resident in HBM, called through the same nn.Module (TileBasedRenderer / ASMWaveFieldRenderer)
+the training harness calls, plus -- for N > 1 -- the RCCL all-reduce of the decoder-gradient
 bucket that the image-wise data-parallel training step performs.
 
-Workload = BASELINE.json configs[2] per GPU (the configuration the metric "512^2 render,
+Default workload = BASELINE.json configs[2] per GPU (the configuration the metric "512^2 render,
 1/2/4/8 MI355X" is quoted on): 32 768 Gaussians, 512x512, 8 images per GPU (64 over 8 GPUs),
 create_dummy_saag distribution (reference scripts/training/train_gaussian_decoder.py:760-778).
-Weak scaling: per-GPU work is fixed as N grows.
+Weak scaling: per-GPU work is fixed as N grows.  --workload config2|config4|config5 and
+--distribution decoder_like (SURVEY §8d's second distribution) select the other measured cases.
 
 Prints ONE JSON line (rank 0).  value = composited Gaussian-pixels per second, whole job.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -30,8 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (packed / dual-issue rate)
 DECODER_GRAD_FLOATS = 673_537  # DirectPatchDecoder gradient bucket (measured)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 WORKLOADS = {
     # name: (N gaussians, resolution, images per GPU)   -- BASELINE.json configs[1..4]
@@ -41,24 +45,90 @@ WORKLOADS = {
     "config5": (8192, 512, 1),     # ASMWaveFieldRenderer, per-channel wavelengths, hipFFT
 }
 
+# ALGORITHMIC work per stage.  P = composited Gaussian-pixels, D = tile
+# duplicates, N = Gaussians, B = images, HW = pixels per image, U = depth-segment units beyond each tile's first.
+FLOPS_PER_PAIR = {"composite_fwd": 23.0, "composite_bwd": 60.0,   # SURVEY §8d "Which roofline"
+                  "splat_fwd": 12.0, "splat_bwd": 36.0}            # 6 MACs per pair; adjoint 3x
+ASM_BYTES_PER_IMAGE = 0.36e9  # SURVEY §8d "ASM": 51 FFTs of 512^2 with the linearity trick, per direction
 
-def synth_batch(n_img, N, seed0, device):
-    """create_dummy_saag (TGD:760-778): pos~N(0,0.5^2), z-=2, scale .05, identity quat,
-    colour~U(0,1), opacity .8; generator seeded per image."""
-    pos, col = [], []
+
+def synth_batch(n_img, N, seed0, device, distribution="saag"):
+    """saag: create_dummy_saag (TGD:760-778): pos~N(0,0.5^2), z-=2, scale .05, identity quat, colour~U(0,1),
+    opacity .8.  decoder_like (what an untrained DirectPatchDecoder emits, GDM:740-948): grid x,y in
+    linspace(-1,1,s), s = floor(sqrt(N)), z = -2-2U, scale~U(.13,.16), random unit quats, opacity~U(.4,.6).
+    Generator seeded per image."""
+    pos, col, scl, quat, opa = [], [], [], [], []
     for i in range(n_img):
         g = torch.Generator().manual_seed(seed0 + i)
-        p = torch.randn(N, 3, generator=g) * 0.5
-        p[:, 2] -= 2
-        pos.append(p)
-        col.append(torch.rand(N, 3, generator=g))
-    pos = torch.stack(pos).to(device)
-    col = torch.stack(col).to(device)
-    scale = torch.full((n_img, N, 3), 0.05, device=device)
-    quat = torch.zeros(n_img, N, 4, device=device)
-    quat[..., 0] = 1
-    opa = torch.full((n_img, N), 0.8, device=device)
-    return pos, scale, quat, col, opa
+        if distribution == "decoder_like":
+            s = int(np.floor(np.sqrt(N)))
+            lin = torch.linspace(-1.0, 1.0, s)
+            gy, gx = torch.meshgrid(lin, lin, indexing="ij")
+            z = -2.0 - 2.0 * torch.rand(s * s, generator=g)
+            pos.append(torch.stack([gx.reshape(-1), gy.reshape(-1), z], 1))
+            scl.append(0.13 + 0.03 * torch.rand(s * s, 3, generator=g))
+            q = torch.randn(s * s, 4, generator=g)
+            quat.append(q / q.norm(dim=1, keepdim=True))
+            col.append(torch.rand(s * s, 3, generator=g))
+            opa.append(0.4 + 0.2 * torch.rand(s * s, generator=g))
+        else:
+            p = torch.randn(N, 3, generator=g) * 0.5
+            p[:, 2] -= 2
+            pos.append(p)
+            col.append(torch.rand(N, 3, generator=g))
+            scl.append(torch.full((N, 3), 0.05))
+            q = torch.zeros(N, 4)
+            q[:, 0] = 1
+            quat.append(q)
+            opa.append(torch.full((N,), 0.8))
+    return [torch.stack(t).to(device) for t in (pos, scl, quat, col, opa)]
+
+
+def pmc_traffic(run_key, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r02_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per the gfx950
+    correction of MI355X_MICROARCH.md).  None when that run was not profiled."""
+    if not os.path.exists(PMC_SUMMARY):
+        return None
+    run = json.load(open(PMC_SUMMARY)).get("runs", {}).get(run_key)
+    for row in (run or {}).get("kernels", []):
+        if row["kernel"] == kernel and row.get("hbm_bytes_corrected"):
+            return int(row["hbm_bytes_corrected"])
+    return None
+
+
+def cpu_baseline_leg(leaves, gI, gD, N, S):
+    """The reference's pure-PyTorch per-Gaussian-loop rasterizer cannot travel to this box, so the CPU baseline is
+    this repo's restatement of it (oracle/torch_loop.py, same algorithm / same per-iteration tensor work, checked
+    against the C oracle in tests/) on a bounded sample: the first 2048 Gaussians of image 0, forward + autograd
+    backward, on all host cores and on one thread; plus the scalar C oracle on two full images."""
+    from oracle import fgs_oracle as orc
+    from oracle import torch_loop as tl
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_sub = min(2048, N)
+    arrs = [t[0, :n_sub].detach().cpu().numpy() for t in leaves]
+    view = np.eye(4, dtype=np.float32)
+    gi, gd = gI[0].cpu().numpy(), gD[0].cpu().numpy()
+    fx = 0.8 * S
+    p_all, t_all = tl.timed_fwd_bwd(arrs, view, fx, fx, S / 2, S / 2, S, S, gi, gd, threads=cores)
+    p_one, t_one = tl.timed_fwd_bwd(arrs, view, fx, fx, S / 2, S / 2, S, S, gi, gd, threads=1)
+    ocam = orc.make_camera(view, fx, fx, S / 2, S / 2, S, S)
+    n_c = min(2, leaves[0].shape[0])
+    Pc, tc = 0, 0.0
+    for i in range(n_c):
+        full = [t[i].detach().cpu().numpy() for t in leaves]
+        t0 = time.perf_counter()
+        Pi, _, _ = orc.render_fwd_bwd_timed(*full, ocam, gI[i].cpu().numpy(), gD[i].cpu().numpy())
+        tc += time.perf_counter() - t0
+        Pc += Pi
+    return {"value": round(p_all / t_all, 1), "unit": "Gaussian-pixels/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_sub} Gaussians of image 0 @ {S}x{S} ({p_all} pairs), forward + autograd backward of the "
+                      f"pure-PyTorch per-Gaussian loop (oracle/torch_loop.py, restatement of DR:582-667) in {t_all:.2f} s "
+                      f"with torch.set_num_threads({cores})",
+            "one_thread": {"value": round(p_one / t_one, 1), "seconds": round(t_one, 2), "cores": 1},
+            "c_oracle": {"value": round(Pc / tc, 1), "cores": 1, "seconds": round(tc, 2),
+                         "sample": f"images 0..{n_c - 1} at full size ({Pc} pairs), scalar C restatement (oracle/fgs_oracle.c), fwd+bwd"},
+            "host_cpus_visible": os.cpu_count(), "note": "baseline, not the target (see roofline.frac)"}
 
 
 def main():
@@ -67,6 +137,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--distribution", default="saag", choices=["saag", "decoder_like"],
+                    help="synthetic Gaussian distribution (SURVEY 8d): create_dummy_saag or the ~3x heavier decoder-like grid")
     ap.add_argument("--images-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--saturation-skip", action="store_true",
@@ -102,7 +174,8 @@ def main():
         per_gpu = args.images_per_gpu
     cfg_id = int(args.workload[-1])
     # image-wise shard: rank r owns images [r*per_gpu, (r+1)*per_gpu)
-    pos, scale, quat, col, opa = synth_batch(per_gpu, N, 1000 * cfg_id + rank * per_gpu, device)
+    pos, scale, quat, col, opa = synth_batch(per_gpu, N, 1000 * cfg_id + rank * per_gpu, device, args.distribution)
+    N = pos.shape[1]  # decoder_like: floor(sqrt(N))^2
     phases = None
     g = torch.Generator().manual_seed(977 + rank)
     if args.workload == "config4":  # z snapped to 8 zone centres, edge-aware scale factor, phases U(0,1)
@@ -114,25 +187,27 @@ def main():
         phases = (torch.rand(per_gpu, N, generator=g) * 2 * np.pi).to(device).requires_grad_(True)
     leaves = [t.requires_grad_(True) for t in (pos, scale, quat, col, opa)]
     cam = R.Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
-    cam_t = R.pack_cameras(cam, device)
-    cfg = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, args.workload == "config4", 0.25, saturation_skip=args.saturation_skip)
-    asm = None
-    if args.workload == "config5":
-        asm = R.ASMWaveFieldRenderer(S, S).to(device)
+    is_asm = args.workload == "config5"
+    if is_asm:
+        ren = R.ASMWaveFieldRenderer(S, S).to(device)
         wl = torch.tensor([0.0635, 0.05, 0.041], device=device, requires_grad=True)
+    else:
+        ren = R.TileBasedRenderer(S, S, use_phase_blending=args.workload == "config4", phase_amplitude=0.25,
+                                  saturation_skip=args.saturation_skip).to(device)
     g = torch.Generator().manual_seed(4242 + rank)
     gI = torch.randn(per_gpu, 3, S, S, generator=g).to(device)
     gD = (torch.randn(per_gpu, S, S, generator=g) * 0.1).to(device)
     bucket = torch.zeros(DECODER_GRAD_FLOATS, device=device) if world > 1 else None
 
     def step():
+        # the nn.Module call the training harness makes (fresnel_amd/train.py train_step): batched tensors, one Camera
         for t in leaves:
             t.grad = None
-        if asm is not None:
-            img = asm(*leaves, cam, phases=phases, wavelengths_rgb=wl)
+        if is_asm:
+            img = ren(*leaves, cam, phases=phases, wavelengths_rgb=wl)
             torch.autograd.backward([img], [gI])
         else:
-            img, dep = R.GaussianRenderer.apply(*leaves, phases, cam_t, cfg)
+            img, dep = ren(*leaves, cam, return_depth=True, phases=phases)
             torch.autograd.backward([img, dep], [gI, gD])
         if bucket is not None:
             dist.all_reduce(bucket)  # decoder-gradient bucket of the DP training step
@@ -148,24 +223,25 @@ def main():
     warm_stage = B.stage_timing_read()
     B.stage_timing_enable(False)
 
-    # unit of work: composited Gaussian-pixels of this rank's batch (device-side count)
+    # unit of work: composited Gaussian-pixels of this rank's batch (device-side count over the reference bboxes,
+    # which are the same for every renderer: DR:594-597 / DR:1240-1247)
     cfg0 = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, False, 0.25)
-    _, _, saved, dims, _ = R.forward_raw(*[t.detach() for t in leaves], None, cam_t, cfg0)
+    _, _, saved, dims, _ = R.forward_raw(*[t.detach() for t in leaves], None, R.pack_cameras(cam, device), cfg0)
     pairs_dev = torch.zeros(1, dtype=torch.int64, device=device)
-    import ctypes
     B.check(B.load().fgs_count_pairs(ctypes.byref(dims), ctypes.c_void_p(saved.data_ptr()),
                                      ctypes.c_void_p(pairs_dev.data_ptr()),
                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "fgs_count_pairs")
     st = R.inspect_saved(saved, dims)
     D_local = int(st["counters"][0].item())
-    U_local = int(st["counters"][2].item())  # backward work units = depth segments of FGS_SEG list entries
+    U_local = int(st["counters"][2].item())  # backward work units = depth segments
     pairs_local = int(pairs_dev.item())
     del saved, st
 
-    # timed region: only the dominant kernel carries an event pair (each pair costs stream time: all eight stages
+    # timed region: only the dominant kernel carries an event pair (each pair costs stream time: all stages
     # together slowed the step by 2.5 %)
     warm_avg = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in warm_stage.items()}
-    dom_stage = max(("composite_bwd", "composite_fwd"), key=lambda k: warm_avg.get(k, 0.0))  # --warmup 0: the backward
+    compute_stages = ("splat_fwd", "field_fwd", "field_bwd", "splat_bwd") if is_asm else ("composite_fwd", "composite_bwd")
+    dom_stage = max(reversed(compute_stages), key=lambda k: warm_avg.get(k, 0.0))  # --warmup 0: the backward
     B.stage_timing_enable(True, stages=[dom_stage])
     B.stage_timing_read()
     if dist is not None:
@@ -195,73 +271,82 @@ def main():
     value = pairs_all / (elapsed / args.steps)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (rank 0's launches, hipEvent-timed in the library
-        # on the stream the kernels run on, over the timed region) ----
+        # ---- roofline (rank 0's launches, hipEvent-timed in the library on the stream the kernels run on) ----
         HW = S * S
-        alg_bytes = {  # ALGORITHMIC bytes per launch (DESIGN.md "Kernels"), B images per launch
-            # + 5 floats x 256 pixels of checkpoint per depth segment after a tile's first (written / read once)
-            "composite_fwd": per_gpu * (40 * HW) + 52 * D_local + 5120 * max(U_local - per_gpu * (S // 16) ** 2, 0),
-            "composite_bwd": per_gpu * (36 * HW) + (52 + 40) * D_local + 5120 * max(U_local - per_gpu * (S // 16) ** 2, 0),
+        tiles = per_gpu * ((S + 15) // 16) ** 2
+        extra_units = max(U_local - tiles, 0)  # checkpoints: 5 floats x 256 pixels per depth segment after a tile's first
+        row_bytes = 4 * 48 if args.workload == "config4" else 40
+        alg_bytes = {  # ALGORITHMIC HBM bytes per launch of each stage, B images per launch
+            "project": per_gpu * N * (56 + 48 + 8),
+            "depth_sort": per_gpu * N * 8 * (1 + 2 * 4),
+            "list_building": per_gpu * N * 8 + 4 * D_local,  # dup_emit + tile_ranges + tile_sort stages together
+            "composite_fwd": per_gpu * (40 * HW) + 52 * D_local + 5120 * extra_units,
+            "composite_bwd": per_gpu * (36 * HW) + (52 + row_bytes) * D_local + 5120 * extra_units,
+            "project_bwd": row_bytes * D_local + per_gpu * N * 2 * 56,
+            "field_fwd": ASM_BYTES_PER_IMAGE * per_gpu, "field_bwd": ASM_BYTES_PER_IMAGE * per_gpu,
         }
-        alg_flops = {"composite_fwd": 23.0 * pairs_local, "composite_bwd": 60.0 * pairs_local}
-        # the dominant kernel's average launch duration comes from the timed region (`stage`); the per-stage split
-        # of the other stages was taken during the warm-up steps of this same run (`warm_avg`)
+        # per-stage average launch time: the dominant kernel's comes from the timed region (`stage`); the split of
+        # the other stages was taken during the warm-up steps of this same run (`warm_avg`)
         avg_ms = dict(warm_avg)
-        dom = dom_stage
-        if stage[dom][1]:
-            avg_ms[dom] = stage[dom][0] / stage[dom][1]
-        dur = avg_ms[dom] * 1e-3
-        gbs = alg_bytes[dom] / dur / 1e9 if dur > 0 else 0.0
-        tfl = alg_flops[dom] / dur / 1e12 if dur > 0 else 0.0
-        # HBM bytes of that kernel from the committed rocprofv3 PMC passes of this same workload
-        # (profiles/r01_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) per launch, gfx950 correction)
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if args.workload == "config3" and per_gpu == 8 and os.path.exists(pmc_path):
-            for row in json.load(open(pmc_path))["kernels"]:
-                if row["kernel"].startswith("k_" + dom) and row.get("hbm_bytes_corrected"):
-                    traffic = int(row["hbm_bytes_corrected"])
-                    break
-        # The compositing kernels are compute (vector-ALU) bound, not HBM bound: the
-        # roofline that bounds them is the f32 rate, 157.3 TFLOP/s -- on gfx950 the dense f32 MFMA
-        # peak and the f32 vector peak are the same number; the kernel uses the vector ALU.
-        roofline = {"kernel": "k_" + dom, "bound": "mfma", "achieved": round(tfl, 3), "peak": FP32_VECTOR_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": round(tfl / FP32_VECTOR_PEAK_TF, 5), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms[dom], 4),
-                    "algorithmic_flops_per_launch": int(alg_flops[dom]),
-                    "algorithmic_bytes_fwd": int(alg_bytes["composite_fwd"]), "algorithmic_bytes_bwd": int(alg_bytes["composite_bwd"]),
-                    "flop_model": "SURVEY 8d: 23 flop per Gaussian-pixel forward, 60 backward; f32 MFMA peak == f32 vector peak",
-                    "hbm": {"achieved_GBs": round(gbs, 2), "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 5),
-                            "algorithmic_bytes_per_launch": int(alg_bytes[dom])},
-                    "stage_avg_ms": {k: round(v, 4) for k, v in avg_ms.items()},
-                    "stage_avg_ms_note": "dominant kernel: timed region; other stages: warm-up steps of this run"}
+        if stage[dom_stage][1]:
+            avg_ms[dom_stage] = stage[dom_stage][0] / stage[dom_stage][1]
+        avg_ms["list_building"] = sum(avg_ms.get(k, 0.0) for k in ("dup_emit", "tile_sort", "tile_ranges"))
+
+        def stage_roofline(name):
+            dur = avg_ms.get(name, 0.0) * 1e-3
+            if dur <= 0:
+                return None
+            if name in FLOPS_PER_PAIR:  # per-pair blend / splat arithmetic on the vector ALU (no MFMA: gather/blend)
+                tfl = FLOPS_PER_PAIR[name] * pairs_local / dur / 1e12
+                return {"bound": "valu", "achieved": round(tfl, 3), "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(tfl / FP32_VECTOR_PEAK_TF, 5), "avg_launch_ms": round(avg_ms[name], 4),
+                        "algorithmic_flops_per_launch": int(FLOPS_PER_PAIR[name] * pairs_local),
+                        "algorithmic_bytes_per_launch": int(alg_bytes[name]) if name in alg_bytes else None}
+            gbs = alg_bytes[name] / dur / 1e9
+            return {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 5), "avg_launch_ms": round(avg_ms[name], 4),
+                    "algorithmic_bytes_per_launch": int(alg_bytes[name])}
+
+        kernel_names = {"composite_fwd": "k_blend_fwd_parts" if args.workload != "config4" and not args.saturation_skip else "k_composite_fwd",
+                        "composite_bwd": "k_composite_bwd_phase" if args.workload == "config4" else "k_composite_bwd",
+                        "splat_fwd": "k_asm_splat<false>", "splat_bwd": "k_asm_splat<true>",
+                        "field_fwd": "hipFFT C2C + k_asm_transfer/accumulate/max/output",
+                        "field_bwd": "k_asm_output_bwd + hipFFT C2C + k_asm_accumulate_bwd"}
+        run_key = f"{args.workload}_{args.distribution}_b{per_gpu}"
+        roofline = {"kernel": kernel_names[dom_stage], "stage": dom_stage}
+        roofline.update(stage_roofline(dom_stage))
+        traffic = pmc_traffic(run_key, kernel_names[dom_stage].split("<")[0]) if not args.saturation_skip else None
+        roofline["traffic"] = traffic
+        roofline["traffic_source"] = (f"profiles/r02_pmc_summary.json run {run_key}: separate rocprofv3 --pmc FETCH_SIZE / "
+                                      "WRITE_SIZE passes of this command, 2*FETCH_SIZE + WRITE_SIZE per launch"
+                                      if traffic is not None else None)
+        roofline["flop_model"] = ("SURVEY 8d: 23 flop per Gaussian-pixel forward, 60 backward (phase path: same count, its extra "
+                                  "cos/sin/divide work is not credited); splat 12 / 36; peak = fp32 vector peak (plain, "
+                                  "non-packed VALU code tops out at about half of it, DESIGN.md section 4)")
+        stages = {}
+        for name in ("project", "depth_sort", "list_building", "composite_fwd", "composite_bwd", "splat_fwd", "field_fwd",
+                     "field_bwd", "splat_bwd", "project_bwd"):
+            r = stage_roofline(name)
+            if r is not None:
+                stages[name] = r
+        roofline["stages"] = stages
+        roofline["stage_avg_ms"] = {k: round(v, 4) for k, v in avg_ms.items() if v > 0}
+        roofline["stage_avg_ms_note"] = "dominant kernel: timed region; other stages: warm-up steps of this run (every stage bracketed)"
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import fgs_oracle as orc
-            ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
-            n_cpu = min(4, per_gpu)  # bounded sample: ~10 s of single-core work
-            P1, tcpu = 0, 0.0
-            for i in range(n_cpu):
-                arrs = [t[i].detach().cpu().numpy() for t in leaves]
-                gi, gd = gI[i].cpu().numpy(), gD[i].cpu().numpy()
-                tc = time.perf_counter()
-                Pi, _, _ = orc.render_fwd_bwd_timed(*arrs, ocam, gi, gd)
-                tcpu += time.perf_counter() - tc
-                P1 += Pi
-            cpu_baseline = {"value": round(P1 / tcpu, 1), "unit": "Gaussian-pixels/s", "cores": 1, "kind": "port",
-                            "sample": f"images 0..{n_cpu - 1} of the batch ({N} Gaussians @ {S}x{S} each, {P1} pairs), "
-                                      f"fwd+bwd in {tcpu:.2f} s, scalar C restatement (oracle/fgs_oracle.c)",
-                            "host_cpus": os.cpu_count()}
+            cpu_baseline = cpu_baseline_leg(leaves, gI, gD, N, S)
+        dist_name = {"saag": "create_dummy_saag distribution", "decoder_like": "decoder-like distribution (SURVEY 8d)"}[args.distribution]
         line = {
             "metric": "composited Gaussian-pixels/sec + train-step ms, 512^2 render",
             "value": value, "unit": "Gaussian-pixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE {args.workload}: {N} Gaussians, {S}x{S}, {per_gpu} images/GPU "
-                                   f"({per_gpu * world} global), create_dummy_saag distribution, rasterizer fwd+bwd"
-                                   + (", + RCCL all-reduce of the 2.7 MB decoder-grad bucket" if world > 1 else ""),
+                                   f"({per_gpu * world} global), {dist_name}, rasterizer fwd+bwd through the nn.Module call"
+                                   + (", + all-reduce of the 2.7 MB decoder-grad bucket (" + args.backend + ")" if world > 1 else ""),
                        "gaussians": N, "resolution": S, "images_per_gpu": per_gpu, "global_batch": per_gpu * world,
-                       "pairs_per_step": int(pairs_all), "tile_duplicates_rank0": D_local, "depth_segments_rank0": U_local,
+                       "distribution": args.distribution, "pairs_per_step": int(pairs_all),
+                       "tile_duplicates_rank0": D_local, "depth_segments_rank0": U_local,
                        "saturation_skip": bool(args.saturation_skip), "parallelism": f"image-wise dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

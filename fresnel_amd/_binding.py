@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
 ]
 
 STAGES = ["project", "depth_sort", "dup_emit", "tile_sort", "tile_ranges", "composite_fwd",
-          "composite_bwd", "project_bwd"]
+          "composite_bwd", "project_bwd", "splat_fwd", "field_fwd", "field_bwd", "splat_bwd"]
 
 
 class FgsDims(ctypes.Structure):
@@ -29,7 +29,9 @@ class FgsDims(ctypes.Structure):
                 ("width", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("max_radius", ctypes.c_float), ("background", ctypes.c_float * 3),
                 ("use_phase", ctypes.c_int32), ("phase_amplitude", ctypes.c_float),
-                ("num_cameras", ctypes.c_int32), ("saturation_skip", ctypes.c_int32)]
+                ("num_cameras", ctypes.c_int32), ("saturation_skip", ctypes.c_int32),
+                ("seg_len", ctypes.c_int32), ("fwd_variant", ctypes.c_int32), ("bin_mode", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class FgsSavedLayout(ctypes.Structure):
@@ -115,7 +117,8 @@ def check(rc, what):
 
 
 def make_dims(batch, num_gaussians, width, height, max_radius=64.0, background=(0.0, 0.0, 0.0),
-              use_phase=False, phase_amplitude=0.25, num_cameras=1, saturation_skip=False):
+              use_phase=False, phase_amplitude=0.25, num_cameras=1, saturation_skip=False, tuning=None):
+    """`tuning`: optional dict of FgsDims overrides {seg_len, fwd_variant, bin_mode} (0 / absent = automatic)."""
     d = FgsDims()
     d.batch, d.num_gaussians, d.width, d.height = int(batch), int(num_gaussians), int(width), int(height)
     d.max_radius = float(max_radius)
@@ -125,6 +128,10 @@ def make_dims(batch, num_gaussians, width, height, max_radius=64.0, background=(
     d.phase_amplitude = float(phase_amplitude)
     d.num_cameras = int(num_cameras)
     d.saturation_skip = 1 if saturation_skip else 0
+    for k, v in (tuning or {}).items():
+        if k not in ("seg_len", "fwd_variant", "bin_mode"):
+            raise FgsError(f"unknown tuning field {k!r}")
+        setattr(d, k, int(v))
     return d
 
 

@@ -26,6 +26,7 @@ unsigned g_timing = 0;  // bit (stage) set: that stage is bracketed by events
 std::vector<StageRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open[FGS_NUM_STAGES];
+
 hipEvent_t take_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -64,6 +65,13 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
                       d->num_gaussians, d->width, d->height, (double)d->max_radius, d->num_cameras);
         return FGS_EINVAL;
     }
+    const int fv = d->fwd_variant, afv = fv < 0 ? -fv : fv;
+    if ((d->seg_len != 0 && d->seg_len != 64 && d->seg_len != FGS_SEG) || (afv != 0 && afv != 1 && afv != 2 && afv != 4) ||
+        d->bin_mode < 0 || d->bin_mode > 2 || d->reserved != 0) {
+        fgs_set_error("invalid tuning: seg_len=%d fwd_variant=%d bin_mode=%d reserved=%d", d->seg_len, d->fwd_variant,
+                      d->bin_mode, d->reserved);
+        return FGS_EINVAL;
+    }
     const size_t B = d->batch, N = d->num_gaussians;
     if (B * N >= (1ull << 31)) { fgs_set_error("B*N too large"); return FGS_EINVAL; }
     memset(p, 0, sizeof(*p));
@@ -99,11 +107,41 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     if (d->use_phase) o = align256(o + (dcap / FGS_PHASE_CKPT + B * p->tiles + 2) * 8 * 64 * 4);
     p->s_layer = o;
     if (layers > 1) o = align256(o + B * N * 4);
+    // ---- tuning: a pure function of the dims (no environment, so a forward and its backward always agree) ----
+    // Forward work split.  Blend path: depth-split forward with 4 list parts per tile, 1 part once the launch has
+    // enough tiles to fill the chip several times over (fwd ms, 8 images x 1024 tiles: row-split 0.642, 2 parts
+    // 0.586, 4 parts 0.588; config 2 (4096 tiles): 0.169 / 0.167 / 0.134; 32 images: one wave per tile 2.215,
+    // 1 part 2.173, 2 parts 2.27).  saturation_skip runs on the row-split forward; its waves per tile: two halve
+    // the serial length of the longest lists, one wins with >= 24576 tiles, four for launches that cannot fill the
+    // chip once.  Phase path: the recurrence is latency-bound (serial cos / divide chain per pixel), four waves.
+    const uint32_t grid_tiles = (uint32_t)(B * p->tiles);
+    if (d->use_phase) {
+        p->fwd_parts = 0;
+        p->fwd_waves = afv ? afv : 4;
+        p->fwd_variant = -p->fwd_waves;
+    } else if (d->saturation_skip || fv < 0) {
+        p->fwd_parts = 0;
+        p->fwd_waves = fv < 0 ? afv : (grid_tiles >= 24576u ? 1 : (grid_tiles <= 6144u ? 4 : 2));
+        p->fwd_variant = -p->fwd_waves;
+    } else {
+        p->fwd_parts = fv > 0 ? fv : (grid_tiles >= 24576u ? 1 : 4);
+        p->fwd_waves = p->fwd_parts;
+        p->fwd_variant = p->fwd_parts;
+    }
     // depth-segment length: shorter segments = more, shorter backward work units; pays off when the launch would
     // not fill the chip a few times over (config 2: -5 %, config 5: -3 %), costs 1 % at config 3's size.  The
-    // row-split forward used for saturation_skip stages 128 records per chunk and needs 128.
-    const char *fp = getenv("FGS_FWD_PARTS");  // A/B switch: the row-split forward (0) also needs 128
-    L.seg_len = (B * N <= 200000 && !d->saturation_skip && !(fp && atoi(fp) == 0)) ? 64 : FGS_SEG;
+    // row-split forward stages up to 128 records per chunk and needs 128.
+    const bool row_split = !d->use_phase && p->fwd_parts == 0;
+    if (row_split && d->seg_len == 64) {
+        fgs_set_error("seg_len=64 is not available with the row-split forward (saturation_skip / fwd_variant < 0)");
+        return FGS_EINVAL;
+    }
+    L.seg_len = d->seg_len ? d->seg_len : ((B * N <= 200000 && !row_split) ? 64 : FGS_SEG);
+    p->direct_binning = layers == 1 && p->tiles <= FGS_BIN_MAX_TILES && d->bin_mode != 2;
+    if (d->bin_mode == 1 && !p->direct_binning) {
+        fgs_set_error("bin_mode=1 (direct binning) needs a single layer and <= %d tiles per image", FGS_BIN_MAX_TILES);
+        return FGS_EINVAL;
+    }
     L.reserved = 0;
     const size_t ucap = dcap / L.seg_len + B * layers * p->tiles;
     L.seg_off = o; L.seg_tile = o; L.seg_ckpt = o; L.seg_capacity = 0;

@@ -19,6 +19,7 @@
 // accurate range reduction of sincosf.
 #include <hipfft/hipfft.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 #include "fgs_internal.h"
@@ -29,7 +30,6 @@ namespace {
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;
 constexpr int ACH = 64;
 constexpr int ASM_FWD_PARTS = 4;  // list parts (waves) per (image, plane, tile) in the forward splat
-constexpr int ST_ASM = ST_COMPOSITE_FWD;  // stage timers: ASM stages are accounted as "composite"
 
 struct AsmPlan {
     FgsAsmDims a;
@@ -51,36 +51,52 @@ struct AsmPlan {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // ---- hipFFT plan cache -----------------------------------------------------------------------
-struct FftKey { int h, w, batch; bool operator<(const FftKey &o) const { return std::tie(h, w, batch) < std::tie(o.h, o.w, o.batch); } };
-struct FftPlan { hipfftHandle handle; size_t work; };
-std::mutex g_fft_mu;
-std::map<FftKey, FftPlan> g_fft;
+// One plan per (device, H, W, batch), built on first use (host work; later calls only enqueue).  A hipFFT handle
+// carries its stream and work area as mutable state, so every use of a handle -- SetStream, SetWorkArea, Exec --
+// happens under that plan's own mutex: callers on different streams or threads that render the same shape on the
+// same device are serialised on the HOST for the few microseconds of the enqueue, and each transform runs on the
+// stream and in the work area of the call that enqueued it.  Plans are never shared between devices.
+struct FftKey {
+    int dev, h, w, batch;
+    bool operator<(const FftKey &o) const { return std::tie(dev, h, w, batch) < std::tie(o.dev, o.h, o.w, o.batch); }
+};
+struct FftPlan { hipfftHandle handle = 0; size_t work = 0; std::mutex mu; };
+std::mutex g_fft_mu;  // guards the map only
+std::map<FftKey, std::unique_ptr<FftPlan>> g_fft;
 
-int get_fft_plan(int H, int W, int batch, FftPlan *out) {
+int get_fft_plan(int H, int W, int batch, FftPlan **out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { fgs_set_error("hipGetDevice failed"); return FGS_ELAUNCH; }
     std::lock_guard<std::mutex> lk(g_fft_mu);
-    const FftKey key{H, W, batch};
+    const FftKey key{dev, H, W, batch};
     auto it = g_fft.find(key);
-    if (it != g_fft.end()) { *out = it->second; return FGS_OK; }
-    FftPlan pl{};
+    if (it != g_fft.end()) { *out = it->second.get(); return FGS_OK; }
+    std::unique_ptr<FftPlan> pl(new FftPlan());
     int n[2] = {H, W};
-    if (hipfftCreate(&pl.handle) != HIPFFT_SUCCESS) { fgs_set_error("hipfftCreate failed"); return FGS_ELAUNCH; }
-    if (hipfftSetAutoAllocation(pl.handle, 0) != HIPFFT_SUCCESS) { fgs_set_error("hipfftSetAutoAllocation failed"); return FGS_ELAUNCH; }
-    const hipfftResult r = hipfftMakePlanMany(pl.handle, 2, n, nullptr, 1, H * W, nullptr, 1, H * W, HIPFFT_C2C, batch, &pl.work);
-    if (r != HIPFFT_SUCCESS) { fgs_set_error("hipfftMakePlanMany(%dx%d x%d) failed: %d", H, W, batch, (int)r); return FGS_ELAUNCH; }
-    g_fft[key] = pl;
-    *out = pl;
+    if (hipfftCreate(&pl->handle) != HIPFFT_SUCCESS) { fgs_set_error("hipfftCreate failed"); return FGS_ELAUNCH; }
+    hipfftResult r = hipfftSetAutoAllocation(pl->handle, 0);
+    if (r == HIPFFT_SUCCESS)
+        r = hipfftMakePlanMany(pl->handle, 2, n, nullptr, 1, H * W, nullptr, 1, H * W, HIPFFT_C2C, batch, &pl->work);
+    if (r != HIPFFT_SUCCESS) {
+        (void)hipfftDestroy(pl->handle);
+        fgs_set_error("hipfftMakePlanMany(%dx%d x%d) failed: %d", H, W, batch, (int)r);
+        return FGS_ELAUNCH;
+    }
+    *out = pl.get();
+    g_fft[key] = std::move(pl);
     return FGS_OK;
 }
 
 int run_fft(int H, int W, int batch, float2 *data, int dir, void *work, hipStream_t st) {
-    FftPlan pl;
+    FftPlan *pl = nullptr;
     const int rc = get_fft_plan(H, W, batch, &pl);
     if (rc) return rc;
-    if (hipfftSetStream(pl.handle, st) != HIPFFT_SUCCESS || hipfftSetWorkArea(pl.handle, work) != HIPFFT_SUCCESS) {
+    std::lock_guard<std::mutex> lk(pl->mu);
+    if (hipfftSetStream(pl->handle, st) != HIPFFT_SUCCESS || hipfftSetWorkArea(pl->handle, work) != HIPFFT_SUCCESS) {
         fgs_set_error("hipfft stream/work-area setup failed");
         return FGS_ELAUNCH;
     }
-    const hipfftResult r = hipfftExecC2C(pl.handle, reinterpret_cast<hipfftComplex *>(data),
+    const hipfftResult r = hipfftExecC2C(pl->handle, reinterpret_cast<hipfftComplex *>(data),
                                          reinterpret_cast<hipfftComplex *>(data), dir);
     if (r != HIPFFT_SUCCESS) { fgs_set_error("hipfftExecC2C failed: %d", (int)r); return FGS_ELAUNCH; }
     return FGS_OK;
@@ -112,12 +128,12 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     p->v_total_bytes = o;
     p->work_big = p->work_small = 0;
     if (need_fft) {
-        FftPlan big, small;
+        FftPlan *big = nullptr, *small = nullptr;
         int r2 = get_fft_plan(a->height, a->width, (int)(B * P * 3), &big);
         if (r2) return r2;
         r2 = get_fft_plan(a->height, a->width, (int)(B * 3), &small);
         if (r2) return r2;
-        p->work_big = big.work; p->work_small = small.work;
+        p->work_big = big->work; p->work_small = small->work;
     }
     o = p->base.s_total;
     p->c_acc = o; o = align256(o + B * 3 * HW * 8);
@@ -734,7 +750,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
         return rc;
     fgs_stage_end(ST_PROJECT, st);
     if ((rc = fgs_launch_binning(p.base, sv, sc, st))) return rc;
-    fgs_stage_begin(ST_ASM, st);
+    fgs_stage_begin(ST_SPLAT_FWD, st);
     float2 *field = reinterpret_cast<float2 *>(sv + p.v_field);
     float2 *htab = reinterpret_cast<float2 *>(sv + p.v_htab);
     float2 *total = reinterpret_cast<float2 *>(sv + p.v_total);
@@ -750,6 +766,8 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, (float2 *)nullptr,
                        (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
     FGS_LAUNCH_CHECK("k_asm_splat");
+    fgs_stage_end(ST_SPLAT_FWD, st);
+    fgs_stage_begin(ST_FIELD_FWD, st);
     if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
@@ -772,7 +790,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     hipLaunchKernelGGL(k_asm_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, inv_hw,
                        a.background[0], a.background[1], a.background[2], total, scal, out_rgb);
     FGS_LAUNCH_CHECK("k_asm_output");
-    fgs_stage_end(ST_ASM, st);
+    fgs_stage_end(ST_FIELD_FWD, st);
     return FGS_OK;
 }
 
@@ -798,7 +816,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     float *scal = reinterpret_cast<float *>(sv + p.v_scal);
     float2 *gtot = reinterpret_cast<float2 *>(sc + p.c_acc);
     const float inv_hw = 1.0f / (float)HW;
-    fgs_stage_begin(ST_COMPOSITE_BWD, st);
+    fgs_stage_begin(ST_FIELD_BWD, st);
     hipError_t e = hipMemsetAsync(g_wavelengths, 0, 3 * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(scal + B, 0, 2 * (size_t)B * sizeof(float), st);
     if (e != hipSuccess) { fgs_set_error("memset g_wavelengths: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
@@ -819,6 +837,8 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     FGS_LAUNCH_CHECK("k_asm_accumulate_bwd");
     // adjoint of the forward FFT is the unnormalised inverse FFT
     if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
+    fgs_stage_end(ST_FIELD_BWD, st);
+    fgs_stage_begin(ST_SPLAT_BWD, st);
     const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units
     float *rows = reinterpret_cast<float *>(sc + p.base.s_grows);
     hipLaunchKernelGGL((k_asm_splat<true, false>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
@@ -833,7 +853,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_tile), (uint32_t)p.base.L.seg_len);
     FGS_LAUNCH_CHECK("k_asm_splat_bwd");
-    fgs_stage_end(ST_COMPOSITE_BWD, st);
+    fgs_stage_end(ST_SPLAT_BWD, st);
     fgs_stage_begin(ST_PROJECT_BWD, st);
     if ((rc = fgs_launch_asm_project_bwd(p.base, cameras, pos, scale, quat, color, phase, a.phase_channels, sv, rows,
                                          g_pos, g_scale, g_quat, g_color, g_opacity, g_phase, st)))
@@ -867,7 +887,7 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
     if ((rc = fgs_launch_project(p.base, cameras, pos, scale, quat, color, opacity, sv, st))) return rc;
     fgs_stage_end(ST_PROJECT, st);
     if ((rc = fgs_launch_binning(p.base, sv, sc, st))) return rc;
-    fgs_stage_begin(ST_ASM, st);
+    fgs_stage_begin(ST_SPLAT_FWD, st);
     float2 *field = reinterpret_cast<float2 *>(sv + p.v_field);
     float2 *dw = reinterpret_cast<float2 *>(sv + p.v_dw);
     float *scal = reinterpret_cast<float *>(sv + p.v_scal);
@@ -881,6 +901,8 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, dw,
                        (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
     FGS_LAUNCH_CHECK("k_wave_splat");
+    fgs_stage_end(ST_SPLAT_FWD, st);
+    fgs_stage_begin(ST_FIELD_FWD, st);
     hipError_t e = hipMemsetAsync(scal, 0, (size_t)B * 4 * sizeof(float), st);
     if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     unsigned gx = (unsigned)((3 * HW + 255) / 256);
@@ -890,7 +912,7 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
     hipLaunchKernelGGL(k_wave_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, p.w.background[0],
                        p.w.background[1], p.w.background[2], field, dw, scal, out_rgb, out_depth);
     FGS_LAUNCH_CHECK("k_wave_output");
-    fgs_stage_end(ST_ASM, st);
+    fgs_stage_end(ST_FIELD_FWD, st);
     return FGS_OK;
 }
 
@@ -915,7 +937,7 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
     float2 *gfield = reinterpret_cast<float2 *>(sc + p.c_gfield);
     float2 *gdw = reinterpret_cast<float2 *>(sc + p.c_gdw);
     float *rows = reinterpret_cast<float *>(sc + p.c_rows);
-    fgs_stage_begin(ST_COMPOSITE_BWD, st);
+    fgs_stage_begin(ST_FIELD_BWD, st);
     hipError_t e = hipMemsetAsync(scal + B, 0, 2 * (size_t)B * sizeof(float), st);
     if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     const dim3 gpix((unsigned)((HW + 255) / 256), B);
@@ -925,6 +947,8 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
     hipLaunchKernelGGL(k_wave_output_bwd2, gpix, dim3(256), 0, st, HW, p.w.background[0], p.w.background[1],
                        p.w.background[2], field, dw, scal, g_rgb, g_depth, gfield, gdw);
     FGS_LAUNCH_CHECK("k_wave_output_bwd2");
+    fgs_stage_end(ST_FIELD_BWD, st);
+    fgs_stage_begin(ST_SPLAT_BWD, st);
     const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units
     hipLaunchKernelGGL((k_asm_splat<true, true>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, 1u, (uint32_t)W, (uint32_t)H, (uint32_t)p.base.L.dup_capacity,
@@ -937,7 +961,7 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_tile), (uint32_t)p.base.L.seg_len);
     FGS_LAUNCH_CHECK("k_wave_splat_bwd");
-    fgs_stage_end(ST_COMPOSITE_BWD, st);
+    fgs_stage_end(ST_SPLAT_BWD, st);
     fgs_stage_begin(ST_PROJECT_BWD, st);
     if ((rc = fgs_launch_asm_project_bwd(p.base, cameras, pos, scale, quat, color, phase, p.w.phase_channels, sv, rows,
                                          g_pos, g_scale, g_quat, g_color, g_opacity, g_phase, st, true)))

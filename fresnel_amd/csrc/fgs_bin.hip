@@ -7,7 +7,6 @@
 // All sizes that depend on the data (D = number of duplicates) stay on the device: grids are
 // sized from capacities and kernels read D from saved.counters, so the whole forward is
 // free of host synchronisation and can be captured in a hipGraph.
-#include <stdlib.h>
 #include "fgs_internal.h"
 
 namespace {
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
 // per duplicate instead of four (two passes x key + payload) and no key traffic at all
 // (emit 0.052 + sort 0.148 + ranges 0.012 ms -> offsets/count/scan 0.030 + scatter 0.080 ms at config 3).
 constexpr uint32_t BIN_G = FGS_BIN_G;    // depth ranks per binning block
-constexpr uint32_t BIN_MAX_TILES = 4096; // LDS counters per block (16 KB)
+constexpr uint32_t BIN_MAX_TILES = FGS_BIN_MAX_TILES; // LDS counters per block (16 KB)
 
 __global__ __launch_bounds__(256) void k_dup_off(uint32_t total, uint32_t N, const uint32_t *__restrict__ order,
                                                  const uint32_t *__restrict__ tile_count,
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
     static_assert(WG % 64 == 0, "whole 64-rank batches per wave");
     uint32_t gid[NB];
     TileRect q[NB];
-    uint32_t inv[NB];  // ceil(2^18 / w): (t * inv) >> 18 == t / w for t < 2^12, w <= 2^6
+    uint32_t inv[NB];  // ceil(2^18 / w): (t * inv) >> 18 is t / w or one more for t < 2^12 (fixed up below)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const uint32_t r = blk * BIN_G + wave * WG + i * 64 + lane;
@@ -284,7 +283,10 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
             const uint32_t idg = __builtin_amdgcn_readlane(gid[i], g);
             const uint32_t ivg = __builtin_amdgcn_readlane(inv[i], g);
             for (uint32_t t = lane; t < cg; t += 64) {  // one trip for up to 64 tiles
-                const uint32_t y = __umul24(t, ivg) >> 18;  // t / wg exactly: t < 2^12, wg <= 2^6 (see inv)
+                // t / wg: the reciprocal is rounded up, so the estimate is exact for wg <= 64 tile columns and at
+                // most one too high beyond (t < 4096 <= 2^18 / 64); one compare makes it exact for any frame
+                uint32_t y = __umul24(t, ivg) >> 18;
+                y -= (y * wg > t) ? 1u : 0u;
                 const uint32_t tile = (tyg + y) * tiles_x + txg + (t - y * wg);
                 const uint32_t pos = run[wave][tile];  // tiles of one Gaussian are distinct: plain read-modify-write
                 run[wave][tile] = pos + 1;
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, uint32_t *
                                                      const uint32_t *__restrict__ lens,
                                                      uint32_t *__restrict__ tile_order,
                                                      uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_tile,
-                                                     uint32_t *__restrict__ counters, uint32_t seg_len) {
+                                                     uint32_t *__restrict__ counters, uint32_t seg_len,
+                                                     uint32_t fwd_variant) {
     __shared__ uint32_t hist[64];
     __shared__ uint32_t maxc;
     __shared__ unsigned long long wsum64[16];
@@ -399,7 +402,13 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, uint32_t *
         }
         off64 += ((unsigned long long)len << 32) | n;
     }
-    if (threadIdx.x == 0 && seg_off) { seg_off[ntiles] = (uint32_t)carry64; counters[2] = (uint32_t)carry64; }
+    if (threadIdx.x == 0 && seg_off) {
+        seg_off[ntiles] = (uint32_t)carry64;
+        counters[2] = (uint32_t)carry64;
+        // the split this forward runs with: the backward kernels read it from here, not from their launch
+        counters[4] = seg_len;
+        counters[5] = fwd_variant;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_count_pairs(uint32_t total, const float *__restrict__ rec,
@@ -455,8 +464,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     FGS_LAUNCH_CHECK("k_dup_blocksum");
     hipLaunchKernelGGL(k_dup_scan_bsum, dim3(1), dim3(256), 0, st, nblk, bsum, counters, dcap);
     FGS_LAUNCH_CHECK("k_dup_scan_bsum");
-    static const int force_radix = [] { const char *e = getenv("FGS_BIN_RADIX"); return e ? atoi(e) : 0; }();
-    if (p.layers == 1 && (uint32_t)p.tiles <= BIN_MAX_TILES && !force_radix) {
+    if (p.direct_binning) {
         // direct binning: counting sort straight from the bboxes (see k_bin_count)
         const uint32_t bpi = (N + BIN_G - 1) / BIN_G;
         uint32_t *cnt = keys0;               // [B][tiles][bpi], fits: keys0 holds >= Dcap words
@@ -472,7 +480,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         fgs_stage_end(ST_DUP_EMIT, st);
         fgs_stage_begin(ST_TILE_RANGES, st);
         hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ntiles_all, ranges, lens, tile_order, seg_off,
-                           seg_tile, counters, (uint32_t)p.L.seg_len);
+                           seg_tile, counters, (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant);
         FGS_LAUNCH_CHECK("k_tile_order");
         fgs_stage_end(ST_TILE_RANGES, st);
         fgs_stage_begin(ST_TILE_SORT, st);
@@ -508,7 +516,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     hipLaunchKernelGGL(k_tile_ranges, dim3(rgrid), dim3(256), 0, st, counters, ks, ranges);
     FGS_LAUNCH_CHECK("k_tile_ranges");
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ntiles_all, ranges, (const uint32_t *)nullptr,
-                       tile_order, seg_off, seg_tile, counters, (uint32_t)p.L.seg_len);
+                       tile_order, seg_off, seg_tile, counters, (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant);
     FGS_LAUNCH_CHECK("k_tile_order");
     fgs_stage_end(ST_TILE_RANGES, st);
     return FGS_OK;

@@ -16,9 +16,6 @@
 //
 // Bound: VALU + transcendental (about 25 VALU + 1 v_exp_f32 per Gaussian-pixel forward, ~60
 // backward); HBM traffic is the 52-byte id+record gather per duplicate plus per-pixel state.
-#include <stdlib.h>
-#include <stdio.h>
-#include <vector>
 #include <type_traits>
 #include "fgs_internal.h"
 #include "fgs_wave.h"
@@ -430,15 +427,17 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     const uint32_t *__restrict__ seg_tile, const float *__restrict__ seg_ckpt, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const uint32_t *__restrict__ dup_off,
     const float *__restrict__ pix_state, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
-    float *__restrict__ grad_rows, unsigned long long *__restrict__ dbg_ts, float t_eps, uint32_t fwd_parts,
-    uint32_t seg_len) {
-    const unsigned long long dbg_t0 = dbg_ts ? wall_clock64() : 0ull;
+    float *__restrict__ grad_rows, float t_eps) {
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
     __shared__ __attribute__((aligned(16))) float red[10][80];  // per-lane partial sums of one list entry, transposed
     // work unit = (tile, depth segment): blockIdx.x indexes the unit list built by k_tile_order; the grid is
     // sized from the capacity, surplus blocks leave at once
     if (blockIdx.x >= counters[2]) return;
+    // the split the forward ran with, as the forward recorded it (k_tile_order): segment length, and the number of
+    // list parts of the depth-split forward (> 1: checkpoints inside a later part are part-local)
+    const uint32_t seg_len = counters[4];
+    const uint32_t fwd_parts = (int32_t)counters[5] > 1 ? counters[5] : 0u;
     const uint32_t unit_tile = seg_tile[blockIdx.x];
     const uint32_t seg = blockIdx.x - seg_off[unit_tile];
     TileCtx c = tile_ctx_of(unit_tile, tiles, tiles_x, ranges);
@@ -529,10 +528,13 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu;
             const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
             she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
-            uint32_t flags, bits;
-            stage_decode(c.X0, c.Y0, bbx, bby, r[1].y, flags, bits);
-            q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
             float4 q0 = r[0], q1 = r[1];
+            // m = a dx^2 + (b+c) dx dy + d dy^2 >= 0 everywhere (so G <= 1): positive definite, with a margin
+            // that covers the fp32 rounding of m
+            const bool conic_ok = q0.z > 0.0f && q1.x > 0.0f && 3.996f * q0.z * q1.x > q0.w * q0.w;
+            uint32_t flags, bits;
+            stage_decode(c.X0, c.Y0, bbx, bby, q1.y, flags, bits, conic_ok);
+            q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;  // conic in exp2 units
             sh0[lane] = q0; sh1[lane] = q1; sh2[lane] = q2;
         }
@@ -605,14 +607,6 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             }
         }
         __syncthreads();
-    }
-    if (dbg_ts && threadIdx.x == 0) {  // scratch instrumentation (FGS_DBG_TS): per-tile start/end, placement, length
-        uint32_t hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long *t = dbg_ts + 4ull * blockIdx.x;
-        t[0] = dbg_t0; t[1] = wall_clock64(); t[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
-        t[3] = c.end - c.start;
     }
 }
 
@@ -796,25 +790,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
 
 }  // namespace
 
-// Kernel variants are template instantiations; FGS_FWD_VARIANT / FGS_BWD_VARIANT (read once)
-// select them for in-process A/B benchmarking.  Defaults are the measured-fastest ones.
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-// Number of list parts of the depth-split forward (0 = k_composite_fwd).  Forward and backward launchers must
-// agree: a function of the plan (and of FGS_FWD_PARTS, an A/B switch that must not change between a forward
-// and its backward).  Measured (fwd ms): 8 images x 1024 tiles: rows-split 0.642, 2 parts 0.586, 4 parts 0.588;
-// config 2 (4096 tiles): 0.169 / 0.167 / 0.134; 32 images: one wave per tile 2.215, 1 part 2.173, 2 parts 2.27.
-static int fwd_parts_of(const FgsPlan &p) {
-    if (p.d.use_phase || p.d.saturation_skip) return 0;
-    const int forced = env_int("FGS_FWD_PARTS", -1);
-    if (forced >= 0) return forced;
-    const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
-    return grid >= 24576u ? 1 : 4;
-}
-
+// Kernel variants are template instantiations selected by the plan (fgs_make_plan: FgsPlan.fwd_parts / fwd_waves,
+// a pure function of the FgsDims; FgsDims.fwd_variant overrides for A/B runs and the variant-agreement tests).
 int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, float *out_rgb,
                              float *out_depth, hipStream_t st) {
     const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
@@ -827,12 +804,8 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     const uint32_t *seg_off = reinterpret_cast<const uint32_t *>(saved + p.L.seg_off);
     float *seg_ckpt = reinterpret_cast<float *>(saved + p.L.seg_ckpt);
     const float t_eps = (p.d.saturation_skip && !p.d.use_phase) ? FGS_SATURATION_EPS : 0.0f;
-    // waves per tile: two halve the serial length of the longest lists (8 images: 0.65 vs 0.77 ms); with enough
-    // tiles to fill the chip several times over one wave per tile wins because the per-record LDS reads are then
-    // amortised over four sub-tile passes (32 images: 2.26 vs 2.61 ms); a launch that cannot even fill the chip once
-    // is latency-bound and gets one wave per sub-tile.  FGS_FWD_WAVES overrides (A/B harness).
-    const int fw = env_int("FGS_FWD_WAVES", grid >= 24576u ? 1 : (grid <= 6144u ? 4 : 2));
-    if (const int np = fwd_parts_of(p)) {
+    const int fw = p.fwd_waves;
+    if (const int np = p.fwd_parts) {
 #define FGS_PARTS_LAUNCH(NP)                                                                                  \
     hipLaunchKernelGGL((k_blend_fwd_parts<NP>), dim3(grid), dim3(64 * NP), 0, st, (uint32_t)p.tiles,          \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
@@ -849,8 +822,7 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
                        p.d.background[1], p.d.background[2], p.d.phase_amplitude, tile_order, ranges, dup_ids, \
                        rec, phase, pix, ckpt, out_rgb, out_depth, seg_off, seg_ckpt, t_eps)
     if (p.d.use_phase) {
-        // the phase recurrence is latency-bound (serial cos / divide chain per pixel): one wave per sub-tile
-        const int pw = env_int("FGS_FWD_WAVES", 4);
+        const int pw = fw;
         if (pw == 1) FGS_FWD_LAUNCH(true, 1, false); else if (pw == 2) FGS_FWD_LAUNCH(true, 2, false); else FGS_FWD_LAUNCH(true, 4, false);
     } else if (t_eps > 0.0f) {  // FgsDims.saturation_skip: separate instantiation, the default path carries no trace of it
         if (fw == 1) FGS_FWD_LAUNCH(false, 1, true); else if (fw == 4) FGS_FWD_LAUNCH(false, 4, true); else FGS_FWD_LAUNCH(false, 2, true);
@@ -881,10 +853,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
         FGS_LAUNCH_CHECK("k_composite_bwd_phase");
         return FGS_OK;
     }
-    unsigned long long *dbg = nullptr;
-    const char *dbg_path = getenv("FGS_DBG_TS");  // scratch instrumentation: per-unit timeline dump
     const uint32_t ugrid = (uint32_t)p.L.seg_capacity;  // surplus blocks exit at once (measured: free)
-    if (dbg_path) { (void)hipMalloc(&dbg, (size_t)ugrid * 32); (void)hipMemsetAsync(dbg, 0, (size_t)ugrid * 32, st); }
     hipLaunchKernelGGL(k_composite_bwd, dim3(ugrid), dim3(64), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
                        (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0], p.d.background[1],
                        p.d.background[2], (uint32_t)p.L.dup_capacity,
@@ -897,15 +866,8 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
                        reinterpret_cast<const float *>(saved + p.L.rec),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const float *>(saved + p.L.pix_state), g_rgb, g_depth,
-                       reinterpret_cast<float *>(scratch + p.s_grows), dbg,
-                       p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f, (uint32_t)(fwd_parts_of(p) == 1 ? 0 : fwd_parts_of(p)), (uint32_t)p.L.seg_len);
-    if (dbg) {
-        (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h((size_t)ugrid * 4);
-        (void)hipMemcpy(h.data(), dbg, (size_t)ugrid * 32, hipMemcpyDeviceToHost);
-        (void)hipFree(dbg);
-        if (FILE *f = fopen(dbg_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-    }
+                       reinterpret_cast<float *>(scratch + p.s_grows),
+                       p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f);
     FGS_LAUNCH_CHECK("k_composite_bwd");
     return FGS_OK;
 }

@@ -24,6 +24,11 @@ struct FgsPlan {
     int32_t tiles;            // tiles per image
     int32_t tiles_per_gauss;  // worst-case tiles touched by one Gaussian
     uint32_t tile_key_bits;   // bits of (image*T + tile)
+    // resolved tuning (FgsDims.seg_len / fwd_variant / bin_mode with FGS_TUNE_AUTO replaced by the choice)
+    int32_t fwd_parts;        // list parts of the depth-split forward; 0 = the row-split forward (k_composite_fwd)
+    int32_t fwd_waves;        // waves per tile of the row-split forward (also the phase path)
+    int32_t fwd_variant;      // the same choice in FgsDims.fwd_variant encoding (recorded in saved.counters[5])
+    bool direct_binning;      // counting sort straight from the bboxes instead of emit + radix sort
     // scratch layout (bytes)
     size_t s_total;
     size_t s_keys0, s_keys1;  // uint32 [max(B*N, Dcap)] radix ping/pong keys
@@ -48,7 +53,9 @@ void fgs_set_error(const char *fmt, ...);
     } while (0)
 
 enum FgsStage { ST_PROJECT = 0, ST_DEPTH_SORT, ST_DUP_EMIT, ST_TILE_SORT, ST_TILE_RANGES, ST_COMPOSITE_FWD,
-                ST_COMPOSITE_BWD, ST_PROJECT_BWD };
+                ST_COMPOSITE_BWD, ST_PROJECT_BWD, ST_SPLAT_FWD, ST_FIELD_FWD, ST_FIELD_BWD, ST_SPLAT_BWD };
+static_assert(ST_SPLAT_BWD + 1 == FGS_NUM_STAGES, "stage list and FGS_NUM_STAGES disagree");
+#define FGS_BIN_MAX_TILES 4096  /* direct binning: LDS counters per block (16 KB) */
 void fgs_stage_begin(int stage, hipStream_t st);  // no-ops unless fgs_stage_timing_enable(1)
 void fgs_stage_end(int stage, hipStream_t st);
 

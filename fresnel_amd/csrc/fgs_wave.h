@@ -54,14 +54,17 @@ __device__ __forceinline__ uint32_t subtile_mask(uint32_t X0, uint32_t Y0, uint3
 // non-phase composite kernels:
 //   flags  bits 0-3: sub-tile s (8x8, s = 2*row + col) intersects the bbox -- all clear when the opacity is
 //                    negative (alpha clamps to 0 with zero gradient, DR:646: the record contributes nothing);
-//          bit 4:    opacity <= 0.98, so alpha = min(G op, 0.99) cannot bind (G <= 1 up to rounding);
+//          bit 4:    opacity <= 0.98 and `conic_ok` (the caller's check that the quadratic form is positive
+//                    definite with a margin), so alpha = min(G op, 0.99) cannot bind: G <= 1 up to rounding.
+//                    For a regularised inverse covariance that came out indefinite in fp32 (needles, edge-on
+//                    discs) G can exceed 1.0102 and the clamp of DR:647 does bind -- those keep the clamped path;
 //          bit 5:    the bbox covers the whole tile (no per-pixel membership test needed)
 //   bits   bit i (i < 16): pixel column X0 + i lies in [x0, x1);  bit 16 + i: pixel row Y0 + i lies in [y0, y1).
 // In the list loop a lane turns its column / row bit into an all-ones / zero mask with one v_bfe_i32.
 __device__ __forceinline__ void stage_decode(uint32_t X0, uint32_t Y0, uint32_t bbx, uint32_t bby, float op,
-                                             uint32_t &flags, uint32_t &bits) {
+                                             uint32_t &flags, uint32_t &bits, bool conic_ok = true) {
     const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
-    flags = (op >= 0.0f ? subtile_mask(X0, Y0, x0, x1, y0, y1) : 0u) | (op <= 0.98f ? 16u : 0u) |
+    flags = (op >= 0.0f ? subtile_mask(X0, Y0, x0, x1, y0, y1) : 0u) | ((op <= 0.98f && conic_ok) ? 16u : 0u) |
             ((x0 <= X0 && x1 >= X0 + 16u && y0 <= Y0 && y1 >= Y0 + 16u) ? 32u : 0u);
     const int lx0 = max((int)x0 - (int)X0, 0), lx1 = min((int)x1 - (int)X0, 16);
     const int ly0 = max((int)y0 - (int)Y0, 0), ly1 = min((int)y1 - (int)Y0, 16);

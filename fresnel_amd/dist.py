@@ -26,10 +26,25 @@ class DPContext:
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
 
     def shard(self, n_items):
-        """Contiguous image shard [lo, hi) of this rank for a global batch of n_items."""
-        per = (n_items + self.world - 1) // self.world
-        lo = min(self.rank * per, n_items)
-        return lo, min(lo + per, n_items)
+        """Contiguous image shard [lo, hi) of this rank for a global batch of n_items.
+
+        The global batch must divide evenly over the ranks: with equal shards the mean of the shard means IS the
+        global-batch mean, so `allreduce_gradients` (sum / world) reproduces the single-process gradient, and no
+        rank is ever left without images (an empty shard would stall the others in the all-reduce)."""
+        if n_items % self.world != 0:
+            raise ValueError(f"global batch of {n_items} images does not divide over {self.world} ranks: "
+                             f"use a --batch_size that is a multiple of the number of GPUs")
+        per = n_items // self.world
+        return self.rank * per, (self.rank + 1) * per
+
+    def global_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """Differentiable sum of a tensor over the ranks (autograd-aware all-reduce: the backward all-reduces the
+        incoming gradients, so statistics of the GLOBAL batch -- e.g. the depth-loss normalisation -- get the exact
+        single-process gradient).  Identity when not distributed."""
+        if not self.enabled:
+            return t
+        import torch.distributed.nn.functional as dnf
+        return dnf.all_reduce(t, op=dist.ReduceOp.SUM)
 
     def broadcast_parameters(self, module):
         if self.enabled:

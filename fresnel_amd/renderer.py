@@ -38,6 +38,7 @@ class Camera:
         self.far = far
         # identity = camera at origin looking down -Z (DR:47-48)
         self.view_matrix = torch.eye(4)
+        self._packed = None  # (key, device tensor): the camera record is uploaded once, not once per call
 
     def set_view(self, view_matrix: torch.Tensor):
         """Set view matrix (world-to-camera transform), DR:50-52."""
@@ -63,6 +64,18 @@ class Camera:
         v = self.view_matrix.detach().to("cpu", torch.float32).reshape(16).tolist()
         return v + [float(self.fx), float(self.fy), float(self.cx), float(self.cy),
                     float(self.near), float(self.far), 0.0, 0.0]
+
+
+    def packed_tensor(self, device) -> torch.Tensor:
+        """(1, FGS_CAMERA_FLOATS) device record, cached until the camera changes (fields, set_view, or an in-place
+        edit of view_matrix): the reference re-uploads the view matrix on every call (DR:151); one H2D copy per
+        camera is enough."""
+        vm = self.view_matrix
+        key = (str(device), float(self.fx), float(self.fy), float(self.cx), float(self.cy), float(self.near),
+               float(self.far), id(vm), vm._version)
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, torch.tensor([self.packed()], dtype=torch.float32, device=device))
+        return self._packed[1]
 
 
 def create_camera_from_pose(elevation_rad: float, azimuth_rad: float, render_size: int,
@@ -92,8 +105,9 @@ def create_camera_from_pose(elevation_rad: float, azimuth_rad: float, render_siz
 
 
 def pack_cameras(cameras: Union[Camera, Sequence[Camera]], device) -> torch.Tensor:
-    cams = [cameras] if isinstance(cameras, Camera) else list(cameras)
-    return torch.tensor([c.packed() for c in cams], dtype=torch.float32, device=device)
+    if isinstance(cameras, Camera):
+        return cameras.packed_tensor(device)
+    return torch.tensor([c.packed() for c in cameras], dtype=torch.float32, device=device)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -107,8 +121,10 @@ def _stream_handle():
 class _Cfg:
     """Static (non-tensor) configuration of one renderer call."""
 
-    def __init__(self, width, height, background, max_radius, use_phase, phase_amplitude, saturation_skip=False):
+    def __init__(self, width, height, background, max_radius, use_phase, phase_amplitude, saturation_skip=False,
+                 tuning=None):
         self.saturation_skip = bool(saturation_skip)
+        self.tuning = dict(tuning) if tuning else None  # FgsDims.seg_len / fwd_variant / bin_mode overrides
         self.width, self.height = int(width), int(height)
         self.background = tuple(float(b) for b in background)
         self.max_radius = float(max_radius)
@@ -134,7 +150,8 @@ def forward_raw(positions, scales, rotations, colors, opacities, phases, cam_ten
     cam_tensor = cam_tensor.contiguous().float()
     dims = B.make_dims(Bn, N, cfg.width, cfg.height, cfg.max_radius, cfg.background,
                        use_phase=ph is not None, phase_amplitude=cfg.phase_amplitude,
-                       num_cameras=cam_tensor.shape[0], saturation_skip=getattr(cfg, "saturation_skip", False))
+                       num_cameras=cam_tensor.shape[0], saturation_skip=getattr(cfg, "saturation_skip", False),
+                       tuning=getattr(cfg, "tuning", None))
     saved_bytes, scratch_bytes = B.workspace_bytes(dims)
     with torch.cuda.device(dev):
         saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
@@ -191,7 +208,7 @@ class GaussianRenderer(torch.autograd.Function):
 
 def render_batch(positions, scales, rotations, colors, opacities, cameras, width, height,
                  background=(0.0, 0.0, 0.0), max_radius=64, phases=None, use_phase_blending=False,
-                 phase_amplitude=0.25, cam_tensor=None, saturation_skip=False):
+                 phase_amplitude=0.25, cam_tensor=None, saturation_skip=False, tuning=None):
     """Functional batched entry point: tensors are (B,N,.); cameras is one Camera (shared by
     the batch, as in the reference's training loop TGD:1209-1223) or a list of B Cameras.
     `saturation_skip` (off by default = the reference's behaviour, every list entry composited): stop
@@ -199,7 +216,7 @@ def render_batch(positions, scales, rotations, colors, opacities, cameras, width
     if cam_tensor is None:
         cam_tensor = pack_cameras(cameras, positions.device)
     cfg = _Cfg(width, height, background, max_radius, use_phase_blending and phases is not None,
-               phase_amplitude, saturation_skip)
+               phase_amplitude, saturation_skip, tuning)
     return GaussianRenderer.apply(positions, scales, rotations, colors, opacities, phases, cam_tensor, cfg)
 
 
@@ -219,6 +236,7 @@ class TileBasedRenderer(nn.Module):
                  saturation_skip: bool = False):
         super().__init__()
         self.saturation_skip = saturation_skip  # extension, off by default (see render_batch)
+        self.tuning = None  # optional FgsDims work-split overrides (tests / A-B runs); never changes results
         self.width = image_width
         self.height = image_height
         self.background = torch.tensor(background)  # plain tensor, as in DR:447
@@ -252,7 +270,8 @@ class TileBasedRenderer(nn.Module):
             return (img, depth) if return_depth else img
         img, depth = render_batch(positions, scales, rotations, colors, opacities, camera, self.width,
                                   self.height, bg, self.max_radius, phases if use_phase else None,
-                                  use_phase, self.phase_amplitude, saturation_skip=self.saturation_skip)
+                                  use_phase, self.phase_amplitude, saturation_skip=self.saturation_skip,
+                                  tuning=self.tuning)
         if not batched:
             img, depth = img[0], depth[0]
         if return_depth:

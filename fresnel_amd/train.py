@@ -105,7 +105,20 @@ class SyntheticDataset:
         return tuple(torch.stack(t).to(device) for t in zip(*items))
 
 
-def compute_losses(rendered, target, rendered_depth, target_depth, cfg: TrainingConfig):
+def _global_mean_std(x, dp):
+    """mean and unbiased std (torch.std default, as TGD:922-925 uses) of x over the GLOBAL batch: the sums are
+    all-reduced differentiably, so an N-rank step normalises the depth loss exactly like the 1-rank step."""
+    n = x.numel() * (dp.world if dp is not None and dp.enabled else 1)
+    s1, s2 = x.sum(), (x * x).sum()
+    if dp is not None and dp.enabled:
+        s = dp.global_sum(torch.stack([s1, s2]))
+        s1, s2 = s[0], s[1]
+    mean = s1 / n
+    var = (s2 - n * mean * mean) / max(n - 1, 1)
+    return mean, torch.sqrt(torch.clamp(var, min=0.0))
+
+
+def compute_losses(rendered, target, rendered_depth, target_depth, cfg: TrainingConfig, dp=None):
     """L1 + (1-SSIM if available) + normalised depth L1 (TGD:890, 906-930)."""
     d: Dict[str, float] = {}
     rgb = F.l1_loss(rendered, target)
@@ -116,10 +129,10 @@ def compute_losses(rendered, target, rendered_depth, target_depth, cfg: Training
         d["ssim"] = float(s.detach())
         total = total + cfg.ssim_weight * s
     if rendered_depth is not None and target_depth is not None:
-        rd_std = torch.clamp(rendered_depth.std(), min=1e-4)
-        td_std = torch.clamp(target_depth.std(), min=1e-4)
-        dl = F.l1_loss((rendered_depth - rendered_depth.mean()) / rd_std,
-                       (target_depth - target_depth.mean()) / td_std)
+        rd_mean, rd_std = _global_mean_std(rendered_depth, dp)
+        td_mean, td_std = _global_mean_std(target_depth, dp)
+        dl = F.l1_loss((rendered_depth - rd_mean) / torch.clamp(rd_std, min=1e-4),
+                       (target_depth - td_mean) / torch.clamp(td_std, min=1e-4))
         d["depth"] = float(dl.detach())
         total = total + cfg.depth_weight * dl
     if cfg.wave_equation_weight > 0:  # TGD:957-964
@@ -177,7 +190,7 @@ def train_step(model, renderer, camera, batch, optimizer, cfg: TrainingConfig, d
     res = cfg.image_size
     target = F.interpolate(images, size=(res, res), mode="bilinear", align_corners=False)
     tdepth = F.interpolate(depth, size=(res, res), mode="bilinear", align_corners=False).squeeze(1)
-    loss, ld = compute_losses(rendered, target, rdepth, tdepth, cfg)
+    loss, ld = compute_losses(rendered, target, rdepth, tdepth, cfg, dp)
     bad = bool(torch.isnan(loss) or torch.isinf(loss))
     if dp.any_true(bad, loss.device):  # collective NaN/Inf skip (TGD:1255-1258)
         optimizer.zero_grad()
@@ -205,6 +218,8 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
                  log=print):
     device = torch.device(cfg.device)
     dp = dp or DPContext(device=device if device.type == "cuda" else None)
+    if cfg.batch_size % dp.world != 0:  # fail fast, before any rank can stall in a collective (see DPContext.shard)
+        raise ValueError(f"--batch_size {cfg.batch_size} is not a multiple of the {dp.world} ranks")
     torch.manual_seed(cfg.seed)
     model = PatchGaussianDecoder(cfg.feature_dim, cfg.gaussians_per_patch, grid=cfg.feature_size,
                                  use_fresnel_zones=cfg.use_fresnel_zones,

@@ -34,6 +34,7 @@ extern "C" {
 #define FGS_TILE 16        /* tile edge in pixels */
 #define FGS_SEG 128        /* largest depth segment: list entries per backward work unit; a call uses
                               FgsSavedLayout.seg_len (64 for small problems, else FGS_SEG)            */
+#define FGS_TUNE_AUTO 0    /* FgsDims.seg_len / fwd_variant / bin_mode: let the library choose        */
 #define FGS_PHASE_CKPT 8   /* list entries between (A, Phi) checkpoints on the phase path */
 #define FGS_CAMERA_FLOATS 24
 
@@ -52,6 +53,17 @@ typedef struct FgsDims {
                                 below 2^-25 for all their pixels (accumulated alpha == 1.0f in fp32) stop being
                                 composited, forward and backward; what is dropped is < 3e-8 * |colour| per pixel.
                                 Blend path only (ignored with use_phase).                                      */
+    /* Tuning overrides.  0 (FGS_TUNE_AUTO) everywhere = the measured-fastest choice for the launch size; the
+     * settings only change how the work is split, never what is computed (results agree to fp32 rounding, the
+     * integer stages bit for bit -- tests/test_hip_parity.py).  The library reads NO environment variables: a
+     * forward and its backward agree because both derive the plan from the same FgsDims, and the forward also
+     * records (seg_len, fwd_variant) in saved.counters[4..5], which the backward kernels read. */
+    int32_t seg_len;        /* list entries per depth segment: 0 | 64 | 128 (saturation_skip needs 128)        */
+    int32_t fwd_variant;    /* forward work split: 0 | 1, 2, 4 = depth-split forward with that many list parts
+                               (waves) per tile | -1, -2, -4 = row-split forward with that many waves per tile.
+                               Phase path: |fwd_variant| = waves per tile.                                      */
+    int32_t bin_mode;       /* tile binning: 0 | 1 = direct counting sort | 2 = emit + stable radix sort        */
+    int32_t reserved;       /* must be 0                                                                        */
 } FgsDims;
 
 /* Camera record on the DEVICE: FGS_CAMERA_FLOATS floats per camera (Camera, DR:27-52):
@@ -69,7 +81,8 @@ typedef struct FgsSavedLayout {
     size_t order;      /* uint32 [B][N]: Gaussian ids in canonical depth order (DR:527)   */
     size_t dup_off;    /* uint32 [B][N]: first duplicate slot of each Gaussian (emission
                                          order = image, depth rank, tile row, tile column)   */
-    size_t counters;   /* uint32 [16]: [0] total duplicates D, [1] overflow flag          */
+    size_t counters;   /* uint32 [16]: [0] total duplicates D, [1] overflow flag, [2] depth-segment units U,
+                                       [4] seg_len and [5] fwd_variant the forward ran with          */
     size_t ranges;     /* uint32 [B*T][2]: [start,end) into dup_ids per (image,tile)      */
     size_t tile_order; /* uint32 [B*T]: (image,tile) indices, longest lists first: the launch
                                          order of the composite kernels (scheduling only)    */
@@ -185,14 +198,16 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
                       void *stream);
 
 /* Per-stage hipEvent timers (profiling aid; SURVEY §5 "tracing").  When enabled, every stage
- * launched by fgs_forward/fgs_backward is bracketed by an event pair on the caller's stream.
- * fgs_stage_timing_read synchronises on the recorded events, ADDS the elapsed milliseconds per
+ * launched by the fgs_*_forward / fgs_*_backward entry points is bracketed by an event pair on the caller's
+ * stream.  fgs_stage_timing_read synchronises on the recorded events, ADDS the elapsed milliseconds per
  * stage to ms[FGS_NUM_STAGES] and the number of launches to count[FGS_NUM_STAGES], and clears
- * the record.  Stage order: project, depth_sort, dup_emit, tile_sort, tile_ranges,
- * composite_fwd, composite_bwd, project_bwd.
+ * the record.  Stage order: project, depth_sort, dup_emit, tile_sort, tile_ranges, composite_fwd,
+ * composite_bwd, project_bwd, and for the splat renderers (ASM / wave field): splat_fwd, field_fwd (FFTs,
+ * transfer function, plane sum, normalisation and output), field_bwd (their adjoints), splat_bwd.
  * enable: 0 = off, 1 = all stages, otherwise a mask with bit (stage + 1) per selected stage -- every event
- * pair costs a few microseconds of stream time, so a benchmark times only the kernel it reports. */
-#define FGS_NUM_STAGES 8
+ * pair costs a few microseconds of stream time, so a benchmark times only the kernel it reports.
+ * (The only entry points that allocate or synchronise; never called by the product path.) */
+#define FGS_NUM_STAGES 12
 int fgs_stage_timing_enable(int enable);
 int fgs_stage_timing_read(float *ms, int32_t *count);
 

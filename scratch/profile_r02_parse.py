@@ -1,0 +1,53 @@
+"""Collect one run of scratch/profile_r02.sh into <out>/pmc_run.json (merged into profiles/r02_pmc_summary.json
+by scratch/profile_r02_merge.py)."""
+import sys, glob, csv, collections, json
+root, key = sys.argv[1], sys.argv[2]
+KEYS = ('k_composite_bwd_phase', 'k_composite_bwd', 'k_blend_fwd_parts', 'k_composite_fwd', 'k_asm_splat', 'k_asm_accumulate_bwd',
+        'k_asm_accumulate', 'k_asm_transfer', 'k_project_bwd', 'k_project', 'k_sort_image', 'k_radix_downsweep', 'k_radix_upsweep',
+        'k_bin_scatter', 'k_bin_count', 'k_tile_order', 'k_tile_scan', 'k_dup_emit')
+
+
+def match(name):
+    for k in KEYS:  # longest names first in KEYS where one is a prefix of another
+        if name.startswith(k) or ('::' + k) in name or (' ' + k) in name:
+            rest = name[name.index(k) + len(k):][:1]
+            if rest in ('', '(', '<', ' '):
+                if k == 'k_asm_splat':
+                    return k + ('<true>' if '<true' in name else '<false>')
+                return k
+    return None
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(lambda: collections.defaultdict(set))
+for f in glob.glob(root + '/g*/**/*counter_collection.csv', recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = match(row['Kernel_Name'])
+        if k:
+            acc[k][row['Counter_Name']] += float(row['Counter_Value'])
+            calls[k][row['Counter_Name']].add(row['Dispatch_Id'])
+stats = {}
+for sf in glob.glob(root + '/stats/**/*kernel_stats.csv', recursive=True):
+    for row in csv.DictReader(open(sf)):
+        k = match(row['Name'])
+        if k:
+            stats[k] = {'calls': int(row['Calls']), 'avg_us': float(row['AverageNs']) / 1e3}
+bench = json.loads(open(root + '/bench.json').read().strip().splitlines()[-1])
+out = {"command": "bench.py " + " ".join(f"--{a} {b}" for a, b in (("workload", key.split('_')[0]),)) + f"  (run key {key})",
+       "ms_per_step": bench["ms_per_step"], "value": bench["value"], "roofline_kernel": bench["roofline"]["kernel"],
+       "roofline_frac": bench["roofline"]["frac"], "kernels": []}
+for k in sorted(set(list(acc) + list(stats))):
+    row = {"kernel": k}
+    if k in stats:
+        row["avg_us_kernel_trace"] = round(stats[k]['avg_us'], 2); row["calls_kernel_trace"] = stats[k]['calls']
+    for c, v in sorted(acc.get(k, {}).items()):
+        row[c if c not in ('FETCH_SIZE', 'WRITE_SIZE') else c + '_KB'] = v / max(len(calls[k][c]), 1)
+    if 'FETCH_SIZE_KB' in row and 'WRITE_SIZE_KB' in row:
+        row['hbm_bytes_corrected'] = (2 * row['FETCH_SIZE_KB'] + row['WRITE_SIZE_KB']) * 1024
+    if row.get('SQ_LDS_IDX_ACTIVE'):
+        row['lds_conflict_share'] = round(row.get('SQ_LDS_BANK_CONFLICT', 0.0) / row['SQ_LDS_IDX_ACTIVE'], 4)
+    out['kernels'].append(row)
+json.dump(out, open(root + '/pmc_run.json', 'w'), indent=1)
+for r in out['kernels']:
+    print(r['kernel'], {k: (round(v, 1) if isinstance(v, float) else v) for k, v in r.items() if k in
+                        ('avg_us_kernel_trace', 'hbm_bytes_corrected', 'lds_conflict_share', 'SQ_INSTS_VALU', 'WRITE_SIZE_KB', 'FETCH_SIZE_KB')})
+print(json.dumps(bench)[:600])

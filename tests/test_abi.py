@@ -71,3 +71,34 @@ def test_renderer_refuses_cpu_tensors():
     cam = Camera(25.6, 25.6, 16, 16, 32, 32)
     with pytest.raises(B.FgsError):
         r(torch.zeros(4, 3), torch.ones(4, 3), torch.ones(4, 4), torch.ones(4, 3), torch.ones(4), cam)
+
+
+def test_shipped_library_reads_no_environment(lib):
+    """The product library takes every switch through FgsDims: it must not import getenv /
+    secure_getenv, so no environment change can put a forward and its backward on different layouts."""
+    import subprocess
+    from fresnel_amd import build
+    out = subprocess.run(["nm", "-D", "--undefined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out, "libfgs_hip.so imports getenv"
+    for src in glob.glob(os.path.join(ROOT, "fresnel_amd", "csrc", "*")):
+        assert "getenv" not in open(src).read(), src
+
+
+def test_tuning_fields_are_validated_and_change_only_the_split():
+    from fresnel_amd import _binding as B
+    base = B.saved_layout(B.make_dims(8, 32768, 512, 512))
+    assert base.seg_len == 128
+    assert B.saved_layout(B.make_dims(2, 32768, 512, 512)).seg_len == 64
+    forced = B.saved_layout(B.make_dims(2, 32768, 512, 512, tuning=dict(seg_len=128)))
+    assert forced.seg_len == 128 and forced.dup_capacity == B.saved_layout(B.make_dims(2, 32768, 512, 512)).dup_capacity
+    for bad in (dict(seg_len=32), dict(fwd_variant=3), dict(fwd_variant=-8), dict(bin_mode=3)):
+        with pytest.raises(B.FgsError):
+            B.workspace_bytes(B.make_dims(2, 1000, 64, 64, tuning=bad))
+    # the row-split forward (saturation_skip / fwd_variant < 0) stages 128-entry chunks
+    with pytest.raises(B.FgsError):
+        B.workspace_bytes(B.make_dims(2, 1000, 64, 64, tuning=dict(fwd_variant=-2, seg_len=64)))
+    assert B.saved_layout(B.make_dims(2, 1000, 64, 64, saturation_skip=True)).seg_len == 128
+    # direct binning needs <= 4096 tiles per image
+    with pytest.raises(B.FgsError):
+        B.workspace_bytes(B.make_dims(1, 100, 2048, 2048, tuning=dict(bin_mode=1)))
+    B.workspace_bytes(B.make_dims(1, 100, 2048, 2048, tuning=dict(bin_mode=2)))

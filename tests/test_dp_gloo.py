@@ -45,7 +45,7 @@ class StubRenderer(torch.nn.Module):
 def _cfg():
     from fresnel_amd.train import TrainingConfig
     return TrainingConfig(batch_size=4, epochs=2, lr=1e-3, image_size=16, feature_size=4, feature_dim=8,
-                          gaussians_per_patch=2, depth_weight=0.0, ssim_weight=0.0, device="cpu",
+                          gaussians_per_patch=2, depth_weight=0.1, ssim_weight=0.0, device="cpu",
                           steps_per_epoch=2, save_interval=1000, log_interval=1000)
 
 
@@ -64,7 +64,19 @@ def _worker(rank, world, port, outdir, mode):
             p.grad = torch.full_like(p, float(rank + 1))
         dp.allreduce_gradients(list(lin.parameters()))
         torch.save([p.grad.clone() for p in lin.parameters()], os.path.join(outdir, f"g{rank}.pt"))
-        torch.save(dp.shard(7), os.path.join(outdir, f"s{rank}.pt"))
+        torch.save(dp.shard(8), os.path.join(outdir, f"s{rank}.pt"))
+        for bad in (7, 1):  # uneven shards / fewer images than ranks: refused, never an empty shard
+            try:
+                dp.shard(bad)
+                raise AssertionError("uneven shard accepted")
+            except ValueError:
+                pass
+        cfg.batch_size = 3
+        try:
+            run_training(cfg, dp, renderer_factory=lambda c, dev: (StubRenderer(c.image_size), None), log=lambda *a: None)
+            raise AssertionError("batch_size 3 on 2 ranks accepted")
+        except ValueError:
+            pass
     else:
         poison = 1 if mode == "nan" else None
         factory = lambda c, dev: (StubRenderer(c.image_size, poison), None)
@@ -84,7 +96,7 @@ def test_bucket_allreduce_and_shards():
     g0, g1 = torch.load(os.path.join(d, "g0.pt")), torch.load(os.path.join(d, "g1.pt"))
     for a, b in zip(g0, g1):
         assert torch.equal(a, b) and torch.allclose(a, torch.full_like(a, 1.5))
-    assert torch.load(os.path.join(d, "s0.pt")) == (0, 4) and torch.load(os.path.join(d, "s1.pt")) == (4, 7)
+    assert torch.load(os.path.join(d, "s0.pt")) == (0, 4) and torch.load(os.path.join(d, "s1.pt")) == (4, 8)
 
 
 def test_two_rank_training_matches_single_rank():
@@ -94,7 +106,8 @@ def test_two_rank_training_matches_single_rank():
         assert torch.equal(m0["sd"][k], m1["sd"][k]), f"ranks diverged on {k}"
     d1 = _spawn("train", world=1)
     s = torch.load(os.path.join(d1, "m0.pt"))
-    # mean-of-shard-means == global mean for equal shards: same parameters up to fp32 reduction order
+    # mean-of-shard-means == global mean for equal shards, and the depth loss is normalised with GLOBAL-batch
+    # statistics (differentiable all-reduce): same parameters up to fp32 reduction order
     for k in s["sd"]:
         assert torch.allclose(s["sd"][k], m0["sd"][k], rtol=1e-4, atol=1e-6), k
     assert len(s["hist"]) == 2 and abs(s["hist"][-1]["total"] - m0["hist"][-1]["total"]) < 1e-5
