@@ -97,21 +97,41 @@ def pmc_traffic(run_key, kernel):
     return None
 
 
-def cpu_baseline_leg(leaves, gI, gD, N, S):
+def host_cores():
+    """CPU cores this process may use: the affinity mask, capped by the cgroup CPU quota when there is one (a GPU
+    box exposes all of the host's cores but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline_leg(leaves, gI, gD, N, S, budget_s=8.0):
     """The reference's pure-PyTorch per-Gaussian-loop rasterizer cannot travel to this box, so the CPU baseline is
     this repo's restatement of it (oracle/torch_loop.py, same algorithm / same per-iteration tensor work, checked
-    against the C oracle in tests/) on a bounded sample: the first 2048 Gaussians of image 0, forward + autograd
-    backward, on all host cores and on one thread; plus the scalar C oracle on two full images."""
+    against the C oracle in tests/) on a BOUNDED sample of image 0: its first n Gaussians, n <= 2048 chosen from a
+    64-Gaussian calibration run so that forward + autograd backward take about `budget_s` seconds -- once with all
+    host cores, once with one thread; plus the scalar C oracle on two full images."""
     from oracle import fgs_oracle as orc
     from oracle import torch_loop as tl
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_sub = min(2048, N)
-    arrs = [t[0, :n_sub].detach().cpu().numpy() for t in leaves]
+    cores = host_cores()
     view = np.eye(4, dtype=np.float32)
     gi, gd = gI[0].cpu().numpy(), gD[0].cpu().numpy()
     fx = 0.8 * S
-    p_all, t_all = tl.timed_fwd_bwd(arrs, view, fx, fx, S / 2, S / 2, S, S, gi, gd, threads=cores)
-    p_one, t_one = tl.timed_fwd_bwd(arrs, view, fx, fx, S / 2, S / 2, S, S, gi, gd, threads=1)
+
+    def run(threads):
+        sub = lambda n: [t[0, :n].detach().cpu().numpy() for t in leaves]
+        _, t_cal = tl.timed_fwd_bwd(sub(min(64, N)), view, fx, fx, S / 2, S / 2, S, S, gi, gd, threads=threads)
+        n = int(max(64, min(2048, N, budget_s / max(t_cal / min(64, N), 1e-6))))
+        p, t = tl.timed_fwd_bwd(sub(n), view, fx, fx, S / 2, S / 2, S, S, gi, gd, threads=threads)
+        return n, p, t
+
+    n_all, p_all, t_all = run(cores)
+    n_one, p_one, t_one = run(1)
     ocam = orc.make_camera(view, fx, fx, S / 2, S / 2, S, S)
     n_c = min(2, leaves[0].shape[0])
     Pc, tc = 0, 0.0
@@ -122,10 +142,11 @@ def cpu_baseline_leg(leaves, gI, gD, N, S):
         tc += time.perf_counter() - t0
         Pc += Pi
     return {"value": round(p_all / t_all, 1), "unit": "Gaussian-pixels/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_sub} Gaussians of image 0 @ {S}x{S} ({p_all} pairs), forward + autograd backward of the "
+            "sample": f"first {n_all} Gaussians of image 0 @ {S}x{S} ({p_all} pairs), forward + autograd backward of the "
                       f"pure-PyTorch per-Gaussian loop (oracle/torch_loop.py, restatement of DR:582-667) in {t_all:.2f} s "
                       f"with torch.set_num_threads({cores})",
-            "one_thread": {"value": round(p_one / t_one, 1), "seconds": round(t_one, 2), "cores": 1},
+            "one_thread": {"value": round(p_one / t_one, 1), "seconds": round(t_one, 2), "cores": 1,
+                           "sample": f"first {n_one} Gaussians ({p_one} pairs)"},
             "c_oracle": {"value": round(Pc / tc, 1), "cores": 1, "seconds": round(tc, 2),
                          "sample": f"images 0..{n_c - 1} at full size ({Pc} pairs), scalar C restatement (oracle/fgs_oracle.c), fwd+bwd"},
             "host_cpus_visible": os.cpu_count(), "note": "baseline, not the target (see roofline.frac)"}
