@@ -41,7 +41,13 @@ def _hipcc():
     return "hipcc"
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), suffix=""):
+    """`defines` / `suffix`: experiment builds (`python -m fresnel_amd.build --define FGS_X=1 --suffix _x` writes
+    _lib/libfgs_hip_x.so next to the product library; select it with FGS_LIB=... for same-box A/B runs)."""
+    global OBJ_DIR, LIB
+    if suffix:
+        OBJ_DIR = os.path.join(OUT_DIR, "obj" + suffix)
+        LIB = os.path.join(OUT_DIR, f"libfgs_hip{suffix}.so")
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -54,7 +60,7 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(OBJ_DIR, name.replace(".hip", ".o"))
         if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_time:
-            cmd = [hipcc] + COMMON + extra + ["-c", src, "-o", obj]
+            cmd = [hipcc] + COMMON + extra + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -69,4 +75,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    _defs = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--define"]
+    _suf = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--suffix"]
+    print(build(force="--force" in sys.argv or bool(_defs), verbose="--verbose" in sys.argv or "-v" in sys.argv,
+                defines=_defs, suffix=_suf[0] if _suf else ""))

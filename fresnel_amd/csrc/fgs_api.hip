@@ -160,7 +160,9 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     // the direct binning keeps its [B][tiles][ceil(N / FGS_BIN_G)] count matrix in the first sort buffer
     const size_t bin_words = B * (size_t)layers * p->tiles * ((N + FGS_BIN_G - 1) / FGS_BIN_G);
     if (bin_words > nsort) nsort = bin_words;
-    const size_t nblk = (B * N + 255) / 256;
+    // block sums of the duplicate-offset scan: per image and block of FGS_BIN_G depth ranks (direct binning) or per
+    // 256 flat elements (radix path) -- whichever is more
+    const size_t nblk = B * ((N + FGS_BIN_G - 1) / FGS_BIN_G) + (B * N + 255) / 256 + 1;
     size_t hist = fgs_radix_hist_bytes((uint32_t)N, (uint32_t)B);
     const size_t hist2 = fgs_radix_hist_bytes((uint32_t)dcap, 1);
     if (hist2 > hist) hist = hist2;

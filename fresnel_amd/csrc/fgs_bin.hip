@@ -11,15 +11,6 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_sort_init(uint32_t total, uint32_t N,
-                                                   const uint32_t *__restrict__ depth_key,
-                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    keys[i] = depth_key[i];
-    vals[i] = i % N;
-}
-
 // exclusive scan of one value per thread over a 256-thread block; returns block total in *tot
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *tot) {
     __shared__ uint32_t wsum[4];
@@ -134,30 +125,20 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
 // ---------------------------------------------------------------------------------------------------------
 // Direct binning (single layer, <= BIN_MAX_TILES tiles per image): a counting sort straight from the bboxes, in
 // place of "emit (tile key, id) pairs, then two stable radix passes over them".
-//   k_dup_off      dup_off[g] = first duplicate slot of Gaussian g (emission order: image, depth rank, tile row,
-//                  tile column) -- the gradient-row addressing of the backward;
 //   k_bin_count    one block per BIN_G consecutive depth ranks of one image: per-tile counts in LDS
-//                  -> cnt[image][block][tile];
+//                  -> cnt[image][block][tile]; also the block's number of duplicates -> bsum;
 //   k_bin_scan     one thread per (image, tile): exclusive scan of its column over the blocks (in place), column
-//                  total = list length;
+//                  total = list length; its last block scans bsum (duplicate offsets, total D -> counters);
 //   k_tile_order   turns the lengths into [start, end) ranges (and launch order, depth segments);
 //   k_bin_scatter  one wave per block of depth ranks walks its Gaussians IN ORDER and drops each id at
-//                  start[tile] + cnt[image][block][tile] + (ids this block already put into the tile).
+//                  start[tile] + cnt[image][block][tile] + (ids this block already put into the tile); also writes
+//                  dup_off[g] = first duplicate slot of Gaussian g (emission order: image, depth rank, tile row, tile
+//                  column -- the gradient-row addressing of the backward) and its share of the unit -> tile table.
 // Every list comes out in depth order, exactly as the stable sort produced it, with one scattered 4-byte store
 // per duplicate instead of four (two passes x key + payload) and no key traffic at all
 // (emit 0.052 + sort 0.148 + ranges 0.012 ms -> offsets/count/scan 0.030 + scatter 0.080 ms at config 3).
 constexpr uint32_t BIN_G = FGS_BIN_G;    // depth ranks per binning block
 constexpr uint32_t BIN_MAX_TILES = FGS_BIN_MAX_TILES; // LDS counters per block (16 KB)
-
-__global__ __launch_bounds__(256) void k_dup_off(uint32_t total, uint32_t N, const uint32_t *__restrict__ order,
-                                                 const uint32_t *__restrict__ tile_count,
-                                                 const uint32_t *__restrict__ bsum, uint32_t *__restrict__ dup_off) {
-    uint32_t gid, tot;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t c = sorted_count(i, total, N, order, tile_count, &gid);
-    const uint32_t off = bsum[blockIdx.x] + block_exclusive_scan_256(c, &tot);
-    if (i < total) dup_off[gid] = off;
-}
 
 struct TileRect { uint32_t tx0, ty0, w, cnt; };
 __device__ __forceinline__ TileRect tile_rect(const float *__restrict__ rec, uint32_t gid, uint32_t cnt) {
@@ -175,25 +156,57 @@ __device__ __forceinline__ TileRect tile_rect(const float *__restrict__ rec, uin
 __global__ __launch_bounds__(256) void k_bin_count(uint32_t N, uint32_t tiles, uint32_t tiles_x, uint32_t bpi,
                                                    const uint32_t *__restrict__ order,
                                                    const uint32_t *__restrict__ tile_count,
-                                                   const float *__restrict__ rec, uint32_t *__restrict__ cnt) {
+                                                   const float *__restrict__ rec, uint32_t *__restrict__ cnt,
+                                                   uint32_t *__restrict__ bsum) {
     __shared__ uint32_t hist[BIN_MAX_TILES];
+    __shared__ uint32_t btot;
     const uint32_t b = blockIdx.x / bpi, blk = blockIdx.x - b * bpi;
     for (uint32_t t = threadIdx.x; t < tiles; t += 256) hist[t] = 0;
+    if (threadIdx.x == 0) btot = 0;
     __syncthreads();
     const uint32_t r = blk * BIN_G + threadIdx.x;
+    uint32_t mine = 0;
     if (threadIdx.x < BIN_G && r < N) {
         const uint32_t gid = b * N + order[b * N + r];
         const TileRect q = tile_rect(rec, gid, tile_count[gid]);
+        mine = q.cnt;
         const uint32_t h = q.cnt / q.w;
         for (uint32_t y = 0; y < h; ++y)
             for (uint32_t x = 0; x < q.w; ++x) atomicAdd(&hist[(q.ty0 + y) * tiles_x + q.tx0 + x], 1u);
     }
+    // duplicates of this block of depth ranks: the block sums of the duplicate-offset scan (k_bin_scan's last block
+    // scans them, k_bin_scatter adds the ranks' own prefix)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&btot, mine);
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < tiles; t += 256) cnt[((size_t)b * bpi + blk) * tiles + t] = hist[t];
+    if (threadIdx.x == 0) bsum[blockIdx.x] = btot;
 }
 
 __global__ __launch_bounds__(256) void k_bin_scan(uint32_t B, uint32_t tiles, uint32_t bpi, uint32_t *__restrict__ cnt,
-                                                  uint32_t *__restrict__ lens) {
+                                                  uint32_t *__restrict__ lens, uint32_t *__restrict__ bsum,
+                                                  uint32_t *__restrict__ counters, uint32_t dcap) {
+    if (blockIdx.x == gridDim.x - 1) {
+        // last block: in-place exclusive scan of the B * bpi block sums of k_bin_count (duplicate offsets in depth
+        // order, image-major), total -> counters[0] (clamped), overflow flag -> counters[1]
+        const uint32_t n = B * bpi;
+        unsigned long long carry = 0;
+        for (uint32_t base = 0; base < n; base += 256) {
+            const uint32_t i = base + threadIdx.x;
+            const uint32_t v = i < n ? bsum[i] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_exclusive_scan_256(v, &tot);
+            if (i < n) bsum[i] = (uint32_t)carry + ex;
+            carry += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            counters[0] = carry > dcap ? dcap : (uint32_t)carry;
+            counters[1] = carry > dcap ? 1u : 0u;
+        }
+        return;
+    }
     // thread = one (image, tile) column of cnt[image][block][tile]; walks the blocks serially (every load of a
     // wave is one contiguous run of tiles), exclusive scan in place, column total = list length
     const uint32_t col = blockIdx.x * 256 + threadIdx.x;
@@ -226,11 +239,58 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
                                                          const float *__restrict__ rec,
                                                          const uint32_t *__restrict__ cnt,
                                                          const uint32_t *__restrict__ ranges,
-                                                         uint32_t *__restrict__ dup_ids) {
+                                                         uint32_t *__restrict__ dup_ids,
+                                                         const uint32_t *__restrict__ bsum,
+                                                         uint32_t *__restrict__ dup_off,
+                                                         const uint32_t *__restrict__ seg_off,
+                                                         uint32_t *__restrict__ seg_tile) {
     constexpr uint32_t T_MAX = NW == 1 ? BIN_MAX_TILES : BIN_MAX_TILES / NW;
     constexpr uint32_t WG = BIN_G / NW;  // ranks per wave
     __shared__ uint32_t run[NW][T_MAX];  // next free slot of every tile list, per wave
-    const uint32_t b = blockIdx.x / bpi, blk = blockIdx.x - b * bpi;
+    // consecutive rank blocks append to neighbouring list slots: keep them on one XCD so that the 4-byte entries
+    // merge into full lines in its L2 (the write side was 6x the list bytes without the remap)
+    const uint32_t lb = fgs_xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t b = lb / bpi, blk = lb - b * bpi;
+    // (a) duplicate offsets of this block's depth ranks: dup_off[g] = first gradient-row / emission slot of
+    //     Gaussian g = scanned block sum + prefix of the tile counts inside the block (rank order)
+    for (uint32_t r0 = 0; r0 < BIN_G; r0 += 64 * NW) {
+        __shared__ uint32_t carry_sh;
+        if (threadIdx.x == 0 && r0 == 0) carry_sh = bsum[lb];
+        const uint32_t r = blk * BIN_G + r0 + threadIdx.x;
+        uint32_t g = 0, c = 0;
+        if (r0 + threadIdx.x < BIN_G && r < N) { g = b * N + order[b * N + r]; c = tile_count[g]; }
+        // inclusive scan over the block's 64 * NW threads (wave scans + serial sum of the wave totals)
+        __shared__ uint32_t wtot[NW];
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if ((int)(threadIdx.x & 63u) >= o) x += y;
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63u) == 63u) wtot[threadIdx.x >> 6] = x;
+        __syncthreads();
+        uint32_t pre = carry_sh, all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            pre += (w < (int)(threadIdx.x >> 6)) ? wtot[w] : 0u;
+            all += wtot[w];
+        }
+        if (r0 + threadIdx.x < BIN_G && r < N) dup_off[g] = pre + x - c;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_sh += all;
+    }
+    // (b) unit -> tile table of this block's share of the image's tiles (the backward's work-unit list)
+    if (seg_tile) {
+        const uint32_t tpb = (tiles + bpi - 1) / bpi;
+        for (uint32_t k = threadIdx.x; k < tpb; k += 64 * NW) {
+            const uint32_t t = blk * tpb + k;
+            if (t < tiles) {
+                const uint32_t bt = b * tiles + t, o0 = seg_off[bt], o1 = seg_off[bt + 1];
+                for (uint32_t u = o0; u < o1; ++u) seg_tile[u] = bt;
+            }
+        }
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     // this lane's Gaussian of each 64-rank batch of the wave (WG / 64 batches)
@@ -290,7 +350,11 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
                 const uint32_t tile = (tyg + y) * tiles_x + txg + (t - y * wg);
                 const uint32_t pos = run[wave][tile];  // tiles of one Gaussian are distinct: plain read-modify-write
                 run[wave][tile] = pos + 1;
+#ifndef FGS_EXP_NOSTORE
                 if (pos < dcap) dup_ids[pos] = idg;
+#else
+                if (pos == 0xFFFFFFF0u) dup_ids[pos] = idg;
+#endif
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -398,7 +462,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, uint32_t *
         if (lens) { ranges[2 * t] = lstart; ranges[2 * t + 1] = lstart + len; }
         if (seg_off) {
             seg_off[t] = off;
-            for (uint32_t k = 0; k < n; ++k) seg_tile[off + k] = t;
+            if (seg_tile) for (uint32_t k = 0; k < n; ++k) seg_tile[off + k] = t;  // (direct binning: k_bin_scatter fills it)
         }
         off64 += ((unsigned long long)len << 32) | n;
     }
@@ -448,52 +512,55 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
 
     // (1) canonical depth order per image
     fgs_stage_begin(ST_DEPTH_SORT, st);
-    hipLaunchKernelGGL(k_sort_init, dim3(nblk), dim3(256), 0, st, total, N, depth_key, keys0, vals0);
-    FGS_LAUNCH_CHECK("k_sort_init");
+    // keys straight from the projection's depth_key (read-only), payload = index inside the image, generated by the
+    // first pass; per-pass prefix formed inside the downsweep: 8 launches (was 13)
     uint32_t *ks, *vs;
-    int rc = fgs_launch_radix_sort(keys0, vals0, keys1, vals1, order, &ks, &vs, N, nullptr, N, N, B, 32, hist, st);
+    int rc = fgs_launch_radix_sort(keys0, vals0, keys1, vals1, order, &ks, &vs, N, nullptr, N, N, B, 32, hist, st,
+                                   depth_key, N);
     if (rc) return rc;
     fgs_stage_end(ST_DEPTH_SORT, st);
     const uint32_t ntiles_all = B * (uint32_t)p.layers * (uint32_t)p.tiles;
     uint32_t *tile_order = reinterpret_cast<uint32_t *>(saved + p.L.tile_order);
     uint32_t *seg_off = p.L.seg_capacity ? reinterpret_cast<uint32_t *>(saved + p.L.seg_off) : nullptr;
     uint32_t *seg_tile = p.L.seg_capacity ? reinterpret_cast<uint32_t *>(saved + p.L.seg_tile) : nullptr;
+    if (p.direct_binning) {
+        // direct binning: counting sort straight from the bboxes (see k_bin_count): 4 launches
+        const uint32_t bpi = (N + BIN_G - 1) / BIN_G;
+        uint32_t *cnt = keys0;               // [B][tiles][bpi], fits: keys0 holds >= Dcap words
+        uint32_t *lens = keys1;              // [B * tiles]
+        uint32_t *dup_off = reinterpret_cast<uint32_t *>(saved + p.L.dup_off);
+        fgs_stage_begin(ST_DUP_EMIT, st);
+        hipLaunchKernelGGL(k_bin_count, dim3(B * bpi), dim3(256), 0, st, N, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
+                           bpi, order, tile_count, rec, cnt, bsum);
+        FGS_LAUNCH_CHECK("k_bin_count");
+        hipLaunchKernelGGL(k_bin_scan, dim3((ntiles_all + 255) / 256 + 1), dim3(256), 0, st, B, (uint32_t)p.tiles, bpi,
+                           cnt, lens, bsum, counters, dcap);
+        FGS_LAUNCH_CHECK("k_bin_scan");
+        fgs_stage_end(ST_DUP_EMIT, st);
+        fgs_stage_begin(ST_TILE_RANGES, st);
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ntiles_all, ranges, lens, tile_order, seg_off,
+                           (uint32_t *)nullptr, counters, (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant);
+        FGS_LAUNCH_CHECK("k_tile_order");
+        fgs_stage_end(ST_TILE_RANGES, st);
+        fgs_stage_begin(ST_TILE_SORT, st);
+        if ((uint32_t)p.tiles <= BIN_MAX_TILES / 4)
+            hipLaunchKernelGGL(k_bin_scatter<4>, dim3(B * bpi), dim3(256), 0, st, N, (uint32_t)p.tiles,
+                               (uint32_t)p.L.tiles_x, bpi, dcap, order, tile_count, rec, cnt, ranges, dup_ids, bsum,
+                               dup_off, seg_off, seg_tile);
+        else
+            hipLaunchKernelGGL(k_bin_scatter<1>, dim3(B * bpi), dim3(64), 0, st, N, (uint32_t)p.tiles,
+                               (uint32_t)p.L.tiles_x, bpi, dcap, order, tile_count, rec, cnt, ranges, dup_ids, bsum,
+                               dup_off, seg_off, seg_tile);
+        FGS_LAUNCH_CHECK("k_bin_scatter");
+        fgs_stage_end(ST_TILE_SORT, st);
+        return FGS_OK;
+    }
     fgs_stage_begin(ST_DUP_EMIT, st);
     // (2) duplicate offsets (exclusive scan over Gaussians in depth order, image-major)
     hipLaunchKernelGGL(k_dup_blocksum, dim3(nblk), dim3(256), 0, st, total, N, order, tile_count, bsum);
     FGS_LAUNCH_CHECK("k_dup_blocksum");
     hipLaunchKernelGGL(k_dup_scan_bsum, dim3(1), dim3(256), 0, st, nblk, bsum, counters, dcap);
     FGS_LAUNCH_CHECK("k_dup_scan_bsum");
-    if (p.direct_binning) {
-        // direct binning: counting sort straight from the bboxes (see k_bin_count)
-        const uint32_t bpi = (N + BIN_G - 1) / BIN_G;
-        uint32_t *cnt = keys0;               // [B][tiles][bpi], fits: keys0 holds >= Dcap words
-        uint32_t *lens = keys1;              // [B * tiles]
-        hipLaunchKernelGGL(k_dup_off, dim3(nblk), dim3(256), 0, st, total, N, order, tile_count, bsum,
-                           reinterpret_cast<uint32_t *>(saved + p.L.dup_off));
-        FGS_LAUNCH_CHECK("k_dup_off");
-        hipLaunchKernelGGL(k_bin_count, dim3(B * bpi), dim3(256), 0, st, N, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
-                           bpi, order, tile_count, rec, cnt);
-        FGS_LAUNCH_CHECK("k_bin_count");
-        hipLaunchKernelGGL(k_bin_scan, dim3((ntiles_all + 255) / 256), dim3(256), 0, st, B, (uint32_t)p.tiles, bpi, cnt, lens);
-        FGS_LAUNCH_CHECK("k_bin_scan");
-        fgs_stage_end(ST_DUP_EMIT, st);
-        fgs_stage_begin(ST_TILE_RANGES, st);
-        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ntiles_all, ranges, lens, tile_order, seg_off,
-                           seg_tile, counters, (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant);
-        FGS_LAUNCH_CHECK("k_tile_order");
-        fgs_stage_end(ST_TILE_RANGES, st);
-        fgs_stage_begin(ST_TILE_SORT, st);
-        if ((uint32_t)p.tiles <= BIN_MAX_TILES / 4)
-            hipLaunchKernelGGL(k_bin_scatter<4>, dim3(B * bpi), dim3(256), 0, st, N, (uint32_t)p.tiles,
-                               (uint32_t)p.L.tiles_x, bpi, dcap, order, tile_count, rec, cnt, ranges, dup_ids);
-        else
-            hipLaunchKernelGGL(k_bin_scatter<1>, dim3(B * bpi), dim3(64), 0, st, N, (uint32_t)p.tiles,
-                               (uint32_t)p.L.tiles_x, bpi, dcap, order, tile_count, rec, cnt, ranges, dup_ids);
-        FGS_LAUNCH_CHECK("k_bin_scatter");
-        fgs_stage_end(ST_TILE_SORT, st);
-        return FGS_OK;
-    }
     // (3) emit (tile key, gaussian id) in depth order
     hipLaunchKernelGGL(k_dup_emit, dim3(nblk), dim3(256), 0, st, total, N, (uint32_t)p.tiles,
                        (uint32_t)p.L.tiles_x, dcap, order, tile_count, rec, bsum,

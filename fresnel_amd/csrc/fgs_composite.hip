@@ -430,16 +430,24 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     float *__restrict__ grad_rows, float t_eps) {
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
-    __shared__ __attribute__((aligned(16))) float red[10][80];  // per-lane partial sums of one list entry, transposed
+#ifdef FGS_AB_OLD_REDUCE
+    __shared__ __attribute__((aligned(16))) float red[10][80];
+#else
+    __shared__ __attribute__((aligned(16))) float red[10 * FGS_RED_PITCH];  // per-lane partial sums of one list entry
+#endif
     // work unit = (tile, depth segment): blockIdx.x indexes the unit list built by k_tile_order; the grid is
     // sized from the capacity, surplus blocks leave at once
-    if (blockIdx.x >= counters[2]) return;
+    const uint32_t num_units = counters[2];
+    if (blockIdx.x >= num_units) return;
+    // units are listed tile by tile: an XCD gets a contiguous run of them, so neighbouring tiles -- which share
+    // Gaussians, and write adjacent 40-byte gradient rows -- meet in one L2
+    const uint32_t unit = fgs_xcd_remap(blockIdx.x, num_units);
     // the split the forward ran with, as the forward recorded it (k_tile_order): segment length, and the number of
     // list parts of the depth-split forward (> 1: checkpoints inside a later part are part-local)
     const uint32_t seg_len = counters[4];
     const uint32_t fwd_parts = (int32_t)counters[5] > 1 ? counters[5] : 0u;
-    const uint32_t unit_tile = seg_tile[blockIdx.x];
-    const uint32_t seg = blockIdx.x - seg_off[unit_tile];
+    const uint32_t unit_tile = seg_tile[unit];
+    const uint32_t seg = unit - seg_off[unit_tile];
     TileCtx c = tile_ctx_of(unit_tile, tiles, tiles_x, ranges);
     uint32_t rebase_seg = seg;  // first segment of this segment's list part if its checkpoint is part-local
     if (fwd_parts > 1) {
@@ -499,9 +507,9 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             // belongs to the list entries before it.  After a depth-split forward (k_blend_fwd_parts, fwd_parts
             // waves per tile) the checkpoint of a segment inside part p > 0 is local to that part and is re-based
             // with the absolute state kept in the slot of the part's first segment.
-            BlendState st = ckpt_load(seg_ckpt + (size_t)blockIdx.x * (5 * 256) + s * 64 + lane);
+            BlendState st = ckpt_load(seg_ckpt + (size_t)unit * (5 * 256) + s * 64 + lane);
             if (rebase_seg != seg) {
-                const size_t slot = (size_t)blockIdx.x - seg + rebase_seg;
+                const size_t slot = (size_t)unit - seg + rebase_seg;
                 st = compose(ckpt_load(seg_ckpt + slot * (5 * 256) + s * 64 + lane), st);
             }
             T[s] = st.T;
@@ -578,9 +586,12 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                     const float alpha = CLAMP ? fminf(raw, 0.99f) : raw;
                     const float w = alpha * T[s];
                     const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
-                    S[s] -= w * q;
+                    // S -= w q and T -= w as in-place (tied-operand) updates: the four code variants below then keep
+                    // T and S in the same eight registers, without which the loop carried them through eight
+                    // v_mov per list entry
+                    asm("v_fma_f32 %0, -%1, %2, %0" : "+v"(S[s]) : "v"(w), "v"(q));
                     const float dalpha = T[s] * q - S[s] * __builtin_amdgcn_rcpf(1.0f - alpha);
-                    T[s] -= w;
+                    asm("v_sub_f32 %0, %0, %1" : "+v"(T[s]) : "v"(w));
                     // clamp backward: closed interval [0, 0.99]
                     const float dG = (CLAMP ? select_le(raw, 0.99f, dalpha) : dalpha) * G;
                     v_op += dG;
@@ -599,7 +610,11 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             // into this duplicate's gradient row: no atomics, fixed order, bitwise reproducible ----
             {
                 const float vals[10] = {v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d};
+#ifdef FGS_AB_OLD_REDUCE
                 const float tot = wave_sum_transposed<10>(red, vals, lane);
+#else
+                const float tot = wave_sum10_addtid(red, vals, lane);
+#endif
                 const uint32_t kk = lane >> 2, e = she[j];
                 // dL/dconic = K * (sums in exp2 units); the other seven sums are already final
                 const float scl = (kk >= 2u && kk <= 4u) ? NEG_HALF_LOG2E : 1.0f;
@@ -628,11 +643,15 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ float shp[CH];
     __shared__ uint32_t she[CH];
-    __shared__ float2 st[PCK][4][64];
-    __shared__ __attribute__((aligned(16))) float red4[4][11][80];  // wave_sum_transposed scratch, one per wave
+    __shared__ uint32_t shm[CH];  // touched sub-tiles of each staged record (4-bit mask)
+    // reduction scratch, one per wave (wave_sum11_addtid).  The (A, Phi) states parked by the forward re-run of a
+    // sub-chunk live in REGISTERS (both loops over a sub-chunk are fully unrolled): the block's static LDS is
+    // 16 KB instead of 37 KB, so occupancy is bounded by the 8 wave slots per SIMD, not by LDS -- this path is a
+    // serial cos / sin / divide chain per pixel and lives on latency hiding
+    __shared__ __attribute__((aligned(16))) float red4[4][11 * FGS_RED_PITCH];
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
-    // FOUR waves per tile, wave w owns the 8x8 sub-tile w and writes its OWN gradient row per list entry
-    // (row 4 e + w; k_project_bwd sums four rows per duplicate): the recurrence is a long serial chain per
+    // FOUR waves per tile, wave w owns the 8x8 sub-tile w and writes its OWN gradient row per list entry it touches
+    // (row 4 e + w; k_project_bwd sums the rows of the touched sub-tiles of every duplicate): the recurrence is a long serial chain per
     // pixel (cos / sin / divide per entry, forward re-run + reverse sweep), so this path is latency-bound and
     // four independent waves per tile cut the critical path ~4x without any cross-wave reduction.
     const uint32_t lane = threadIdx.x & 63u;
@@ -641,7 +660,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
     const size_t HW = (size_t)W * H;
     const uint32_t sx = c.X0 + 8u * (wave & 1u), sy = c.Y0 + 8u * (wave >> 1);
     const uint32_t px = sx + lx, py = sy + ly;
-    float (*red)[80] = red4[wave];
+    float *red = red4[wave];
     float gr, gg, gb, gd, Abar, Pbar;
     {
         gr = gg = gb = gd = 0.0f;
@@ -675,25 +694,37 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
             const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
             const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE;
             she[lane_s] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
+            shm[lane_s] = subtile_mask(c.X0, c.Y0, bbx & 0xFFFFu, bbx >> 16, bby & 0xFFFFu, bby >> 16);
         }
         __syncthreads();
+        // entries of this chunk whose bbox touches THIS wave's sub-tile, as a 64-bit scalar mask: untouched entries
+        // cost nothing below (no LDS reads, no bbox arithmetic, no gradient row -- k_project_bwd repeats the same
+        // integer test and never reads the rows of untouched sub-tiles), and a sub-chunk without touched entries
+        // is skipped with its checkpoint load
+        const unsigned long long touched = __ballot(lane < n && ((shm[lane] >> wave) & 1u));
         const uint32_t nsub = (n + PCK - 1) / PCK;
         for (uint32_t si = nsub; si-- > 0;) {
             const uint32_t j0 = si * PCK;
             const uint32_t m = min((uint32_t)PCK, n - j0);
+            const uint32_t tsub = (uint32_t)(touched >> j0) & ((1u << PCK) - 1u);
+            if (!tsub) continue;
             const size_t slot = (size_t)(c.start / PCK) + (ci * CH + j0) / PCK + c.tile;
             const float *ck = phase_ckpt + slot * 512 + lane;
             float Af = ck[wave * 64], Pf = ck[(4 + wave) * 64];
             // ---- forward re-run of the sub-chunk: park (A_{i-1}, Phi_{i-1}) ----
-            for (uint32_t k = 0; k < m; ++k) {
+            float sA[PCK], sP[PCK];
+#pragma unroll
+            for (int k = 0; k < PCK; ++k) {
+                sA[k] = 0.0f; sP[k] = 0.0f;
+                if (k >= (int)m || !((tsub >> k) & 1u)) continue;  // wave-uniform
                 const uint32_t j = j0 + k;
                 const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
                 const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
                 const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
                 const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
                 const float ph = shp[j];
-                if (!(x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u)) {
-                    st[k][wave][lane] = make_float2(Af, Pf);
+                {
+                    sA[k] = Af; sP[k] = Pf;
                     const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
                     const float dx = (float)px - q0.x, dy = (float)py - q0.y;
                     const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
@@ -710,7 +741,9 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                 }
             }
             // ---- reverse sweep of the sub-chunk ----
-            for (uint32_t k = m; k-- > 0;) {
+#pragma unroll
+            for (int k = PCK - 1; k >= 0; --k) {
+                if (k >= (int)m || !((tsub >> k) & 1u)) continue;  // wave-uniform
                 const uint32_t j = j0 + k;
                 const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
                 const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
@@ -721,14 +754,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                 float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0,
                       v_ph = 0;
                 const uint32_t e = she[j];
-                if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) {
-                    // sub-tile not touched: this wave's row of the duplicate is all zeros
-                    if (lane < 12u && e < dcap) grad_rows[((size_t)e * 4 + wave) * FGS_GROW_FLOATS + lane] = 0.0f;
-                    continue;
-                }
                 {
-                    const float2 sv = st[k][wave][lane];
-                    const float Aprev = sv.x, Pprev = sv.y;
+                    const float Aprev = sA[k], Pprev = sP[k];
                     const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
                     const float dx = (float)px - q0.x, dy = (float)py - q0.y;
                     const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
@@ -778,7 +805,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                 }
                 {
                     const float vals[11] = {v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d, v_ph};
-                    const float tot = wave_sum_transposed<11>(red, vals, lane);
+                    const float tot = wave_sum11_addtid(red, vals, lane);
                     if ((lane & 3u) == 3u && lane < 44u && e < dcap)
                         grad_rows[((size_t)e * 4 + wave) * FGS_GROW_FLOATS + (lane >> 2)] = tot;
                 }

@@ -85,7 +85,8 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
                           uint32_t **keys_sorted /*out: which buffer holds sorted keys*/,
                           uint32_t **vals_sorted, uint32_t seg_len, const uint32_t *seg_len_dev,
                           uint32_t seg_capacity, uint32_t seg_stride, uint32_t num_segs, uint32_t key_bits,
-                          uint32_t *hist, hipStream_t st);
+                          uint32_t *hist, hipStream_t st, const uint32_t *keys_first = nullptr,
+                          uint32_t index_payload_mod = 0);
 size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs);
 
 int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t st);
@@ -97,6 +98,22 @@ int fgs_launch_count_pairs(const FgsPlan &p, const char *saved, uint64_t *out, h
 
 // ---- small device helpers ----
 __device__ __forceinline__ uint32_t fgs_lane() { return threadIdx.x & 63u; }
+
+// XCD-aware block remap (cdna_hip_programming.md T1).  Workgroups are dealt round-robin over the 8 XCDs, each with
+// its own L2, so blocks bid and bid + 1 never share an L2.  remap(bid) gives every XCD a CONTIGUOUS range of
+// logical work items: neighbours in the work list (adjacent depth-rank blocks of one image, adjacent tiles) then hit
+// the same L2 -- shared records are fetched once and, more importantly, partial-line writes to neighbouring
+// addresses (4-byte list entries, 40-byte gradient rows) merge in that L2 instead of reaching HBM as masked
+// partial writes from several XCDs.  Bijective on [0, nwg) for any nwg; placement only, never correctness.
+__device__ __forceinline__ uint32_t fgs_xcd_remap(uint32_t bid, uint32_t nwg) {
+#ifdef FGS_NO_XCD_REMAP
+    (void)nwg;
+    return bid;
+#else
+    const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, i = bid >> 3;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + i;
+#endif
+}
 
 // order-preserving map float -> uint32 (ascending), -0.0 folded into +0.0
 __device__ __forceinline__ uint32_t fgs_float_key(float f) {

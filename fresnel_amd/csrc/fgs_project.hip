@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const float *__restrict__ grad_rows, float *__restrict__ g_pos, float *__restrict__ g_scale,
     float *__restrict__ g_quat, float *__restrict__ g_color, float *__restrict__ g_opacity,
     float *__restrict__ g_phase, const float *__restrict__ color, const float *__restrict__ phase,
-    int32_t phase_channels, uint32_t rows_per_dup) {
+    int32_t phase_channels, uint32_t rows_per_dup, const float *__restrict__ rec) {
     // four lanes per Gaussian: lane `sub` sums rows sub, sub+4, ... (neighbouring lanes read
     // neighbouring 48-byte rows), then two quad shuffles combine the partial sums in a fixed order
     const int32_t tid = blockIdx.x * 256 + threadIdx.x;
@@ -199,6 +199,25 @@ __global__ __launch_bounds__(256) void k_project_bwd(
                 const float2 a = r[0], bq = r[1], cq = r[2], dq = r[3], eq = r[4];
                 acc[0] += a.x; acc[1] += a.y; acc[2] += bq.x; acc[3] += bq.y; acc[4] += cq.x;
                 acc[5] += cq.y; acc[6] += dq.x; acc[7] += dq.y; acc[8] += eq.x; acc[9] += eq.y;
+            }
+        } else if (MODE == 0) {
+            // phase path: FOUR rows per duplicate, one per 8x8 sub-tile wave of k_composite_bwd_phase, which writes
+            // only the rows of sub-tiles the bbox touches -- the same integer test decides here which rows exist
+            // (lane `sub` of the quad owns sub-tile `sub` of every duplicate)
+            const uint32_t bbx = __float_as_uint(rec[(size_t)idx * FGS_REC_FLOATS + R_BBX]);
+            const uint32_t bby = __float_as_uint(rec[(size_t)idx * FGS_REC_FLOATS + R_BBY]);
+            const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
+            const uint32_t tx0 = x0 / FGS_TILE, ty0 = y0 / FGS_TILE, tw = (x1 - 1) / FGS_TILE - tx0 + 1;
+            uint32_t tx = 0, ty = 0;  // tile of duplicate k / 4, walked without a division
+            for (uint32_t k = sub; k < cnt && off + k < dcap * rows_per_dup; k += 4) {
+                const uint32_t sx = (tx0 + tx) * FGS_TILE + 8u * (sub & 1u), sy = (ty0 + ty) * FGS_TILE + 8u * (sub >> 1);
+                if (++tx == tw) { tx = 0; ++ty; }
+                if (x1 <= sx || x0 >= sx + 8u || y1 <= sy || y0 >= sy + 8u) continue;  // row never written
+                const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * ROWF);
+                const float4 a = r[0], bq = r[1], cq = r[2];
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
+                acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z; acc[11] += cq.w;
             }
         } else
         for (uint32_t k = sub; k < cnt && off + k < dcap * rows_per_dup; k += 4) {
@@ -420,7 +439,7 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
                        g_quat, g_color, g_opacity, g_phase, nullptr, nullptr, p.d.use_phase ? 0 : 1,
-                       p.d.use_phase ? 4u : 1u);
+                       p.d.use_phase ? 4u : 1u, reinterpret_cast<const float *>(saved + p.L.rec));
     FGS_LAUNCH_CHECK("k_project_bwd");
     return FGS_OK;
 }
@@ -439,7 +458,7 @@ int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float 
                            reinterpret_cast<const uint32_t *>(saved + p.L.order),
                            reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                            reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                           g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u);
+                           g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u, nullptr);
         FGS_LAUNCH_CHECK("k_wave_project_bwd");
         return FGS_OK;
     }
@@ -449,7 +468,7 @@ int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float 
                        reinterpret_cast<const uint32_t *>(saved + p.L.order),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                       g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u);
+                       g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u, nullptr);
     FGS_LAUNCH_CHECK("k_asm_project_bwd");
     return FGS_OK;
 }

@@ -81,7 +81,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t seg_len,
     const uint32_t *__restrict__ seg_len_dev, uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift,
-    uint32_t dmask, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ dtot) {
+    uint32_t dmask, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ dtot, uint32_t idx_mod) {
+    // dtot == nullptr: `hist` holds the RAW per-block digit counts of k_radix_upsweep and this block forms its own
+    // prefix (sum over the blocks before it, total over all of them) -- no k_radix_scan launch; used when a segment
+    // has few blocks (the depth sort: 13 launches -> 8, every one of them at the ~4.5 us launch floor).
+    // vals_in == nullptr: the payload is the element's index modulo idx_mod (first pass of the depth sort).
     __shared__ uint32_t run_off[256];
     __shared__ uint32_t wcnt[RS_WAVES][256];
     __shared__ uint32_t scan_tmp[256];
@@ -89,7 +93,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
     const SegInfo r = block_range(seg_len, seg_len_dev, seg_capacity, seg_stride);
     // exclusive scan of the 256 digit totals of this segment (Hillis-Steele in LDS)
     {
-        const uint32_t t = dtot[blockIdx.y * 256 + tid];
+        uint32_t t, mine;
+        if (dtot) {
+            t = dtot[blockIdx.y * 256 + tid];
+            mine = hist[((size_t)blockIdx.y * 256 + tid) * gridDim.x + blockIdx.x];
+        } else {
+            const uint32_t *row = hist + ((size_t)blockIdx.y * 256 + tid) * gridDim.x;
+            t = 0; mine = 0;
+            for (uint32_t k = 0; k < gridDim.x; ++k) {
+                const uint32_t c = row[k];
+                mine += k < blockIdx.x ? c : 0u;
+                t += c;
+            }
+        }
         scan_tmp[tid] = t;
         __syncthreads();
         uint32_t s = t;
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
             __syncthreads();
         }
         const uint32_t seg0 = blockIdx.y * seg_stride;
-        run_off[tid] = seg0 + (s - t) + hist[((size_t)blockIdx.y * 256 + tid) * gridDim.x + blockIdx.x];
+        run_off[tid] = seg0 + (s - t) + mine;
 #pragma unroll
         for (int w = 0; w < RS_WAVES; ++w) wcnt[w][tid] = 0;
     }
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
             const uint32_t i = base + wave * 256u + it * 64u + lane;
             valid[it] = i < r.end;
             key[it] = valid[it] ? keys_in[i] : 0u;
-            val[it] = valid[it] ? vals_in[i] : 0u;
+            val[it] = valid[it] ? (vals_in ? vals_in[i] : i % idx_mod) : 0u;
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -189,14 +205,19 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
                           uint32_t *vals_final, uint32_t **keys_sorted, uint32_t **vals_sorted,
                           uint32_t seg_len, const uint32_t *seg_len_dev, uint32_t seg_capacity,
                           uint32_t seg_stride, uint32_t num_segs, uint32_t key_bits, uint32_t *hist,
-                          hipStream_t st) {
+                          hipStream_t st, const uint32_t *keys_first, uint32_t index_payload_mod) {
     const uint32_t bps = blocks_per_seg(seg_capacity, num_segs);
     uint32_t *dtot = hist + (size_t)num_segs * 256 * bps;
     const uint32_t passes = (key_bits + 7) / 8;
     // equal digit widths over the passes (13 key bits -> 7 + 6, not 8 + 5): fewer bins per pass means longer
     // runs of neighbouring destinations in the scatter
     const uint32_t width = passes ? (key_bits + passes - 1) / passes : 8;
-    uint32_t *kin = keys_in, *vin = vals_in, *kout = keys_alt, *vout = vals_alt;
+    // keys_first: the first pass reads its keys from there (read-only) instead of keys_in; index_payload_mod != 0:
+    // the first pass generates the payload (element index modulo it) instead of reading vals_in
+    const uint32_t *kin = keys_first ? keys_first : keys_in;
+    uint32_t *vin = vals_in, *kout = keys_first ? keys_in : keys_alt, *vout = vals_alt;
+    uint32_t *kspare = keys_alt;
+    const bool fused_scan = bps <= 64;
     if (passes == 0) {
         if (vals_final && vals_final != vals_in) {
             // single possible key: already sorted; move the payload where the caller wants it
@@ -205,27 +226,34 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
             if (e != hipSuccess) { fgs_set_error("radix copy: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
             vin = vals_final;
         }
-        *keys_sorted = kin; *vals_sorted = vin;
+        *keys_sorted = const_cast<uint32_t *>(kin); *vals_sorted = vin;
         return FGS_OK;
     }
     (void)vout;
     for (uint32_t p = 0; p < passes; ++p) {
         uint32_t *vdst = (p == passes - 1 && vals_final) ? vals_final : (vin == vals_in ? vals_alt : vals_in);
+        if (p == 0 && index_payload_mod && !(passes == 1 && vals_final)) vdst = vals_in;  // vals_in is free: nothing to read
         const dim3 grid(bps, num_segs);
         hipLaunchKernelGGL(k_radix_upsweep, grid, dim3(RS_THREADS), 0, st, kin, seg_len, seg_len_dev,
                            seg_capacity, seg_stride, p * width, dmask_of(p, width, key_bits), hist);
         FGS_LAUNCH_CHECK("k_radix_upsweep");
         const uint32_t rows = num_segs * 256;
-        hipLaunchKernelGGL(k_radix_scan, dim3((rows + 3) / 4), dim3(256), 0, st, hist, dtot, bps, rows);
-        FGS_LAUNCH_CHECK("k_radix_scan");
-        hipLaunchKernelGGL(k_radix_downsweep, grid, dim3(RS_THREADS), 0, st, kin, vin, kout, vdst, seg_len,
-                           seg_len_dev, seg_capacity, seg_stride, p * width, dmask_of(p, width, key_bits), hist, dtot);
+        if (!fused_scan) {
+            hipLaunchKernelGGL(k_radix_scan, dim3((rows + 3) / 4), dim3(256), 0, st, hist, dtot, bps, rows);
+            FGS_LAUNCH_CHECK("k_radix_scan");
+        }
+        const uint32_t *vsrc = (p == 0 && index_payload_mod) ? nullptr : vin;
+        hipLaunchKernelGGL(k_radix_downsweep, grid, dim3(RS_THREADS), 0, st, kin, vsrc, kout, vdst, seg_len,
+                           seg_len_dev, seg_capacity, seg_stride, p * width, dmask_of(p, width, key_bits), hist,
+                           fused_scan ? (const uint32_t *)nullptr : dtot, index_payload_mod ? index_payload_mod : 1u);
         FGS_LAUNCH_CHECK("k_radix_downsweep");
-        uint32_t *t;
-        t = kin; kin = kout; kout = t;
+        // ping-pong: the buffer just read becomes the next output, except a read-only first-pass source
+        uint32_t *next_out = (p == 0 && keys_first) ? kspare : const_cast<uint32_t *>(kin);
+        kin = kout; kout = next_out;
         vin = vdst;
     }
-    *keys_sorted = kin;
+    *keys_sorted = const_cast<uint32_t *>(kin);
     *vals_sorted = vin;
     return FGS_OK;
 }
+
