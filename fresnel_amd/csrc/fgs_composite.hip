@@ -167,16 +167,65 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
             if (PHASE) shp[threadIdx.x] = phase[gid];
         }
         __syncthreads();
-        for (uint32_t j = 0; j < n; ++j) {
-            if (PHASE && (j % FGS_PHASE_CKPT) == 0) {
-                // (A, Phi) before list entry (base - start + j): the backward restarts from here
-                const size_t slot = (size_t)(c.start / FGS_PHASE_CKPT) + (base - c.start + j) / FGS_PHASE_CKPT + c.tile;
-                float *ck = phase_ckpt + slot * 512 + lane;
+        if constexpr (PHASE) {
+            // Phase path: the list walk visits only the entries whose bbox touches one of this wave's sub-tiles
+            // (64-bit scalar masks from the staged 4-bit sub-tile masks), in sub-chunks of FGS_PHASE_CKPT entries; a
+            // sub-chunk's (A, Phi) checkpoint is written when it has such an entry -- exactly the sub-chunks the
+            // backward's waves re-run (untouched entries leave the state as it is)
+            const uint32_t wmask = ((1u << NS) - 1u) << (wave * NS);
+            auto phase_entry = [&](uint32_t j) {
+                const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
+                const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
+                const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);  // origin | extent << 16
+                const float ph = shp[j];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) { ck[(wave * NS + s) * 64] = A[s]; ck[(4 + wave * NS + s) * 64] = Ph[s]; }
+                for (int s = 0; s < NS; ++s) {
+                    const uint32_t sg = wave * NS + s;  // sub-tile index inside the tile (scalar)
+                    if (!((msk >> sg) & 1u)) continue;  // scalar branch: sub-tile not touched
+                    const uint32_t px = c.X0 + 8u * (sg & 1) + lx, py = c.Y0 + 8u * (sg >> 1) + ly;
+                    const bool in = (px - (bbx & 0xFFFFu)) < (bbx >> 16) && (py - (bby & 0xFFFFu)) < (bby >> 16);
+                    const float dx = (float)px - q0.x, dy = (float)py - q0.y;
+                    const float m = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
+                    float alpha = __builtin_amdgcn_exp2f(m) * q1.y;
+                    if (PHASE) {
+                        float pd = fabsf(ph - Ph[s]);
+                        pd = fminf(pd, 1.0f - pd);
+                        alpha *= (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
+                    }
+                    alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
+                    alpha = in ? alpha : 0.0f;
+                    const float w = alpha * (1.0f - A[s]);
+                    Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
+                    A[s] += w;
+                    if (PHASE) {
+                        const float pc = w / fmaxf(A[s], 1e-6f);
+                        Ph[s] = in ? (Ph[s] * (1.0f - pc) + ph * pc) : Ph[s];
+                    }
+                }
+            };
+            for (uint32_t g0 = 0; g0 < n; g0 += 64) {
+                unsigned long long touched = __ballot(g0 + lane < n && (shm[g0 + lane] & wmask) != 0u);
+                while (touched) {
+                    const uint32_t sc = (uint32_t)(__ffsll((long long)touched) - 1) >> 3;  // sub-chunk inside the group
+                    uint32_t tsub = (uint32_t)(touched >> (8u * sc)) & 0xFFu;
+                    touched &= ~(0xFFull << (8u * sc));
+                    const uint32_t j0 = g0 + 8u * sc;
+                    static_assert(FGS_PHASE_CKPT == 8, "sub-chunk masks are bytes");
+                    const size_t slot = (size_t)(c.start / FGS_PHASE_CKPT) + (base - c.start + j0) / FGS_PHASE_CKPT + c.tile;
+                    float *ck = phase_ckpt + slot * 512 + lane;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { ck[(wave * NS + s) * 64] = A[s]; ck[(4 + wave * NS + s) * 64] = Ph[s]; }
+                    while (tsub) {
+                        const uint32_t k = (uint32_t)__ffs((int)tsub) - 1u;
+                        tsub &= tsub - 1u;
+                        phase_entry(j0 + k);
+                    }
+                }
             }
+        } else
+        for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-            if constexpr (!PHASE) {
+            {
                 // Non-phase blend.  Most list entries touch only one or two of a wave's sub-tiles, so nothing is
                 // precomputed beyond the row terms; bbox membership = the lane's column / row bit of the staged
                 // pixel bits as an all-ones / zero mask (v_bfe_i32) and-ed onto G (no compare / select).
@@ -205,33 +254,6 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
                     }
                 }
                 continue;
-            }
-            const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
-            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);  // origin | extent << 16
-            const float ph = PHASE ? shp[j] : 0.0f;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const uint32_t sg = wave * NS + s;  // sub-tile index inside the tile (scalar)
-                if (!((msk >> sg) & 1u)) continue;  // scalar branch: sub-tile not touched
-                const uint32_t px = c.X0 + 8u * (sg & 1) + lx, py = c.Y0 + 8u * (sg >> 1) + ly;
-                const bool in = (px - (bbx & 0xFFFFu)) < (bbx >> 16) && (py - (bby & 0xFFFFu)) < (bby >> 16);
-                const float dx = (float)px - q0.x, dy = (float)py - q0.y;
-                const float m = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
-                float alpha = __builtin_amdgcn_exp2f(m) * q1.y;
-                if (PHASE) {
-                    float pd = fabsf(ph - Ph[s]);
-                    pd = fminf(pd, 1.0f - pd);
-                    alpha *= (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
-                }
-                alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
-                alpha = in ? alpha : 0.0f;
-                const float w = alpha * (1.0f - A[s]);
-                Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
-                A[s] += w;
-                if (PHASE) {
-                    const float pc = w / fmaxf(A[s], 1e-6f);
-                    Ph[s] = in ? (Ph[s] * (1.0f - pc) + ph * pc) : Ph[s];
-                }
             }
         }
         __syncthreads();
