@@ -18,6 +18,7 @@ EXPORTED_SYMBOLS = [
     "fgs_last_error", "fgs_version", "fgs_stage_timing_enable", "fgs_stage_timing_read",
     "fgs_asm_workspace_bytes", "fgs_asm_forward", "fgs_asm_backward",
     "fgs_wave_workspace_bytes", "fgs_wave_forward", "fgs_wave_backward",
+    "fgs_gather_forward", "fgs_gather_backward",
 ]
 
 STAGES = ["project", "depth_sort", "dup_emit", "tile_sort", "tile_ranges", "composite_fwd",
@@ -101,6 +102,10 @@ def load():
     lib.fgs_wave_workspace_bytes.argtypes = [cp(FgsWaveDims), cp(ctypes.c_size_t), cp(ctypes.c_size_t)]
     lib.fgs_wave_forward.argtypes = [cp(FgsWaveDims)] + [vp] * 12
     lib.fgs_wave_backward.argtypes = [cp(FgsWaveDims)] + [vp] * 18
+    i32 = ctypes.c_int32
+    lib.fgs_gather_forward.argtypes = [i32, i32, i32, i32] + [vp] * 14
+    lib.fgs_gather_backward.argtypes = [i32, i32, i32, i32] + [vp] * 14
+    lib.fgs_gather_forward.restype = lib.fgs_gather_backward.restype = ctypes.c_int
     for fn in (lib.fgs_asm_workspace_bytes, lib.fgs_asm_forward, lib.fgs_asm_backward,
                lib.fgs_wave_workspace_bytes, lib.fgs_wave_forward, lib.fgs_wave_backward):
         fn.restype = ctypes.c_int

@@ -26,6 +26,7 @@ SOURCES = {
     "fgs_bin.hip": [],
     "fgs_composite.hip": ["-ffast-math", "-fno-finite-math-only", "-fno-slp-vectorize"],
     "fgs_asm.hip": [],
+    "fgs_gather.hip": [],
 }
 LINK_LIBS = ["-lhipfft"]
 

@@ -6,6 +6,13 @@ Kept from TGD (same flag names / defaults / behaviour):
   flags             --experiment --data_dir --output_dir --batch_size --epochs --lr --image_size
                     --gaussians_per_patch --max_images --use_fresnel_zones --num_fresnel_zones
                     --use_phase_blending --phase_amplitude --resume            TGD:1401-1545
+                    --use_edge_aware --edge_scale_factor --stochastic_k --progressive_schedule --train_resolution
+                    --fast_mode --multi_pose_augmentation --pose_range_elevation/azimuth --frontal_prob
+                    --use_pose_encoding                                         TGD:1455-1461, 1524-1545
+  data              ImageDataset over --data_dir with the `features/` caches (fresnel_amd/data.py, TGD:525-675);
+                    synthetic stand-in data only when --data_dir holds no images
+  hand-off          progressive Gaussians-per-patch, importance subsampling of K Gaussians, one orbit camera per
+                    batch (fresnel_amd/handoff.py, TGD:1069-1207)
   renderer choice   TileBasedRenderer(res, res, use_phase_blending, phase_amplitude)   TGD:1898-1907
   camera            fx = fy = 0.8*res, cx = cy = res/2, view = I                       TGD:1910-1917
   step              decoder -> render -> stack -> L1 + normalised-depth L1 (SSIM / LPIPS only when
@@ -17,8 +24,8 @@ Changed on purpose:
   * the per-image Python loop TGD:1209-1223 becomes ONE batched renderer call;
   * image-wise data parallelism: one process per GPU, the batch is sharded by image and the
     decoder gradients are all-reduced once per step over RCCL (fresnel_amd/dist.py);
-  * no dataset tooling: without --data_dir caches the harness fabricates images/features like
-    TGD:1748-1758 / TGD:613-630 do when files are missing.
+  * no dataset preprocessing tooling (DINOv2 / depth extraction): caches are read when present; when --data_dir has
+    no images the harness fabricates images/features like TGD:1748-1758 / TGD:613-630 do when files are missing.
 
     python -m fresnel_amd.train --experiment 2 --epochs 1                      # 1 GPU
     python -m torch.distributed.run --nproc-per-node 8 -m fresnel_amd.train    # 8 GPUs, DP
@@ -35,8 +42,11 @@ import torch.nn.functional as F
 from torch.optim import AdamW
 from torch.optim.lr_scheduler import CosineAnnealingLR
 
+import numpy as np
+
 from .decoder import PatchGaussianDecoder
 from .dist import DPContext
+from .handoff import HFTSConfig, camera_for_batch, importance_subsample, sample_training_pose
 
 try:  # optional perceptual losses, exactly like TGD:53-65
     from pytorch_msssim import ssim as ssim_fn
@@ -66,6 +76,14 @@ class TrainingConfig:  # subset of TGD:97-162 that this path uses; same names an
     num_fresnel_zones: int = 8
     use_phase_blending: bool = False
     phase_amplitude: float = 0.25
+    use_edge_aware: bool = False      # smaller / more opaque Gaussians at depth edges (TGD:147-151)
+    edge_scale_factor: float = 0.5
+    edge_opacity_boost: float = 0.2
+    multi_pose_augmentation: bool = False  # one random orbit pose per batch (TGD:155-159)
+    pose_range_elevation: tuple = (-30.0, 45.0)
+    pose_range_azimuth: tuple = (0.0, 360.0)
+    frontal_prob: float = 0.3
+    use_pose_encoding: bool = False
     use_wave_rendering: bool = False  # WaveFieldRenderer (TGD:178, 1891-1897); --use_qsr implies it
     # spectral / stencil losses after the renderer (TGD:191, 225-229; fresnel_amd/losses.py)
     wave_equation_weight: float = 0.0
@@ -163,10 +181,11 @@ def _loss_module(kind: str, cfg: TrainingConfig):
     return _LOSS_MODULES[kind]
 
 
-def default_renderer_factory(cfg: TrainingConfig, device):
-    """The product renderer: HIP TileBasedRenderer + the reference camera (TGD:1898-1917)."""
+def default_renderer_factory(cfg: TrainingConfig, device, res: Optional[int] = None):
+    """The product renderer: HIP TileBasedRenderer + the reference camera (TGD:1898-1917), at the effective training
+    resolution (HFTS --train_resolution / --fast_mode, TGD:1643, 1880-1887)."""
     from .renderer import Camera, TileBasedRenderer
-    res = cfg.image_size
+    res = res or cfg.image_size
     if cfg.use_wave_rendering:  # TGD:1891-1897
         from .renderer import WaveFieldRenderer
         renderer = WaveFieldRenderer(res, res).to(device)
@@ -177,17 +196,31 @@ def default_renderer_factory(cfg: TrainingConfig, device):
     return renderer, camera
 
 
-def train_step(model, renderer, camera, batch, optimizer, cfg: TrainingConfig, dp: DPContext):
+def train_step(model, renderer, camera, batch, optimizer, cfg: TrainingConfig, dp: DPContext,
+               hfts: Optional[HFTSConfig] = None, epoch: int = 0, train_res: Optional[int] = None,
+               pose_rng: Optional[np.random.RandomState] = None, sample_gen: Optional[torch.Generator] = None):
     """One optimizer step on this rank's image shard.  Returns (loss_dict | None if skipped)."""
     images, feats, depth = batch
-    out = model(feats, depth)
-    phases = out.get("phases") if (cfg.use_phase_blending or cfg.use_wave_rendering) else None
+    res = train_res or cfg.image_size
+    # progressive Gaussian growing (TGD:1069-1076) and the batch's pose (TGD:1078-1098)
+    num_gaussians = hfts.get_gaussians_per_patch(epoch, cfg.epochs, cfg.gaussians_per_patch) if hfts is not None else None
+    el, az, _ = sample_training_pose(cfg.multi_pose_augmentation, cfg.use_pose_encoding, cfg.frontal_prob,
+                                     cfg.pose_range_elevation, cfg.pose_range_azimuth, pose_rng)
+    el_t = torch.full((feats.shape[0],), el, device=feats.device) if el is not None else None
+    az_t = torch.full((feats.shape[0],), az, device=feats.device) if az is not None else None
+    out = model(feats, depth, num_gaussians=num_gaussians, elevation=el_t, azimuth=az_t)
+    if not (cfg.use_phase_blending or cfg.use_wave_rendering):
+        out.pop("phases", None)
+    # stochastic Gaussian rendering: K Gaussians by opacity importance, gathered on the device (TGD:1154-1187)
+    if hfts is not None:
+        out, _ = importance_subsample(out, hfts.get_stochastic_k(out["positions"].shape[1]), generator=sample_gen)
+    phases = out.get("phases")
     if cfg.use_wave_rendering and phases is not None:
         phases = phases * (2.0 * math.pi)  # wave renderers take radians (DR:772), the decoder emits [0,1]
+    render_camera = camera_for_batch(camera, el, az, res, cfg.multi_pose_augmentation)  # TGD:1196-1207
     # ONE batched call replaces the per-image loop of TGD:1209-1223
     rendered, rdepth = renderer(out["positions"], out["scales"], out["rotations"], out["colors"],
-                                out["opacities"], camera, return_depth=True, phases=phases)
-    res = cfg.image_size
+                                out["opacities"], render_camera, return_depth=True, phases=phases)
     target = F.interpolate(images, size=(res, res), mode="bilinear", align_corners=False)
     tdepth = F.interpolate(depth, size=(res, res), mode="bilinear", align_corners=False).squeeze(1)
     loss, ld = compute_losses(rendered, target, rdepth, tdepth, cfg, dp)
@@ -213,9 +246,25 @@ def save_checkpoint(model, optimizer, epoch, losses, cfg: TrainingConfig):
     return path
 
 
+def make_dataset(cfg: TrainingConfig, log=print):
+    """ImageDataset over --data_dir (with its `features/` caches) when it holds images; otherwise the synthetic
+    stand-in (the reference fabricates test images itself when the directory is empty, TGD:1748-1758)."""
+    if cfg.data_dir and os.path.isdir(cfg.data_dir):
+        from .data import ImageDataset
+        ds = ImageDataset(cfg.data_dir, cfg.image_size, max_images=cfg.max_images, feature_dim=cfg.feature_dim)
+        if len(ds) > 0:
+            if ds[0]["features"].shape[-1] != cfg.feature_size:
+                raise ValueError(f"feature caches are 37x37 patch grids; got feature_size={cfg.feature_size}")
+            log(f"Found {len(ds)} images in {cfg.data_dir}")
+            return ds, len(ds)
+        log(f"No images in {cfg.data_dir}: synthetic data")
+    n_items = cfg.max_images or cfg.batch_size * cfg.steps_per_epoch
+    return SyntheticDataset(n_items, cfg), n_items
+
+
 def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
                  renderer_factory: Callable = default_renderer_factory, resume: Optional[str] = None,
-                 log=print):
+                 log=print, hfts: Optional[HFTSConfig] = None):
     device = torch.device(cfg.device)
     dp = dp or DPContext(device=device if device.type == "cuda" else None)
     if cfg.batch_size % dp.world != 0:  # fail fast, before any rank can stall in a collective (see DPContext.shard)
@@ -224,9 +273,19 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
     model = PatchGaussianDecoder(cfg.feature_dim, cfg.gaussians_per_patch, grid=cfg.feature_size,
                                  use_fresnel_zones=cfg.use_fresnel_zones,
                                  num_fresnel_zones=cfg.num_fresnel_zones,
-                                 use_phase_output=cfg.use_phase_blending or cfg.use_wave_rendering).to(device)
+                                 use_phase_output=cfg.use_phase_blending or cfg.use_wave_rendering,
+                                 use_edge_aware=cfg.use_edge_aware, edge_scale_factor=cfg.edge_scale_factor,
+                                 edge_opacity_boost=cfg.edge_opacity_boost).to(device)
     dp.broadcast_parameters(model)
-    renderer, camera = renderer_factory(cfg, device)
+    train_res = hfts.get_effective_train_resolution(cfg.image_size) if hfts is not None else cfg.image_size
+    try:
+        renderer, camera = renderer_factory(cfg, device, train_res)
+    except TypeError:  # factories that predate the resolution argument
+        renderer, camera = renderer_factory(cfg, device)
+    # host-side draws that every rank must make identically (the pose is shared by the global batch; the K sampled
+    # indices differ per rank like any other per-shard quantity)
+    pose_rng = np.random.RandomState(cfg.seed + 7919)
+    sample_gen = torch.Generator(device=device).manual_seed(cfg.seed * 104729 + dp.rank) if device.type == "cuda" else None
     optimizer = AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
     scheduler = CosineAnnealingLR(optimizer, T_max=cfg.epochs)
     start_epoch = 0
@@ -235,8 +294,7 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
         model.load_state_dict(ck["model_state_dict"])
         optimizer.load_state_dict(ck["optimizer_state_dict"])
         start_epoch = ck["epoch"] + 1
-    n_items = cfg.max_images or cfg.batch_size * cfg.steps_per_epoch
-    data = SyntheticDataset(n_items, cfg)
+    data, n_items = make_dataset(cfg, log if dp.rank == 0 else (lambda *a: None))
     history = []
     for epoch in range(start_epoch, cfg.epochs):
         model.train()
@@ -244,7 +302,8 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
         for bi in range(0, n_items - cfg.batch_size + 1, cfg.batch_size):
             lo, hi = dp.shard(cfg.batch_size)  # image-wise shard of the global batch
             idx = list(range(bi + lo, bi + hi))
-            ld = train_step(model, renderer, camera, data.batch(idx, device), optimizer, cfg, dp)
+            ld = train_step(model, renderer, camera, data.batch(idx, device), optimizer, cfg, dp, hfts=hfts, epoch=epoch,
+                            train_res=train_res, pose_rng=pose_rng, sample_gen=sample_gen)
             if ld is None:
                 if dp.rank == 0:
                     log(f"  Warning: NaN/Inf loss at batch {bi // cfg.batch_size}, skipping")
@@ -281,6 +340,17 @@ def main(argv=None):
     ap.add_argument("--num_fresnel_zones", type=int, default=c.num_fresnel_zones)
     ap.add_argument("--use_phase_blending", action="store_true")
     ap.add_argument("--phase_amplitude", type=float, default=c.phase_amplitude)
+    ap.add_argument("--use_edge_aware", action="store_true", help="smaller Gaussians at depth edges (TGD:1455)")
+    ap.add_argument("--edge_scale_factor", type=float, default=c.edge_scale_factor, help="TGD:1461")
+    ap.add_argument("--train_resolution", type=int, default=None, help="HFTS render resolution (TGD:1524)")
+    ap.add_argument("--progressive_schedule", action="store_true", help="HFTS progressive Gaussian growing (TGD:1526)")
+    ap.add_argument("--stochastic_k", type=int, default=None, help="HFTS: render K importance-sampled Gaussians (TGD:1528)")
+    ap.add_argument("--fast_mode", action="store_true", help="HFTS preset: 64x64, progressive, K=256 (TGD:1530)")
+    ap.add_argument("--multi_pose_augmentation", action="store_true", help="random orbit pose per batch (TGD:1536)")
+    ap.add_argument("--pose_range_elevation", type=float, nargs=2, default=[-30, 45], help="degrees (TGD:1538)")
+    ap.add_argument("--pose_range_azimuth", type=float, nargs=2, default=[0, 360], help="degrees (TGD:1540)")
+    ap.add_argument("--frontal_prob", type=float, default=c.frontal_prob, help="TGD:1542")
+    ap.add_argument("--use_pose_encoding", action="store_true", help="TGD:1544 (pose-dependent decoder output)")
     ap.add_argument("--use_wave_rendering", action="store_true", help="WaveFieldRenderer (TGD:1469)")
     ap.add_argument("--use_qsr", action="store_true", help="macro flag: implies --use_wave_rendering (TGD:1550-1553)")
     ap.add_argument("--wave_equation_weight", type=float, default=c.wave_equation_weight, help="TGD:1483")
@@ -306,15 +376,21 @@ def main(argv=None):
                          use_fresnel_zones=bool(a.use_fresnel_zones),
                          num_fresnel_zones=a.use_fresnel_zones or a.num_fresnel_zones,
                          use_phase_blending=a.use_phase_blending, phase_amplitude=a.phase_amplitude,
+                         use_edge_aware=a.use_edge_aware, edge_scale_factor=a.edge_scale_factor,
+                         multi_pose_augmentation=a.multi_pose_augmentation,
+                         pose_range_elevation=tuple(a.pose_range_elevation), pose_range_azimuth=tuple(a.pose_range_azimuth),
+                         frontal_prob=a.frontal_prob, use_pose_encoding=a.use_pose_encoding,
                          use_wave_rendering=a.use_wave_rendering or a.use_qsr,
                          wave_equation_weight=a.wave_equation_weight, wavelength=a.wavelength,
                          use_phase_retrieval_loss=a.use_phase_retrieval_loss or a.use_qsr,
                          phase_retrieval_weight=a.phase_retrieval_weight,
                          use_frequency_loss=a.use_frequency_loss, frequency_loss_weight=a.frequency_loss_weight,
                          device=f"cuda:{local_rank}", seed=a.seed)
+    hfts = HFTSConfig(train_resolution=a.train_resolution, progressive_schedule=a.progressive_schedule,
+                      stochastic_k=a.stochastic_k, fast_mode=a.fast_mode)
     dp = DPContext(device=torch.device(cfg.device))
     try:
-        run_training(cfg, dp, resume=a.resume)
+        run_training(cfg, dp, resume=a.resume, hfts=hfts if hfts.enabled else None)
     finally:
         dp.shutdown()
 

@@ -197,6 +197,21 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
                       float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
                       void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Importance-subsampling hand-off between decoder and rasterizer (--stochastic_k; reference
+ * scripts/training/train_gaussian_decoder.py:1160-1187): the n_out Gaussians whose indices torch.multinomial
+ * drew (DEVICE int64 (n_out,), unique, shared by the batch) are gathered out of every (B, n_in, .) tensor into
+ * (B, n_out, .) in one launch; the backward scatters the (B, n_out, .) gradients back and zero-fills the rest.
+ *   phase_channels 0 (no phases) | 1 (B,N) | 3 (B,N,3). */
+int fgs_gather_forward(int32_t batch, int32_t n_in, int32_t n_out, int32_t phase_channels, const int64_t *indices,
+                       const float *pos, const float *scale, const float *quat, const float *color,
+                       const float *opacity, const float *phase, float *o_pos, float *o_scale, float *o_quat,
+                       float *o_color, float *o_opacity, float *o_phase, void *stream);
+int fgs_gather_backward(int32_t batch, int32_t n_in, int32_t n_out, int32_t phase_channels, const int64_t *indices,
+                        const float *g_o_pos, const float *g_o_scale, const float *g_o_quat, const float *g_o_color,
+                        const float *g_o_opacity, const float *g_o_phase, float *g_pos, float *g_scale, float *g_quat,
+                        float *g_color, float *g_opacity, float *g_phase, void *stream);
+
 /* Per-stage hipEvent timers (profiling aid; SURVEY §5 "tracing").  When enabled, every stage
  * launched by the fgs_*_forward / fgs_*_backward entry points is bracketed by an event pair on the caller's
  * stream.  fgs_stage_timing_read synchronises on the recorded events, ADDS the elapsed milliseconds per

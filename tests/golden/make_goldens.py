@@ -435,8 +435,102 @@ def loss_goldens():
     save(rec, "G11_losses_48x40.npz")
 
 
+def handoff_goldens():
+    """G12: the caller-side pieces around the renderer, produced by the reference's own code.
+    train_gaussian_decoder.py cannot be imported whole (torchvision), so -- as for G11 -- the definitions under test
+    (HFTSConfig, create_camera_from_pose, ImageDataset) are parsed out of the file with `ast` and executed in a
+    namespace holding what they use; rotate_positions_for_pose and load/save_gaussians_*_binary are imported from
+    their modules.  Nothing of the reference's text is stored: only inputs (incl. the bytes of the small data files
+    the dataset reads) and outputs."""
+    import ast
+    import io as _io
+    import tempfile
+    from dataclasses import dataclass
+    from pathlib import Path
+    from typing import Dict, Optional, Tuple
+    from PIL import Image
+    from torch.utils.data import Dataset
+    import json
+    import models.differentiable_renderer as DR
+    from models.gaussian_decoder_models import rotate_positions_for_pose
+    path = os.path.join(REF, "training", "train_gaussian_decoder.py")
+    tree = ast.parse(open(path).read())
+    want = {"HFTSConfig", "create_camera_from_pose", "ImageDataset"}
+    body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in want]
+    assert {n.name for n in body} == want
+    ns = dict(torch=torch, np=np, dataclass=dataclass, Tuple=Tuple, Optional=Optional, Dict=Dict, Camera=DR.Camera,
+              Dataset=Dataset, Path=Path, Image=Image, load_gaussians_from_binary=DR.load_gaussians_from_binary,
+              transforms=None)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    rec = {}
+    # ---- HFTSConfig tables (TGD:239-303)
+    H = ns["HFTSConfig"]
+    cfgs = [dict(), dict(progressive_schedule=True), dict(fast_mode=True), dict(stochastic_k=300), dict(train_resolution=96),
+            dict(fast_mode=True, stochastic_k=100, train_resolution=128)]
+    gpp, sk, tr = [], [], []
+    for kw in cfgs:
+        h = H(**kw)
+        gpp.append([[h.get_gaussians_per_patch(e, T, b) for e in range(0, 21)] for (T, b) in [(20, 4), (20, 8), (7, 2), (0, 4)]])
+        sk.append([-1 if h.get_stochastic_k(n) is None else h.get_stochastic_k(n) for n in (100, 256, 5476)])
+        tr.append([h.get_effective_train_resolution(s) for s in (64, 256, 512)])
+    rec["hfts_configs"] = np.array([json.dumps(kw) for kw in cfgs])
+    rec["hfts_gpp"], rec["hfts_k"], rec["hfts_res"] = np.array(gpp), np.array(sk), np.array(tr)
+    # ---- create_camera_from_pose (TGD:684-757)
+    poses = [(0.0, 0.0), (20.0, 135.0), (-30.0, 270.0), (89.9999, 10.0), (90.0, 0.0), (45.0, 360.0)]
+    views, intr = [], []
+    for el, az in poses:
+        cam = ns["create_camera_from_pose"](np.radians(el), np.radians(az), 96)
+        views.append(cam.view_matrix.numpy())
+        intr.append([cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height, cam.near, cam.far])
+    cam = ns["create_camera_from_pose"](0.3, 1.1, 128, focal_length_mult=1.2, distance=3.5)
+    views.append(cam.view_matrix.numpy()); intr.append([cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height, cam.near, cam.far])
+    rec["pose_deg"], rec["pose_view"], rec["pose_intr"] = np.array(poses), np.array(views), np.array(intr)
+    # ---- rotate_positions_for_pose (GDM:51-104)
+    rs = np.random.RandomState(77)
+    P = rs.standard_normal((3, 5, 5, 2, 3)).astype(np.float32)
+    el, az = rs.uniform(-0.5, 0.8, 3).astype(np.float32), rs.uniform(0, 6.28, 3).astype(np.float32)
+    rec["rot_in"], rec["rot_el"], rec["rot_az"] = P, el, az
+    rec["rot_out"] = rotate_positions_for_pose(torch.from_numpy(P), torch.from_numpy(el), torch.from_numpy(az)).numpy()
+    # ---- ImageDataset (TGD:525-675) over a tiny directory; the files' bytes travel with the fixture
+    S, FD = 24, 4
+    with tempfile.TemporaryDirectory() as td:
+        files = {}
+        def put(rel, data):
+            full = os.path.join(td, rel)
+            os.makedirs(os.path.dirname(full), exist_ok=True)
+            open(full, "wb").write(data)
+            files[rel] = np.frombuffer(data, dtype=np.uint8)
+        for name, (w, h) in [("img_a", (28, 20)), ("img_b", (24, 24)), ("img_c", (9, 31))]:
+            buf = _io.BytesIO()
+            Image.fromarray(rs.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(buf, format="PNG")
+            put(name + ".png", buf.getvalue())
+        put("features/img_a_dinov2.bin", rs.standard_normal((37, 37, FD)).astype(np.float32).tobytes())
+        put("features/img_a_depth.bin", rs.uniform(0, 1, (12, 12)).astype(np.float32).tobytes())   # resized 12 -> 24
+        put("features/img_b_depth.bin", rs.uniform(0, 1, (S, S)).astype(np.float32).tobytes())     # native size
+        saag = rs.standard_normal((5, 14)).astype(np.float32)
+        put("features/img_b_saag.bin", saag.tobytes())
+        ds = ns["ImageDataset"](td, image_size=S, use_augmentation=False, feature_dim=FD)
+        assert len(ds) == 3
+        for i in range(3):
+            it = ds[i]
+            for k in ("image", "features", "depth", "saag_positions", "saag_scales", "saag_rotations", "saag_colors", "saag_opacities"):
+                rec[f"ds{i}_{k}"] = it[k].numpy()
+            rec[f"ds{i}_name"], rec[f"ds{i}_has_saag"] = np.array(it["name"]), np.array(it["has_saag"])
+        ds2 = ns["ImageDataset"](td, image_size=S, use_augmentation=False, max_images=2, feature_dim=768)
+        rec["ds_max2_len"], rec["ds_suffix_768"] = np.array(len(ds2)), np.array(ds2.feature_suffix)
+        rec["ds_files"] = np.array(sorted(files))
+        for rel, data in files.items():
+            rec["file:" + rel] = data
+    rec["ds_image_size"], rec["ds_feature_dim"] = np.array(S), np.array(FD)
+    for k, v in META.items():
+        rec["meta_" + k] = np.array(v)
+    save(rec, "G12_handoff.npz")
+
+
 if __name__ == "__main__":
-    if "--wave-only" in sys.argv:
+    if "--handoff-only" in sys.argv:
+        handoff_goldens()
+    elif "--wave-only" in sys.argv:
         wave_goldens()
     elif "--losses-only" in sys.argv:
         loss_goldens()
@@ -444,3 +538,4 @@ if __name__ == "__main__":
         main()
         wave_goldens()
         loss_goldens()
+        handoff_goldens()

@@ -50,3 +50,71 @@ def test_harness_spectral_losses_with_wave_renderer(tmp_path):
     assert all(v == v and abs(v) < float("inf") for v in hist[0].values())
     for p in model.parameters():
         assert torch.isfinite(p).all()
+
+
+def test_importance_subsample_gather_matches_torch_indexing():
+    """fgs_gather_forward / backward (one launch for all Gaussian tensors) == the reference's advanced indexing
+    `output[k][:, indices]` (TGD:1175-1184) and autograd's scatter, bit for bit; (B,N) and (B,N,3) phases; draws are
+    without replacement and follow the opacity importance."""
+    from fresnel_amd.handoff import importance_subsample, importance_weights
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    Bn, N, K = 3, 500, 120
+    for pc in (0, 1, 3):
+        out = dict(positions=torch.randn(Bn, N, 3, generator=g), scales=torch.rand(Bn, N, 3, generator=g),
+                   rotations=torch.randn(Bn, N, 4, generator=g), colors=torch.rand(Bn, N, 3, generator=g),
+                   opacities=torch.rand(Bn, N, generator=g))
+        if pc:
+            out["phases"] = torch.rand(Bn, N, generator=g) if pc == 1 else torch.rand(Bn, N, 3, generator=g)
+        a = {k: v.to(dev).requires_grad_(True) for k, v in out.items()}
+        b = {k: v.to(dev).requires_grad_(True) for k, v in out.items()}
+        sub, idx = importance_subsample(a, K, generator=torch.Generator(device=dev).manual_seed(1))
+        assert idx.shape == (K,) and len(set(idx.tolist())) == K  # without replacement
+        ref = {k: v[:, idx] for k, v in b.items()}
+        ws = {k: torch.randn(v.shape, generator=g).to(dev) for k, v in ref.items()}
+        sum((sub[k] * ws[k]).sum() for k in sub).backward()
+        sum((ref[k] * ws[k]).sum() for k in ref).backward()
+        for k in out:
+            assert torch.equal(sub[k], ref[k]), k
+            assert torch.equal(a[k].grad, b[k].grad), k
+    same, none_idx = importance_subsample(a, None)
+    assert same is a and none_idx is None and importance_subsample(a, N)[0] is a
+    # the draw follows p ~ batch-mean opacity: near-zero-opacity Gaussians are (almost) never kept
+    opa = torch.full((2, 1000), 1e-9, device=dev)
+    opa[:, :300] = 0.9
+    many = dict(a, opacities=opa, positions=torch.zeros(2, 1000, 3, device=dev), scales=torch.zeros(2, 1000, 3, device=dev),
+                rotations=torch.zeros(2, 1000, 4, device=dev), colors=torch.zeros(2, 1000, 3, device=dev))
+    many.pop("phases", None)
+    _, idx = importance_subsample(many, 200)
+    assert int((idx < 300).sum()) >= 198
+    assert abs(float(importance_weights(opa).sum()) - 1.0) < 1e-5
+
+
+def test_harness_hfts_flags_and_data_dir(tmp_path):
+    """The hand-off flags of configs 1 and 4 run through the harness on the GPU: --stochastic_k (importance
+    subsampling through fgs_gather), --progressive_schedule, --train_resolution, --use_edge_aware,
+    --multi_pose_augmentation with --use_pose_encoding (one orbit camera per batch), and --data_dir with feature /
+    depth caches written in the reference's on-disk formats."""
+    import numpy as np
+    from PIL import Image
+    from fresnel_amd.handoff import HFTSConfig
+    from fresnel_amd.train import TrainingConfig, run_training
+    rs = np.random.RandomState(0)
+    d = tmp_path / "images"
+    (d / "features").mkdir(parents=True)
+    for i in range(4):
+        Image.fromarray(rs.randint(0, 256, (40, 40, 3)).astype(np.uint8)).save(d / f"im{i}.png")
+        (rs.standard_normal((37, 37, 8)).astype(np.float32) * 0.5).tofile(d / "features" / f"im{i}_dinov2.bin")
+        rs.uniform(0, 1, (32, 32)).astype(np.float32).tofile(d / "features" / f"im{i}_depth.bin")
+    cfg = TrainingConfig(batch_size=2, epochs=4, lr=2e-3, image_size=64, feature_size=37, feature_dim=8,
+                         gaussians_per_patch=4, device="cuda:0", save_interval=100, output_dir=str(tmp_path / "ck"),
+                         log_interval=1000, data_dir=str(d), use_edge_aware=True, multi_pose_augmentation=True,
+                         use_pose_encoding=True, frontal_prob=0.5)
+    hfts = HFTSConfig(train_resolution=48, progressive_schedule=True, stochastic_k=700)
+    seen = []
+    model, hist = run_training(cfg, hfts=hfts, log=lambda *a: seen.append(" ".join(str(x) for x in a)))
+    assert any("Found 4 images" in s for s in seen)
+    assert len(hist) == 4 and all(h["total"] == h["total"] for h in hist)
+    for p in model.parameters():
+        assert torch.isfinite(p).all()
+    assert any(p.grad is not None and p.grad.abs().sum() > 0 for p in model.edge_detector.parameters())
