@@ -19,6 +19,9 @@ EXPORTED_SYMBOLS = [
     "fgs_asm_workspace_bytes", "fgs_asm_forward", "fgs_asm_backward",
     "fgs_wave_workspace_bytes", "fgs_wave_forward", "fgs_wave_backward",
     "fgs_gather_forward", "fgs_gather_backward",
+    "fgs_asm_propagate_workspace_bytes", "fgs_asm_propagate_forward", "fgs_asm_propagate_backward",
+    "fgs_spectral_workspace_bytes", "fgs_spectral_loss_forward", "fgs_spectral_loss_backward",
+    "fgs_helmholtz_loss_forward", "fgs_helmholtz_loss_backward", "fgs_reduction_scratch_bytes",
 ]
 
 STAGES = ["project", "depth_sort", "dup_emit", "tile_sort", "tile_ranges", "composite_fwd",
@@ -64,6 +67,12 @@ class FgsWaveDims(ctypes.Structure):
                 ("phase_channels", ctypes.c_int32), ("num_cameras", ctypes.c_int32)]
 
 
+class FgsSpectralDims(ctypes.Structure):
+    _fields_ = [("images", ctypes.c_int32), ("channels", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("width", ctypes.c_int32), ("mode", ctypes.c_int32), ("cutoff", ctypes.c_float),
+                ("high_weight", ctypes.c_float), ("focal_depth", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
 class FgsError(RuntimeError):
     pass
 
@@ -106,6 +115,21 @@ def load():
     lib.fgs_gather_forward.argtypes = [i32, i32, i32, i32] + [vp] * 14
     lib.fgs_gather_backward.argtypes = [i32, i32, i32, i32] + [vp] * 14
     lib.fgs_gather_forward.restype = lib.fgs_gather_backward.restype = ctypes.c_int
+    f32 = ctypes.c_float
+    lib.fgs_asm_propagate_workspace_bytes.argtypes = [i32, i32, i32, cp(ctypes.c_size_t)]
+    lib.fgs_asm_propagate_forward.argtypes = [i32, i32, i32, f32, i32] + [vp] * 7
+    lib.fgs_asm_propagate_backward.argtypes = [i32, i32, i32, f32, i32] + [vp] * 9
+    lib.fgs_spectral_workspace_bytes.argtypes = [cp(FgsSpectralDims), cp(ctypes.c_size_t), cp(ctypes.c_size_t)]
+    lib.fgs_spectral_loss_forward.argtypes = [cp(FgsSpectralDims)] + [vp] * 8
+    lib.fgs_spectral_loss_backward.argtypes = [cp(FgsSpectralDims)] + [vp] * 12
+    lib.fgs_helmholtz_loss_forward.argtypes = [i32, i32, i32, f32, f32] + [vp] * 5
+    lib.fgs_helmholtz_loss_backward.argtypes = [i32, i32, i32, f32, f32] + [vp] * 4
+    lib.fgs_reduction_scratch_bytes.argtypes = []
+    lib.fgs_reduction_scratch_bytes.restype = ctypes.c_size_t
+    for fn in (lib.fgs_asm_propagate_workspace_bytes, lib.fgs_asm_propagate_forward, lib.fgs_asm_propagate_backward,
+               lib.fgs_spectral_workspace_bytes, lib.fgs_spectral_loss_forward, lib.fgs_spectral_loss_backward,
+               lib.fgs_helmholtz_loss_forward, lib.fgs_helmholtz_loss_backward):
+        fn.restype = ctypes.c_int
     for fn in (lib.fgs_asm_workspace_bytes, lib.fgs_asm_forward, lib.fgs_asm_backward,
                lib.fgs_wave_workspace_bytes, lib.fgs_wave_forward, lib.fgs_wave_backward):
         fn.restype = ctypes.c_int

@@ -27,6 +27,8 @@ SOURCES = {
     "fgs_composite.hip": ["-ffast-math", "-fno-finite-math-only", "-fno-slp-vectorize"],
     "fgs_asm.hip": [],
     "fgs_gather.hip": [],
+    "fgs_fft.hip": [],
+    "fgs_spectral.hip": [],
 }
 LINK_LIBS = ["-lhipfft"]
 

@@ -18,10 +18,6 @@
 // Compiled WITHOUT fast-math: the transfer-function phase reaches ~200 rad, so sin/cos need the
 // accurate range reduction of sincosf.
 #include <hipfft/hipfft.h>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <tuple>
 #include "fgs_internal.h"
 #include "fgs_wave.h"
 
@@ -50,58 +46,6 @@ struct AsmPlan {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// ---- hipFFT plan cache -----------------------------------------------------------------------
-// One plan per (device, H, W, batch), built on first use (host work; later calls only enqueue).  A hipFFT handle
-// carries its stream and work area as mutable state, so every use of a handle -- SetStream, SetWorkArea, Exec --
-// happens under that plan's own mutex: callers on different streams or threads that render the same shape on the
-// same device are serialised on the HOST for the few microseconds of the enqueue, and each transform runs on the
-// stream and in the work area of the call that enqueued it.  Plans are never shared between devices.
-struct FftKey {
-    int dev, h, w, batch;
-    bool operator<(const FftKey &o) const { return std::tie(dev, h, w, batch) < std::tie(o.dev, o.h, o.w, o.batch); }
-};
-struct FftPlan { hipfftHandle handle = 0; size_t work = 0; std::mutex mu; };
-std::mutex g_fft_mu;  // guards the map only
-std::map<FftKey, std::unique_ptr<FftPlan>> g_fft;
-
-int get_fft_plan(int H, int W, int batch, FftPlan **out) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { fgs_set_error("hipGetDevice failed"); return FGS_ELAUNCH; }
-    std::lock_guard<std::mutex> lk(g_fft_mu);
-    const FftKey key{dev, H, W, batch};
-    auto it = g_fft.find(key);
-    if (it != g_fft.end()) { *out = it->second.get(); return FGS_OK; }
-    std::unique_ptr<FftPlan> pl(new FftPlan());
-    int n[2] = {H, W};
-    if (hipfftCreate(&pl->handle) != HIPFFT_SUCCESS) { fgs_set_error("hipfftCreate failed"); return FGS_ELAUNCH; }
-    hipfftResult r = hipfftSetAutoAllocation(pl->handle, 0);
-    if (r == HIPFFT_SUCCESS)
-        r = hipfftMakePlanMany(pl->handle, 2, n, nullptr, 1, H * W, nullptr, 1, H * W, HIPFFT_C2C, batch, &pl->work);
-    if (r != HIPFFT_SUCCESS) {
-        (void)hipfftDestroy(pl->handle);
-        fgs_set_error("hipfftMakePlanMany(%dx%d x%d) failed: %d", H, W, batch, (int)r);
-        return FGS_ELAUNCH;
-    }
-    *out = pl.get();
-    g_fft[key] = std::move(pl);
-    return FGS_OK;
-}
-
-int run_fft(int H, int W, int batch, float2 *data, int dir, void *work, hipStream_t st) {
-    FftPlan *pl = nullptr;
-    const int rc = get_fft_plan(H, W, batch, &pl);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(pl->mu);
-    if (hipfftSetStream(pl->handle, st) != HIPFFT_SUCCESS || hipfftSetWorkArea(pl->handle, work) != HIPFFT_SUCCESS) {
-        fgs_set_error("hipfft stream/work-area setup failed");
-        return FGS_ELAUNCH;
-    }
-    const hipfftResult r = hipfftExecC2C(pl->handle, reinterpret_cast<hipfftComplex *>(data),
-                                         reinterpret_cast<hipfftComplex *>(data), dir);
-    if (r != HIPFFT_SUCCESS) { fgs_set_error("hipfftExecC2C failed: %d", (int)r); return FGS_ELAUNCH; }
-    return FGS_OK;
-}
-
 int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     if (!a) { fgs_set_error("null dims"); return FGS_EINVAL; }
     if (a->num_planes < 1 || a->num_planes > 64 || (a->phase_channels != 1 && a->phase_channels != 3) ||
@@ -128,12 +72,10 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     p->v_total_bytes = o;
     p->work_big = p->work_small = 0;
     if (need_fft) {
-        FftPlan *big = nullptr, *small = nullptr;
-        int r2 = get_fft_plan(a->height, a->width, (int)(B * P * 3), &big);
+        int r2 = fgs_fft_work_bytes(a->height, a->width, (int)(B * P * 3), &p->work_big);
         if (r2) return r2;
-        r2 = get_fft_plan(a->height, a->width, (int)(B * 3), &small);
+        r2 = fgs_fft_work_bytes(a->height, a->width, (int)(B * 3), &p->work_small);
         if (r2) return r2;
-        p->work_big = big->work; p->work_small = small->work;
     }
     o = p->base.s_total;
     p->c_acc = o; o = align256(o + B * 3 * HW * 8);
@@ -768,7 +710,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     FGS_LAUNCH_CHECK("k_asm_splat");
     fgs_stage_end(ST_SPLAT_FWD, st);
     fgs_stage_begin(ST_FIELD_FWD, st);
-    if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
+    if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
     const size_t nh = 3 * (size_t)P * HW;
@@ -779,7 +721,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     hipLaunchKernelGGL(k_asm_accumulate, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, HW, B, P, field, htab,
                        total);
     FGS_LAUNCH_CHECK("k_asm_accumulate");
-    if ((rc = run_fft(H, W, B * 3, total, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
+    if ((rc = fgs_fft_exec(H, W, B * 3, total, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
     hipError_t e = hipMemsetAsync(scal, 0, (size_t)B * 4 * sizeof(float), st);
     if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     const float inv_hw = 1.0f / (float)HW;
@@ -828,7 +770,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
                        a.background[2], total, scal, g_rgb, gtot);
     FGS_LAUNCH_CHECK("k_asm_output_bwd2");
     // adjoint of the unnormalised inverse FFT is the unnormalised forward FFT
-    if ((rc = run_fft(H, W, B * 3, gtot, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
+    if ((rc = fgs_fft_exec(H, W, B * 3, gtot, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
     hipLaunchKernelGGL(k_asm_accumulate_bwd, dim3((unsigned)(((size_t)B * HW + 255) / 256), 3), dim3(256), 0, st, W, H,
@@ -836,7 +778,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
                        g_wavelengths);
     FGS_LAUNCH_CHECK("k_asm_accumulate_bwd");
     // adjoint of the forward FFT is the unnormalised inverse FFT
-    if ((rc = run_fft(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
+    if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
     fgs_stage_end(ST_FIELD_BWD, st);
     fgs_stage_begin(ST_SPLAT_BWD, st);
     const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units

@@ -90,6 +90,12 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
 size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs);
 
 int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t st);
+
+// Batched in-place 2-D C2C FFT of `batch` H x W complex fields (fgs_fft.hip: plans cached per (device, H, W, batch),
+// built on first use; `work` = caller's work area of fgs_fft_work_bytes bytes).  dir: HIPFFT_FORWARD (-1) /
+// HIPFFT_BACKWARD (+1), both unnormalised.
+int fgs_fft_work_bytes(int H, int W, int batch, size_t *bytes);
+int fgs_fft_exec(int H, int W, int batch, float2 *data, int dir, void *work, hipStream_t st);
 int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, float *out_rgb,
                              float *out_depth, hipStream_t st);
 int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *saved, char *scratch,

@@ -365,11 +365,57 @@ class AsmRenderer(torch.autograd.Function):
         return g_pos, g_scl, g_rot, g_col, g_opa, g_ph, g_wl, None, None
 
 
+class _AsmPropagate(torch.autograd.Function):
+    """fgs_asm_propagate_forward / backward: field (C,H,W) complex64, z scalar tensor, wavelengths (C,)."""
+
+    @staticmethod
+    def forward(ctx, field, z, wavelengths, pixel_pitch, band_limit):
+        if not field.is_cuda:
+            raise B.FgsError("AngularSpectrumPropagator (HIP) needs CUDA/ROCm tensors; there is no CPU fallback")
+        lib = B.load()
+        dev = field.device
+        f = torch.view_as_real(field.detach().to(torch.complex64).contiguous())
+        C, H, W = field.shape
+        zt = z.detach().reshape(1).float().contiguous().to(dev)
+        wl = wavelengths.detach().reshape(C).float().contiguous().to(dev)
+        cb = ctypes.c_size_t(0)
+        with torch.cuda.device(dev):
+            B.check(lib.fgs_asm_propagate_workspace_bytes(H, W, C, ctypes.byref(cb)), "fgs_asm_propagate_workspace_bytes")
+            scratch = torch.empty(cb.value, dtype=torch.uint8, device=dev)
+            out = torch.empty_like(f)
+            spec = torch.empty_like(f)
+            B.check(lib.fgs_asm_propagate_forward(H, W, C, float(pixel_pitch), 1 if band_limit else 0, _ptr(f), _ptr(zt),
+                                                  _ptr(wl), _ptr(out), _ptr(spec), _ptr(scratch), _stream_handle()),
+                    "fgs_asm_propagate_forward")
+        ctx.cfg = (H, W, C, float(pixel_pitch), 1 if band_limit else 0, cb.value)
+        ctx.shapes = (z.shape, wavelengths.shape)
+        ctx.save_for_backward(spec, zt, wl)
+        return torch.view_as_complex(out)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = B.load()
+        spec, zt, wl = ctx.saved_tensors
+        H, W, C, pitch, bl, cbytes = ctx.cfg
+        dev = spec.device
+        g = torch.view_as_real(g_out.detach().to(torch.complex64).contiguous())
+        with torch.cuda.device(dev):
+            scratch = torch.empty(cbytes, dtype=torch.uint8, device=dev)
+            g_field = torch.empty_like(g)
+            g_z = torch.empty(1, dtype=torch.float32, device=dev)
+            g_wl = torch.empty(C, dtype=torch.float32, device=dev)
+            B.check(lib.fgs_asm_propagate_backward(H, W, C, pitch, bl, _ptr(spec), _ptr(zt), _ptr(wl), _ptr(g), _ptr(g_field),
+                                                   _ptr(g_z), _ptr(g_wl), _ptr(scratch), _stream_handle()),
+                    "fgs_asm_propagate_backward")
+        return (torch.view_as_complex(g_field), g_z.reshape(ctx.shapes[0]) if ctx.needs_input_grad[1] else None,
+                g_wl.reshape(ctx.shapes[1]) if ctx.needs_input_grad[2] else None, None, None)
+
+
 class AngularSpectrumPropagator(nn.Module):
     """Angular Spectrum Method propagation of a complex field (same interface as DR:929-1065):
-    U(z) = ifft2(fft2(U0) * exp(i 2 pi z sqrt(max(1/lambda^2 - fx^2 - fy^2, 0)))).
-    Stand-alone utility on torch.fft (hipFFT/rocFFT on ROCm); the renderer below runs the same
-    transfer function inside libfgs_hip.so."""
+    U(z) = ifft2(fft2(U0) * exp(i 2 pi z sqrt(max(1/lambda^2 - fx^2 - fy^2, 0)))), per channel wavelength.
+    Runs in libfgs_hip.so (fgs_asm_propagate_forward / backward: batched rocFFT + fused transfer-function kernels),
+    differentiable in the field, the distance and the wavelengths."""
 
     def __init__(self, height: int, width: int, pixel_pitch: float = 1.0 / 256.0, wavelength: float = 0.05,
                  band_limit: bool = True):
@@ -379,32 +425,32 @@ class AngularSpectrumPropagator(nn.Module):
         fx = torch.fft.fftfreq(width, d=pixel_pitch)
         fy = torch.fft.fftfreq(height, d=pixel_pitch)
         FX, FY = torch.meshgrid(fx, fy, indexing="xy")
-        self.register_buffer("FX", FX)
+        self.register_buffer("FX", FX)  # kept for interface parity (DR:963-964); the kernels form them on the fly
         self.register_buffer("FY", FY)
 
-    def _compute_transfer_function(self, z_distance, wavelength=None):
-        device = z_distance.device
-        wl = wavelength if wavelength is not None else self.wavelength
-        if isinstance(wl, (int, float)):
-            wl = torch.tensor(wl, device=device)
-        kz_sq = (1.0 / wl) ** 2 - self.FX.to(device) ** 2 - self.FY.to(device) ** 2
-        if self.band_limit:
-            kz_sq = torch.clamp(kz_sq, min=0)
-        return torch.exp(1j * 2 * torch.pi * z_distance * torch.sqrt(kz_sq))
-
     def propagate(self, field, z_distance, wavelength=None):
+        """field (H,W) or (H,W,C) complex; z_distance scalar tensor; wavelength None | scalar | (C,) tensor: channel c
+        uses wavelength[c] when the tensor has more than c entries, else the tensor itself (DR:1035-1040)."""
         squeeze = field.dim() == 2
         if squeeze:
             field = field.unsqueeze(-1)
-        chans = []
-        for c in range(field.shape[-1]):
-            if wavelength is not None and wavelength.dim() > 0:
-                wl = wavelength[c] if len(wavelength) > c else wavelength
-            else:
-                wl = wavelength
-            Htf = self._compute_transfer_function(z_distance, wl)
-            chans.append(torch.fft.ifft2(torch.fft.fft2(field[..., c]) * Htf))
-        out = torch.stack(chans, dim=-1)
+        C = field.shape[-1]
+        dev = field.device
+        if wavelength is None:
+            wl = torch.full((C,), float(self.wavelength), device=dev)
+        elif not torch.is_tensor(wavelength):
+            wl = torch.full((C,), float(wavelength), device=dev)
+        elif wavelength.dim() == 0:
+            wl = wavelength.to(dev).expand(C)
+        else:
+            if len(wavelength) < C and len(wavelength) != 1:
+                raise RuntimeError(f"wavelength has {len(wavelength)} entries for {C} channels")
+            wl = wavelength.to(dev) if len(wavelength) >= C else wavelength.to(dev).expand(C)
+            wl = wl[:C]
+        if not torch.is_tensor(z_distance):
+            z_distance = torch.tensor(float(z_distance), device=dev)
+        out = _AsmPropagate.apply(field.permute(2, 0, 1), z_distance, wl, self.pixel_pitch, self.band_limit)
+        out = out.permute(1, 2, 0)
         return out.squeeze(-1) if squeeze else out
 
     def forward(self, field, z_distance, wavelength=None):

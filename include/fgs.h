@@ -198,6 +198,52 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
                       void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Standalone angular-spectrum propagation: replaces AngularSpectrumPropagator.propagate (DR:1000-1065) and its
+ * autograd.  field / out / g_* are (C, H, W) interleaved complex64 (the reference's (H, W, C) layout is permuted by
+ * the binding); z = DEVICE scalar propagation distance; wavelengths = DEVICE (C,).  `spectrum` (C,H,W complex) receives
+ * fft2(field) and is what the backward needs; scratch from fgs_asm_propagate_workspace_bytes.  band_limit: clamp
+ * 1/l^2 - fx^2 - fy^2 at 0 (DR:993-994).  dL/dwavelength is taken as 0 where the clamp binds (see fgs_asm_backward). */
+int fgs_asm_propagate_workspace_bytes(int32_t height, int32_t width, int32_t channels, size_t *scratch_bytes);
+int fgs_asm_propagate_forward(int32_t height, int32_t width, int32_t channels, float pixel_pitch, int32_t band_limit,
+                              const float *field, const float *z, const float *wavelengths, float *out,
+                              float *spectrum, void *scratch, void *stream);
+int fgs_asm_propagate_backward(int32_t height, int32_t width, int32_t channels, float pixel_pitch, int32_t band_limit,
+                               const float *spectrum, const float *z, const float *wavelengths, const float *g_out,
+                               float *g_field, float *g_z, float *g_wavelengths, void *scratch, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spectral / stencil losses on the rendered batch.
+ * mode 0 = FrequencyDomainLoss (TGD:428-522): mean over (B,C,H,W) of w (|fft2(rendered)| - |fft2(target)|)^2, w = 1
+ *          below the radial frequency `cutoff`, `high_weight` above.
+ * mode 1 = PhaseRetrievalLoss (TGD:342-425): the same with w = 1 on the fields sqrt(max(I, 1e-8)) exp(i phi),
+ *          phi = (2 pi / wavelength) |depth - focal_depth|; depth (B,H,W), wavelength = DEVICE scalar.
+ * loss / g_loss / g_wavelength are DEVICE scalars.  The backward CONSUMES `saved` (spectra -> their gradients).
+ * g_target / g_depth may be NULL. */
+typedef struct FgsSpectralDims {
+    int32_t images, channels, height, width;
+    int32_t mode;
+    float cutoff, high_weight;   /* mode 0 */
+    float focal_depth;           /* mode 1 */
+    int32_t reserved;            /* must be 0 */
+} FgsSpectralDims;
+int fgs_spectral_workspace_bytes(const FgsSpectralDims *dims, size_t *saved_bytes, size_t *scratch_bytes);
+int fgs_spectral_loss_forward(const FgsSpectralDims *dims, const float *rendered, const float *target,
+                              const float *depth, const float *wavelength, float *loss, void *saved, void *scratch,
+                              void *stream);
+int fgs_spectral_loss_backward(const FgsSpectralDims *dims, const float *rendered, const float *target,
+                               const float *depth, const float *wavelength, void *saved, void *scratch,
+                               const float *g_loss, float *g_rendered, float *g_target, float *g_depth,
+                               float *g_wavelength, void *stream);
+/* wave_equation_loss (TGD:781-835): mean squared Helmholtz residual lap(U) + (2 pi / wavelength)^2 U of `images`
+ * fields (H,W) with the periodic 5-point Laplacian on a grid of spacing pixel_spacing.  residual (images,H,W) is
+ * written by the forward and read by the backward; scratch = fgs_reduction_scratch_bytes() bytes. */
+int fgs_helmholtz_loss_forward(int32_t images, int32_t height, int32_t width, float wavelength, float pixel_spacing,
+                               const float *field, float *loss, float *residual, void *scratch, void *stream);
+int fgs_helmholtz_loss_backward(int32_t images, int32_t height, int32_t width, float wavelength, float pixel_spacing,
+                                const float *residual, const float *g_loss, float *g_field, void *stream);
+size_t fgs_reduction_scratch_bytes(void);
+
+/* ------------------------------------------------------------------------------------------
  * Importance-subsampling hand-off between decoder and rasterizer (--stochastic_k; reference
  * scripts/training/train_gaussian_decoder.py:1160-1187): the n_out Gaussians whose indices torch.multinomial
  * drew (DEVICE int64 (n_out,), unique, shared by the batch) are gathered out of every (B, n_in, .) tensor into
