@@ -92,12 +92,11 @@ def test_asm_propagator_gradients_vs_torch_autograd():
         wl = torch.tensor(wl0.astype(np.float64), requires_grad=True)
         fx = torch.fft.fftfreq(W, d=pitch, dtype=torch.float64)
         fy = torch.fft.fftfreq(H, d=pitch, dtype=torch.float64)
-        FX, FY = torch.meshgrid(fx, fy, indexing="xy")
-        FX, FY = FX.T, FY.T  # (H, W)
+        FX, FY = torch.meshgrid(fx, fy, indexing="xy")  # (H, W), as DR:961
         outs = []
         for c in range(C):
             raw = (1.0 / wl[c]) ** 2 - FX ** 2 - FY ** 2
-            kz = torch.sqrt(torch.clamp(raw, min=0) + (raw <= 0) * 0.0)
+            # sqrt(clamp(raw, 0)) with a zero (instead of NaN) derivative where the clamp binds
             kz = torch.where(raw > 0, torch.sqrt(torch.where(raw > 0, raw, torch.ones_like(raw))), torch.zeros_like(raw))
             Htf = torch.exp(1j * 2 * torch.pi * z * kz)
             outs.append(torch.fft.ifft2(torch.fft.fft2(f[..., c]) * Htf))
