@@ -344,33 +344,45 @@ __global__ __launch_bounds__(64 * NP) void k_blend_fwd_parts(
             const uint32_t gid = dup_ids[base + lane];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
             float4 q0 = r[0], q1 = r[1], q2 = r[2];
+            // m >= 0 everywhere (G <= 1): positive definite with a margin (as in k_composite_bwd's staging)
+            const bool conic_ok = q0.z > 0.0f && q1.x > 0.0f && 3.996f * q0.z * q1.x > q0.w * q0.w;
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
             uint32_t flags, bits;
-            stage_decode(c.X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, bits);
+            stage_decode(c.X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, bits, conic_ok);
             q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
             sh0[wave][lane] = q0; sh1[wave][lane] = q1; sh2[wave][lane] = q2;
         }
         __builtin_amdgcn_wave_barrier();  // wave-private LDS: one wave's LDS instructions execute in order
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[wave][j], q1 = sh1[wave][j], q2 = sh2[wave][j];
-            const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w)) & 15u;
+            const uint32_t fl = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));  // stage_decode flags
+            const uint32_t msk = fl & 15u;
             if (!msk) continue;
+            // (Skipping the lane masks for entries whose bbox covers the tile, or the min for opacities <= 0.98, behind
+            // wave-uniform branches -- what pays in the backward -- made this loop 10 % SLOWER: 0.68 -> 0.75 ms at config 3;
+            // its passes are too short to amortise a branch.)
+            constexpr bool inside = false, clamp = true;
             const uint32_t bits = __float_as_uint(q2.z);
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
                 if (!((msk >> (2 * row)) & 3u)) continue;
                 const float dy = row ? fy0 + 8.0f - q0.y : fy0 - q0.y;
                 const float bdy = q0.w * dy, cyy = (q1.x * dy) * dy;
-                const uint32_t my = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u * row, 1);
+                uint32_t my = ~0u;
+                if (!inside) my = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u * row, 1);
 #pragma unroll
                 for (int col = 0; col < 2; ++col) {
                     const int s = 2 * row + col;
                     if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
                     const float dx = (col ? fx1 : fx0) - q0.x;
                     const float t = q0.z * dx + bdy;
-                    const uint32_t mk = my & (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u * col, 1);
-                    const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(t * dx + cyy)) & mk);
-                    const float alpha = fminf(G * q1.y, 0.99f);  // opacity >= 0 here: no lower clamp needed
+                    float G = __builtin_amdgcn_exp2f(t * dx + cyy);
+                    if (!inside) {
+                        const uint32_t mk = my & (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u * col, 1);
+                        G = __uint_as_float(__float_as_uint(G) & mk);
+                    }
+                    float alpha = G * q1.y;  // opacity >= 0 here: no lower clamp needed
+                    if (clamp) alpha = fminf(alpha, 0.99f);
                     const float w = alpha * T[s];
                     Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
                     T[s] -= w;
@@ -548,6 +560,15 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
     }
     float fx0 = (float)(c.X0 + lx), fy0 = (float)(c.Y0 + ly);
     asm("" : "+v"(fx0), "+v"(fy0));  // hoisted for good: no v_cvt in the list loop
+    // Geometry gradients are accumulated as RAW moments of dL/dG about the TILE ORIGIN: sum dG {1, x, y, x^2, x y,
+    // y^2} with x, y in [0, 16) the lane's pixel inside the tile -- per-lane constants, so every moment is one FMA
+    // per pixel and Gaussian (the central moments sum dm' {dx, dy, dx^2, dx dy, dy^2} took nine).  k_project_bwd
+    // shifts each row's moments to the Gaussian's mean (in double) and applies the ln2 * opacity and K factors.
+    float pxs[2] = {(float)lx, (float)(lx + 8u)}, pys[2] = {(float)ly, (float)(ly + 8u)};
+    float pxx[2] = {pxs[0] * pxs[0], pxs[1] * pxs[1]}, pyy[2] = {pys[0] * pys[0], pys[1] * pys[1]};
+    float pxy[4] = {pxs[0] * pys[0], pxs[1] * pys[0], pxs[0] * pys[1], pxs[1] * pys[1]};
+    asm("" : "+v"(pxs[0]), "+v"(pxs[1]), "+v"(pys[0]), "+v"(pys[1]), "+v"(pxx[0]), "+v"(pxx[1]), "+v"(pyy[0]), "+v"(pyy[1]),
+        "+v"(pxy[0]), "+v"(pxy[1]), "+v"(pxy[2]), "+v"(pxy[3]));  // constants for the whole unit: never recomputed
     for (uint32_t base = c.start; base < c.end; base += CH) {
         const uint32_t n = min((uint32_t)CH, c.end - base);
         if (lane < n) {
@@ -578,56 +599,46 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
             const float dxa = fx0 - q0.x, dya = fy0 - q0.y, dxb = dxa + 8.0f, dyb = dya + 8.0f;
             float bdya = cbc * dya, bdyb = cbc * dyb, cyya = (cd * dya) * dya, cyyb = (cd * dyb) * dyb;
             asm("" : "+v"(bdya), "+v"(bdyb), "+v"(cyya), "+v"(cyyb));  // keep the row terms: do not recompute them per sub-tile
-            const float hp = 0.69314718055994530942f * op;  // dL/dm' = ln2 * opacity * dL/dG (m' = K m)
             // bbox membership: the lane's column / row bits of the staged pixel bits become all-ones / zero masks
             // (v_bfe_i32) and zero G with a bit-and -- no per-pixel compare / select (issue costs: DESIGN.md).
-            // per-lane partial sums over this lane's (up to four) pixels; the conic sums are in exp2 units
-            // (rescaled by K when the totals are stored)
+            // per-lane partial sums over this lane's (up to four) pixels: raw moments of dL/dG (see above)
             float v_mx = 0, v_my = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
-            // CLAMP = false: opacity <= 0.98 and G <= 1 (+ rounding), so alpha = min(G op, 0.99) never binds and
-            // neither the min nor the clamp-gradient select is needed (flag bit 4 of the staged mask)
-            auto passes = [&](auto clamp_tag, auto full_tag, auto inside_tag) {
-                constexpr bool CLAMP = decltype(clamp_tag)::value;
-                constexpr bool FULL = decltype(full_tag)::value;  // all four sub-tiles touched: straight-line code
-                constexpr bool INSIDE = decltype(inside_tag)::value;  // tile entirely inside the bbox: no lane masks
-                uint32_t mx0 = 0, mx1 = 0, my0 = 0, my1 = 0;
-                if (!INSIDE) {  // one v_bfe_i32 per column / row half: the lane's bit as an all-ones / zero mask
+            {   // ONE code path for every kind of entry; what differs is handled by wave-uniform branches around a few
+                // ops: `inside` (bbox covers the tile, flag bit 5): no lane masks to extract; `clamp` (flag bit 4
+                // clear: opacity > 0.98 or a doubtful conic): alpha = min(G op, 0.99) and the clamp-gradient select.
+                // (Four specialised instantiations of this loop body made the compiler carry T and S through eight
+                // v_mov per list entry and were 5 % slower.)
+                const bool inside = (msk & 32u) != 0u, clamp = (msk & 16u) == 0u;
+                uint32_t mx0 = ~0u, mx1 = ~0u, my0 = ~0u, my1 = ~0u;
+                if (!inside) {
                     mx0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx, 1); mx1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u, 1);
                     my0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy, 1); my1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u, 1);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    if (!FULL && !((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
-                    const uint32_t mk = ((s & 1) ? mx1 : mx0) & ((s >> 1) ? my1 : my0);
-                    const float dx = (s & 1) ? dxb : dxa, dy = (s >> 1) ? dyb : dya;
-                    const float t = ca * dx + ((s >> 1) ? bdyb : bdya);
+                    if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
                     // G is zeroed outside the bbox: alpha, w and every gradient term below then vanish by themselves
+                    const uint32_t mk = ((s & 1) ? mx1 : mx0) & ((s >> 1) ? my1 : my0);
+                    const float dx = (s & 1) ? dxb : dxa;
+                    const float t = ca * dx + ((s >> 1) ? bdyb : bdya);
                     const float Gu = __builtin_amdgcn_exp2f(t * dx + ((s >> 1) ? cyyb : cyya));
-                    const float G = INSIDE ? Gu : __uint_as_float(__float_as_uint(Gu) & mk);
-                    const float raw = G * op;  // >= 0: records with a negative opacity are dropped at staging
-                    const float alpha = CLAMP ? fminf(raw, 0.99f) : raw;
+                    const float G = __uint_as_float(__float_as_uint(Gu) & mk);
+                    const float raw = G * op;
+                    float alpha = raw;
+                    if (clamp) alpha = fminf(raw, 0.99f);
                     const float w = alpha * T[s];
                     const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
-                    // S -= w q and T -= w as in-place (tied-operand) updates: the four code variants below then keep
-                    // T and S in the same eight registers, without which the loop carried them through eight
-                    // v_mov per list entry
-                    asm("v_fma_f32 %0, -%1, %2, %0" : "+v"(S[s]) : "v"(w), "v"(q));
-                    const float dalpha = T[s] * q - S[s] * __builtin_amdgcn_rcpf(1.0f - alpha);
-                    asm("v_sub_f32 %0, %0, %1" : "+v"(T[s]) : "v"(w));
-                    // clamp backward: closed interval [0, 0.99]
-                    const float dG = (CLAMP ? select_le(raw, 0.99f, dalpha) : dalpha) * G;
+                    S[s] -= w * q;
+                    float dalpha = T[s] * q - S[s] * __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T[s] -= w;
+                    if (clamp) dalpha = select_le(raw, 0.99f, dalpha);
+                    const float dG = dalpha * G;
                     v_op += dG;
-                    const float dmp = hp * dG;
-                    const float dmx = dmp * dx, dmy = dmp * dy;
-                    v_mx += dmx; v_my += dmy;  // first moments; dL/d(u,v) = -conic_sym' (v_mx, v_my) is formed in k_project_bwd
-                    v_ca += dmx * dx; v_cbc += dmx * dy; v_cd += dmy * dy;
+                    v_mx += dG * pxs[s & 1]; v_my += dG * pys[s >> 1];
+                    v_ca += dG * pxx[s & 1]; v_cbc += dG * pxy[s]; v_cd += dG * pyy[s >> 1];
                     v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
                 }
-            };
-            if ((msk & 63u) == 63u) passes(std::false_type{}, std::true_type{}, std::true_type{});
-            else if ((msk & 31u) == 31u) passes(std::false_type{}, std::true_type{}, std::false_type{});
-            else if (msk & 16u) passes(std::false_type{}, std::false_type{}, std::false_type{});
-            else passes(std::true_type{}, std::false_type{}, std::false_type{});
+            }
             // ---- reduce the ten sums over the 64 lanes (wave_sum_transposed, fgs_wave.h) and store them straight
             // into this duplicate's gradient row: no atomics, fixed order, bitwise reproducible ----
             {
@@ -638,9 +649,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(
                 const float tot = wave_sum10_addtid(red, vals, lane);
 #endif
                 const uint32_t kk = lane >> 2, e = she[j];
-                // dL/dconic = K * (sums in exp2 units); the other seven sums are already final
-                const float scl = (kk >= 2u && kk <= 4u) ? NEG_HALF_LOG2E : 1.0f;
-                if ((lane & 3u) == 3u && lane < 40u && e < dcap) grad_rows[(size_t)e * FGS_BLEND_ROW_FLOATS + kk] = tot * scl;
+                if ((lane & 3u) == 3u && lane < 40u && e < dcap) grad_rows[(size_t)e * FGS_BLEND_ROW_FLOATS + kk] = tot;
             }
         }
         __syncthreads();
