@@ -455,7 +455,9 @@ __global__ __launch_bounds__(64 * NP) void k_blend_fwd_parts(
 //
 // Work unit = (tile, depth segment of FGS_SEG list entries): the unit restarts from the forward's
 // per-pixel checkpoint in front of its segment, so units are independent and of bounded length.
-__global__ __launch_bounds__(64) void k_composite_bwd(
+// Six waves per SIMD (80 VGPRs): the loop is bound by VALU issue with dependent chains in every pass (exp -> alpha -> w
+// -> S -> rcp -> dalpha), and the sixth wave buys 4 % (1.37 -> 1.31 ms at config 3); a seventh needs spills and loses 35 %.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_composite_bwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, uint32_t dcap,
     const uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg_off,
     const uint32_t *__restrict__ seg_tile, const float *__restrict__ seg_ckpt, const uint32_t *__restrict__ ranges,
