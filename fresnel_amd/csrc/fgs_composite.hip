@@ -309,7 +309,7 @@ __device__ __forceinline__ BlendState ckpt_load(const float *ck) {
 }
 
 template <int NP>
-__global__ __launch_bounds__(64 * NP) void k_blend_fwd_parts(
+__global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blend_fwd_parts(  // 64 VGPRs: -2.6 %
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, float *__restrict__ pix_state,
@@ -363,6 +363,8 @@ __global__ __launch_bounds__(64 * NP) void k_blend_fwd_parts(
             // its passes are too short to amortise a branch.)
             constexpr bool inside = false, clamp = true;
             const uint32_t bits = __float_as_uint(q2.z);
+            // the lane's two column masks once per entry (3.3 sub-tile passes per entry on average: -2.8 %)
+            const uint32_t mxc[2] = {(uint32_t)__builtin_amdgcn_sbfe((int)bits, shx, 1), (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u, 1)};
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
                 if (!((msk >> (2 * row)) & 3u)) continue;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(64 * NP) void k_blend_fwd_parts(
                     const float t = q0.z * dx + bdy;
                     float G = __builtin_amdgcn_exp2f(t * dx + cyy);
                     if (!inside) {
-                        const uint32_t mk = my & (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u * col, 1);
+                        const uint32_t mk = my & mxc[col];
                         G = __uint_as_float(__float_as_uint(G) & mk);
                     }
                     float alpha = G * q1.y;  // opacity >= 0 here: no lower clamp needed
