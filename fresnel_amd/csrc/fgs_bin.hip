@@ -129,11 +129,11 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
 //                  -> cnt[image][block][tile]; also the block's number of duplicates -> bsum;
 //   k_bin_scan     one thread per (image, tile): exclusive scan of its column over the blocks (in place), column
 //                  total = list length; its last block scans bsum (duplicate offsets, total D -> counters);
-//   k_tile_order   turns the lengths into [start, end) ranges (and launch order, depth segments);
+//   k_tile_pre/post turn the lengths into [start, end) ranges (and launch order, depth segments);
 //   k_bin_scatter  one wave per block of depth ranks walks its Gaussians IN ORDER and drops each id at
 //                  start[tile] + cnt[image][block][tile] + (ids this block already put into the tile); also writes
 //                  dup_off[g] = first duplicate slot of Gaussian g (emission order: image, depth rank, tile row, tile
-//                  column -- the gradient-row addressing of the backward) and its share of the unit -> tile table.
+//                  column -- the gradient-row addressing of the backward).
 // Every list comes out in depth order, exactly as the stable sort produced it, with one scattered 4-byte store
 // per duplicate instead of four (two passes x key + payload) and no key traffic at all
 // (emit 0.052 + sort 0.148 + ranges 0.012 ms -> offsets/count/scan 0.030 + scatter 0.080 ms at config 3).
@@ -241,9 +241,7 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
                                                          const uint32_t *__restrict__ ranges,
                                                          uint32_t *__restrict__ dup_ids,
                                                          const uint32_t *__restrict__ bsum,
-                                                         uint32_t *__restrict__ dup_off,
-                                                         const uint32_t *__restrict__ seg_off,
-                                                         uint32_t *__restrict__ seg_tile) {
+                                                         uint32_t *__restrict__ dup_off) {
     constexpr uint32_t T_MAX = NW == 1 ? BIN_MAX_TILES : BIN_MAX_TILES / NW;
     constexpr uint32_t WG = BIN_G / NW;  // ranks per wave
     __shared__ uint32_t run[NW][T_MAX];  // next free slot of every tile list, per wave
@@ -279,17 +277,6 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
         if (r0 + threadIdx.x < BIN_G && r < N) dup_off[g] = pre + x - c;
         __syncthreads();
         if (threadIdx.x == 0) carry_sh += all;
-    }
-    // (b) unit -> tile table of this block's share of the image's tiles (the backward's work-unit list)
-    if (seg_tile) {
-        const uint32_t tpb = (tiles + bpi - 1) / bpi;
-        for (uint32_t k = threadIdx.x; k < tpb; k += 64 * NW) {
-            const uint32_t t = blk * tpb + k;
-            if (t < tiles) {
-                const uint32_t bt = b * tiles + t, o0 = seg_off[bt], o1 = seg_off[bt + 1];
-                for (uint32_t u = o0; u < o1; ++u) seg_tile[u] = bt;
-            }
-        }
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
@@ -372,107 +359,166 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t *__restrict_
     }
 }
 
-// Launch order of the composite kernels: tiles with the longest lists first (LPT scheduling:
-// the hardware dispatcher hands workgroups to CUs in blockIdx order, so heavy tiles start
-// early and light ones fill the tail).  Single-block counting sort into 64 length buckets;
-// the order inside a bucket is arbitrary -- it affects scheduling only, never results.
-//
-// The same block also cuts every list into depth segments of FGS_SEG entries (the backward's work
-// units): exclusive scan of ceil(len / FGS_SEG) over the tiles -> seg_off, the unit -> tile map
-// seg_tile, and the unit count in seg_off[ntiles] and counters[2].
-__global__ __launch_bounds__(1024) void k_tile_order(uint32_t ntiles, uint32_t *__restrict__ ranges,
-                                                     const uint32_t *__restrict__ lens,
-                                                     uint32_t *__restrict__ tile_order,
-                                                     uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_tile,
-                                                     uint32_t *__restrict__ counters, uint32_t seg_len,
-                                                     uint32_t fwd_variant) {
+// Per-tile tables from the list lengths, in two multi-block launches (one 1024-thread block used to do all of it:
+// 18 us at 8 192 tiles, 470 us at the 131 072 (image, plane, tile) lists of the batched ASM renderer):
+//   ranges      [start, end) of every list (direct binning: from `lens`; radix path: already known);
+//   seg_off / seg_tile  the backward's work units: a list is cut into depth segments of seg_len entries; exclusive
+//               scan of ceil(len / seg_len) over the tiles, the unit -> tile table, the unit count in
+//               seg_off[ntiles] and counters[2]; counters[4..5] = the split this forward runs with;
+//   tile_order  launch order of the forward kernels, longest lists first (LPT: the dispatcher hands out workgroups
+//               in blockIdx order, so heavy tiles start early and light ones fill the tail): a counting sort into
+//               64 quarter-octave length buckets; the order inside a bucket is arbitrary -- scheduling only.
+// k_tile_pre: per block of TO_TILES tiles, the sums of (length, units) and the bucket histogram.
+// k_tile_post: every block adds up the sums / histograms of the blocks before it (a few hundred values), scans its
+// own tiles and writes their rows of all tables.
+constexpr uint32_t TO_TILES = 1024;  // tiles per block (256 threads x 4 consecutive tiles)
+
+__device__ __forceinline__ uint32_t length_bucket(uint32_t len) {
+    // 63 - quarter-octave of the length: longer lists get smaller bucket numbers (4 buckets per power of two)
+    if (len == 0) return 63u;
+    const uint32_t lg = 31u - (uint32_t)__clz((int)len);
+    const uint32_t frac = lg >= 2u ? (len >> (lg - 2u)) & 3u : (len << (2u - lg)) & 3u;
+    const uint32_t q = lg * 4u + frac;  // 0 .. 127
+    return q >= 62u ? 0u : 62u - q;
+}
+
+__device__ __forceinline__ uint32_t tile_len(const uint32_t *__restrict__ lens, const uint32_t *__restrict__ ranges,
+                                             uint32_t t) {
+    if (lens) return lens[t];
+    const uint2 r = reinterpret_cast<const uint2 *>(ranges)[t];
+    return r.y - r.x;
+}
+
+__global__ __launch_bounds__(256) void k_tile_pre(uint32_t ntiles, const uint32_t *__restrict__ ranges,
+                                                  const uint32_t *__restrict__ lens, uint32_t seg_len,
+                                                  unsigned long long *__restrict__ pre64,
+                                                  uint32_t *__restrict__ bhist) {
     __shared__ uint32_t hist[64];
-    __shared__ uint32_t maxc;
-    __shared__ unsigned long long wsum64[16];
-    __shared__ unsigned long long carry64;
-    // list lengths are read from global memory once and kept in LDS (when they fit) for the four sweeps below
-    constexpr uint32_t LCAP = 8192;
-    __shared__ uint32_t lcnt[LCAP];
-    const bool cached = ntiles <= LCAP;
-    // list lengths: from the sorted keys' ranges (radix path) or straight from the direct binning (`lens`, in
-    // which case the [start, end) ranges are produced here by the sweep at the end)
-    auto len_of = [&](uint32_t t) -> uint32_t {
-        return cached ? lcnt[t] : (lens ? lens[t] : ranges[2 * t + 1] - ranges[2 * t]);
-    };
+    __shared__ unsigned long long wsum[4];
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) maxc = 1;
     __syncthreads();
-    uint32_t mymax = 0;
-    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
-        uint32_t len;
-        if (lens) len = lens[t];
-        else { const uint2 r = reinterpret_cast<const uint2 *>(ranges)[t]; len = r.y - r.x; }
-        if (cached) lcnt[t] = len;
-        mymax = max(mymax, len);
+    unsigned long long v = 0;
+    const uint32_t t0 = blockIdx.x * TO_TILES + threadIdx.x * 4u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t = t0 + k;
+        if (t < ntiles) {
+            const uint32_t len = tile_len(lens, ranges, t);
+            v += ((unsigned long long)len << 32) | ((len + seg_len - 1) / seg_len);
+            atomicAdd(&hist[length_bucket(len)], 1u);
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o, 64));
-    if ((threadIdx.x & 63u) == 0) atomicMax(&maxc, mymax);  // one LDS atomic per wave
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
-    const float scale = 63.0f / (float)maxc;  // bucket = 63 - floor(len * 63 / max), in float: scheduling only
-    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
-        const uint32_t cnt = len_of(t);
-        atomicAdd(&hist[63u - min(63u, (uint32_t)((float)cnt * scale))], 1u);
+    if (threadIdx.x == 0) pre64[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (threadIdx.x < 64) bhist[blockIdx.x * 64 + threadIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_tile_post(uint32_t ntiles, uint32_t *__restrict__ ranges,
+                                                   const uint32_t *__restrict__ lens,
+                                                   uint32_t *__restrict__ tile_order, uint32_t *__restrict__ seg_off,
+                                                   uint32_t *__restrict__ seg_tile, uint32_t *__restrict__ counters,
+                                                   uint32_t seg_len, uint32_t fwd_variant,
+                                                   const unsigned long long *__restrict__ pre64,
+                                                   const uint32_t *__restrict__ bhist) {
+    __shared__ uint32_t bucket_pos[64];         // next slot of every bucket for this block's tiles
+    __shared__ unsigned long long wsum[4], carry_sh, total_sh;
+    __shared__ uint32_t col_before[64], col_total[64];
+    const uint32_t nblk = gridDim.x, blk = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // (1) sums of the blocks before this one (and of all blocks)
+    {
+        unsigned long long before = 0, all = 0;
+        for (uint32_t k = threadIdx.x; k < nblk; k += 256) {
+            const unsigned long long p = pre64[k];
+            all += p;
+            if (k < blk) before += p;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o, 64); all += __shfl_down(all, o, 64); }
+        __shared__ unsigned long long wb[4], wa[4];
+        if (lane == 0) { wb[wave] = before; wa[wave] = all; }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry_sh = (wb[0] + wb[1]) + (wb[2] + wb[3]); total_sh = (wa[0] + wa[1]) + (wa[2] + wa[3]); }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < 64; ++i) { const uint32_t h = hist[i]; hist[i] = run; run += h; }
+    // (2) bucket columns: thread (bucket b = tid & 63, quarter q = tid >> 6) sums rows q, q + 4, ...
+    {
+        uint32_t before = 0, all = 0;
+        const uint32_t b = threadIdx.x & 63u;
+        for (uint32_t k = threadIdx.x >> 6; k < nblk; k += 4) {
+            const uint32_t h = bhist[k * 64 + b];
+            all += h;
+            if (k < blk) before += h;
+        }
+        __shared__ uint32_t pb[4][64], pa[4][64];
+        pb[threadIdx.x >> 6][b] = before; pa[threadIdx.x >> 6][b] = all;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            col_before[b] = (pb[0][b] + pb[1][b]) + (pb[2][b] + pb[3][b]);
+            col_total[b] = (pa[0][b] + pa[1][b]) + (pa[2][b] + pa[3][b]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int i = 0; i < 64; ++i) { bucket_pos[i] = run + col_before[i]; run += col_total[i]; }
+        }
     }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
-        const uint32_t cnt = len_of(t);
-        const uint32_t pos = atomicAdd(&hist[63u - min(63u, (uint32_t)((float)cnt * scale))], 1u);
-        tile_order[pos] = t;
-    }
-    if (!seg_off && !lens) return;
-    // One sweep over the tiles scans (list length, depth segments) packed in 64 bits: ranges (direct binning) and
-    // the depth-segment units.  Every thread owns a run of consecutive tiles, so the block needs ONE scan (a wave
-    // scan and sixteen wave sums) however many tiles there are.
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t per = (ntiles + 1023) / 1024, t0 = threadIdx.x * per, t1 = min(ntiles, t0 + per);
+    // (3) this block's tiles: exclusive scan of (length, units) in tile order
+    const uint32_t t0 = blk * TO_TILES + threadIdx.x * 4u;
+    uint32_t len[4];
     unsigned long long v = 0;
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t len = len_of(t);
-        v += ((unsigned long long)len << 32) | ((len + seg_len - 1) / seg_len);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        len[k] = (t0 + k < ntiles) ? tile_len(lens, ranges, t0 + k) : 0u;
+        v += ((unsigned long long)len[k] << 32) | ((len[k] + seg_len - 1) / seg_len);
     }
-    unsigned long long x = v;  // inclusive scan inside the wave
+    unsigned long long x = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned long long y = __shfl_up(x, o, 64);
         if (lane >= (uint32_t)o) x += y;
     }
-    if (lane == 63) wsum64[wave] = x;
+    if (lane == 63) wsum[wave] = x;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < 16; ++i) { const unsigned long long h = wsum64[i]; wsum64[i] = run; run += h; }
-        carry64 = run;
-    }
-    __syncthreads();
-    unsigned long long off64 = wsum64[wave] + x - v;
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t len = len_of(t), n = (len + seg_len - 1) / seg_len;
-        const uint32_t off = (uint32_t)off64, lstart = (uint32_t)(off64 >> 32);
-        if (lens) { ranges[2 * t] = lstart; ranges[2 * t + 1] = lstart + len; }
+    unsigned long long off64 = carry_sh + x - v;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) off64 += (w < (int)wave) ? wsum[w] : 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t = t0 + k;
+        if (t >= ntiles) break;
+        const uint32_t n = (len[k] + seg_len - 1) / seg_len, off = (uint32_t)off64, lstart = (uint32_t)(off64 >> 32);
+        if (lens) { ranges[2 * t] = lstart; ranges[2 * t + 1] = lstart + len[k]; }
         if (seg_off) {
             seg_off[t] = off;
-            if (seg_tile) for (uint32_t k = 0; k < n; ++k) seg_tile[off + k] = t;  // (direct binning: k_bin_scatter fills it)
+            for (uint32_t u = 0; u < n; ++u) seg_tile[off + u] = t;
         }
-        off64 += ((unsigned long long)len << 32) | n;
+        tile_order[atomicAdd(&bucket_pos[length_bucket(len[k])], 1u)] = t;
+        off64 += ((unsigned long long)len[k] << 32) | n;
     }
-    if (threadIdx.x == 0 && seg_off) {
-        seg_off[ntiles] = (uint32_t)carry64;
-        counters[2] = (uint32_t)carry64;
+    if (blk == nblk - 1 && threadIdx.x == 0 && seg_off) {
+        seg_off[ntiles] = (uint32_t)total_sh;
+        counters[2] = (uint32_t)total_sh;
         // the split this forward runs with: the backward kernels read it from here, not from their launch
         counters[4] = seg_len;
         counters[5] = fwd_variant;
     }
+}
+
+// scratch of the two kernels above: (sums, histograms) per block of TO_TILES tiles
+static int launch_tile_tables(uint32_t ntiles, uint32_t *ranges, const uint32_t *lens, uint32_t *tile_order,
+                              uint32_t *seg_off, uint32_t *seg_tile, uint32_t *counters, uint32_t seg_len,
+                              uint32_t fwd_variant, uint32_t *scratch_words, hipStream_t st) {
+    const uint32_t nblk = (ntiles + TO_TILES - 1) / TO_TILES;
+    unsigned long long *pre64 = reinterpret_cast<unsigned long long *>(scratch_words);
+    uint32_t *bhist = scratch_words + 2 * (size_t)nblk;
+    hipLaunchKernelGGL(k_tile_pre, dim3(nblk), dim3(256), 0, st, ntiles, ranges, lens, seg_len, pre64, bhist);
+    FGS_LAUNCH_CHECK("k_tile_pre");
+    hipLaunchKernelGGL(k_tile_post, dim3(nblk), dim3(256), 0, st, ntiles, ranges, lens, tile_order, seg_off, seg_tile,
+                       counters, seg_len, fwd_variant, pre64, bhist);
+    FGS_LAUNCH_CHECK("k_tile_post");
+    return FGS_OK;
 }
 
 __global__ __launch_bounds__(256) void k_count_pairs(uint32_t total, const float *__restrict__ rec,
@@ -538,19 +584,19 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         FGS_LAUNCH_CHECK("k_bin_scan");
         fgs_stage_end(ST_DUP_EMIT, st);
         fgs_stage_begin(ST_TILE_RANGES, st);
-        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ntiles_all, ranges, lens, tile_order, seg_off,
-                           (uint32_t *)nullptr, counters, (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant);
-        FGS_LAUNCH_CHECK("k_tile_order");
+        if ((rc = launch_tile_tables(ntiles_all, ranges, lens, tile_order, seg_off, seg_tile, counters,
+                                     (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant, vals1, st)))
+            return rc;
         fgs_stage_end(ST_TILE_RANGES, st);
         fgs_stage_begin(ST_TILE_SORT, st);
         if ((uint32_t)p.tiles <= BIN_MAX_TILES / 4)
             hipLaunchKernelGGL(k_bin_scatter<4>, dim3(B * bpi), dim3(256), 0, st, N, (uint32_t)p.tiles,
                                (uint32_t)p.L.tiles_x, bpi, dcap, order, tile_count, rec, cnt, ranges, dup_ids, bsum,
-                               dup_off, seg_off, seg_tile);
+                               dup_off);
         else
             hipLaunchKernelGGL(k_bin_scatter<1>, dim3(B * bpi), dim3(64), 0, st, N, (uint32_t)p.tiles,
                                (uint32_t)p.L.tiles_x, bpi, dcap, order, tile_count, rec, cnt, ranges, dup_ids, bsum,
-                               dup_off, seg_off, seg_tile);
+                               dup_off);
         FGS_LAUNCH_CHECK("k_bin_scatter");
         fgs_stage_end(ST_TILE_SORT, st);
         return FGS_OK;
@@ -582,9 +628,10 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     if (rgrid > 2048) rgrid = 2048;
     hipLaunchKernelGGL(k_tile_ranges, dim3(rgrid), dim3(256), 0, st, counters, ks, ranges);
     FGS_LAUNCH_CHECK("k_tile_ranges");
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, ntiles_all, ranges, (const uint32_t *)nullptr,
-                       tile_order, seg_off, seg_tile, counters, (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant);
-    FGS_LAUNCH_CHECK("k_tile_order");
+    // (vals0 is free again: the sort's final payload went to dup_ids, its last keys are in `ks`)
+    if ((rc = launch_tile_tables(ntiles_all, ranges, nullptr, tile_order, seg_off, seg_tile, counters,
+                                 (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant, ks == keys0 ? keys1 : keys0, st)))
+        return rc;
     fgs_stage_end(ST_TILE_RANGES, st);
     return FGS_OK;
 }
