@@ -628,8 +628,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     const float Gu = __builtin_amdgcn_exp2f(t * dx + ((s >> 1) ? cyyb : cyya));
                     const float G = __uint_as_float(__float_as_uint(Gu) & mk);
                     const float raw = G * op;
-                    float alpha = raw;
-                    if (clamp) alpha = fminf(raw, 0.99f);
+                    const float alpha = fminf(raw, 0.99f);  // a no-op unless `clamp` (then only the select below differs)
                     const float w = alpha * T[s];
                     const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
                     S[s] -= w * q;
