@@ -564,15 +564,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     }
     float fx0 = (float)(c.X0 + lx), fy0 = (float)(c.Y0 + ly);
     asm("" : "+v"(fx0), "+v"(fy0));  // hoisted for good: no v_cvt in the list loop
-    // Geometry gradients are accumulated as RAW moments of dL/dG about the TILE ORIGIN: sum dG {1, x, y, x^2, x y,
-    // y^2} with x, y in [0, 16) the lane's pixel inside the tile -- per-lane constants, so every moment is one FMA
-    // per pixel and Gaussian (the central moments sum dm' {dx, dy, dx^2, dx dy, dy^2} took nine).  k_project_bwd
-    // shifts each row's moments to the Gaussian's mean (in double) and applies the ln2 * opacity and K factors.
-    float pxs[2] = {(float)lx, (float)(lx + 8u)}, pys[2] = {(float)ly, (float)(ly + 8u)};
-    float pxx[2] = {pxs[0] * pxs[0], pxs[1] * pxs[1]}, pyy[2] = {pys[0] * pys[0], pys[1] * pys[1]};
-    float pxy[4] = {pxs[0] * pys[0], pxs[1] * pys[0], pxs[0] * pys[1], pxs[1] * pys[1]};
-    asm("" : "+v"(pxs[0]), "+v"(pxs[1]), "+v"(pys[0]), "+v"(pys[1]), "+v"(pxx[0]), "+v"(pxx[1]), "+v"(pyy[0]), "+v"(pyy[1]),
-        "+v"(pxy[0]), "+v"(pxy[1]), "+v"(pxy[2]), "+v"(pxy[3]));  // constants for the whole unit: never recomputed
     for (uint32_t base = c.start; base < c.end; base += CH) {
         const uint32_t n = min((uint32_t)CH, c.end - base);
         if (lane < n) {
@@ -605,7 +596,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             asm("" : "+v"(bdya), "+v"(bdyb), "+v"(cyya), "+v"(cyyb));  // keep the row terms: do not recompute them per sub-tile
             // bbox membership: the lane's column / row bits of the staged pixel bits become all-ones / zero masks
             // (v_bfe_i32) and zero G with a bit-and -- no per-pixel compare / select (issue costs: DESIGN.md).
-            // per-lane partial sums over this lane's (up to four) pixels: raw moments of dL/dG (see above)
+            // per-lane partial sums over this lane's (up to four) pixels: moments of dL/dG about the Gaussian's mean, sum dG
+            // {dx, dy, dx^2, dx dy, dy^2, 1}; the ln2 * opacity and K factors of the chain through m' = K m are
+            // applied once per Gaussian in k_project_bwd.  (Raw moments about the tile origin -- one FMA each with
+            // per-lane constants -- were 4 % faster but lose the second moments of sub-pixel Gaussians to
+            // cancellation in fp32: up to 4e-2 on dL/dscale in the randomized sweeps.)
             float v_mx = 0, v_my = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
             {   // ONE code path for every kind of entry; what differs is handled by wave-uniform branches around a few
                 // ops: `inside` (bbox covers the tile, flag bit 5): no lane masks to extract; `clamp` (flag bit 4
@@ -623,7 +618,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
                     // G is zeroed outside the bbox: alpha, w and every gradient term below then vanish by themselves
                     const uint32_t mk = ((s & 1) ? mx1 : mx0) & ((s >> 1) ? my1 : my0);
-                    const float dx = (s & 1) ? dxb : dxa;
+                    const float dx = (s & 1) ? dxb : dxa, dy = (s >> 1) ? dyb : dya;
                     const float t = ca * dx + ((s >> 1) ? bdyb : bdya);
                     const float Gu = __builtin_amdgcn_exp2f(t * dx + ((s >> 1) ? cyyb : cyya));
                     const float G = __uint_as_float(__float_as_uint(Gu) & mk);
@@ -637,8 +632,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     if (clamp) dalpha = select_le(raw, 0.99f, dalpha);
                     const float dG = dalpha * G;
                     v_op += dG;
-                    v_mx += dG * pxs[s & 1]; v_my += dG * pys[s >> 1];
-                    v_ca += dG * pxx[s & 1]; v_cbc += dG * pxy[s]; v_cd += dG * pyy[s >> 1];
+                    const float dmx = dG * dx, dmy = dG * dy;
+                    v_mx += dmx; v_my += dmy;
+                    v_ca += dmx * dx; v_cbc += dmx * dy; v_cd += dmy * dy;
                     v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
                 }
             }

@@ -193,36 +193,18 @@ __global__ __launch_bounds__(256) void k_project_bwd(
         // rows_per_dup gradient rows per duplicate (4 on the phase path: one per sub-tile wave), contiguous
         const uint32_t cnt = tile_count[idx] * rows_per_dup, off = dup_off[idx] * rows_per_dup;
         if (MODE == 0 && phase_channels) {
-            // blend path: 10-float rows = RAW moments of dL/dG about the row's tile origin (sum dG {x, y, x^2, x y,
-            // y^2, 1}, x, y the pixel inside the tile), colour and depth sums (k_composite_bwd).  Each row is shifted
-            // to the Gaussian's mean here, in double: with (a, b) = mean - tile origin,
-            //   sum dG dx = Rx - a R0, sum dG dx^2 = Rxx - 2 a Rx + a^2 R0, sum dG dx dy = Rxy - a Ry - b Rx + a b R0, ...
-            // and the totals get the factors of the chain through m' = K m, G = exp2(m'), alpha = G opacity:
-            // first moments x ln2 opacity (then dL/d(u,v) = -K conic_sym M below), dL/dconic = K ln2 opacity x second.
-            const float *rc = rec + (size_t)idx * FGS_REC_FLOATS;
-            const uint32_t bbx = __float_as_uint(rc[R_BBX]), bby = __float_as_uint(rc[R_BBY]);
-            const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, ty0 = (bby & 0xFFFFu) / FGS_TILE;
-            const uint32_t tw = ((bbx >> 16) - 1) / FGS_TILE - tx0 + 1;
-            const double u = rc[R_U], v = rc[R_V];
+            // blend path: 10-float rows = moments of dL/dG about the Gaussian's mean (sum dG {dx, dy, dx^2, dx dy, dy^2,
+            // 1}), colour and depth sums (k_composite_bwd), summed in double.  The totals get the factors of the chain
+            // through m' = K m, G = exp2(m'), alpha = G opacity: first moments x ln2 opacity (then dL/d(u,v) =
+            // -K conic_sym M below), dL/dconic = K ln2 opacity x second moments.
             double m[6] = {0, 0, 0, 0, 0, 0};
-            uint32_t tx = sub % tw, ty = sub / tw;  // tile of row k inside the Gaussian's tile rectangle (k = sub, sub + 4, ...)
-            const uint32_t stepx = 4u % tw, stepy = 4u / tw;
             for (uint32_t k = sub; k < cnt && off + k < dcap; k += 4) {
                 const float2 *r = reinterpret_cast<const float2 *>(grad_rows + (size_t)(off + k) * FGS_BLEND_ROW_FLOATS);
                 const float2 a = r[0], bq = r[1], cq = r[2], dq = r[3], eq = r[4];
-                const double pa = u - (double)((tx0 + tx) * FGS_TILE), pb = v - (double)((ty0 + ty) * FGS_TILE);
-                const double Rx = a.x, Ry = a.y, Rxx = bq.x, Rxy = bq.y, Ryy = cq.x, R0 = cq.y;
-                m[0] += Rx - pa * R0;
-                m[1] += Ry - pb * R0;
-                m[2] += Rxx - 2.0 * pa * Rx + pa * pa * R0;
-                m[3] += Rxy - pa * Ry - pb * Rx + pa * pb * R0;
-                m[4] += Ryy - 2.0 * pb * Ry + pb * pb * R0;
-                m[5] += R0;
+                m[0] += a.x; m[1] += a.y; m[2] += bq.x; m[3] += bq.y; m[4] += cq.x; m[5] += cq.y;
                 acc[6] += dq.x; acc[7] += dq.y; acc[8] += eq.x; acc[9] += eq.y;
-                tx += stepx; ty += stepy;
-                if (tx >= tw) { tx -= tw; ++ty; }
             }
-            const double hp = 0.69314718055994530942 * (double)rc[R_OP];
+            const double hp = 0.69314718055994530942 * (double)rec[(size_t)idx * FGS_REC_FLOATS + R_OP];
             acc[0] = (float)(hp * m[0]); acc[1] = (float)(hp * m[1]);
             acc[2] = (float)(-0.72134752044448170368 * hp * m[2]); acc[3] = (float)(-0.72134752044448170368 * hp * m[3]);
             acc[4] = (float)(-0.72134752044448170368 * hp * m[4]); acc[5] = (float)m[5];
