@@ -113,7 +113,7 @@ def host_cores():
 def cpu_baseline_leg(leaves, gI, gD, N, S, budget_s=8.0):
     """The reference's pure-PyTorch per-Gaussian-loop rasterizer cannot travel to this box, so the CPU baseline is
     this repo's restatement of it (oracle/torch_loop.py, same algorithm / same per-iteration tensor work, checked
-    against the C oracle in tests/) on a BOUNDED sample of image 0: its first n Gaussians, n <= 2048 chosen from a
+    against the C oracle in tests/) on a BOUNDED sample of image 0: its first n Gaussians, n <= 8192 chosen from a
     64-Gaussian calibration run so that forward + autograd backward take about `budget_s` seconds -- once with all
     host cores, once with one thread; plus the scalar C oracle on two full images."""
     from oracle import fgs_oracle as orc
@@ -126,7 +126,7 @@ def cpu_baseline_leg(leaves, gI, gD, N, S, budget_s=8.0):
     def run(threads):
         sub = lambda n: [t[0, :n].detach().cpu().numpy() for t in leaves]
         _, t_cal = tl.timed_fwd_bwd(sub(min(64, N)), view, fx, fx, S / 2, S / 2, S, S, gi, gd, threads=threads)
-        n = int(max(64, min(2048, N, budget_s / max(t_cal / min(64, N), 1e-6))))
+        n = int(max(64, min(8192, N, budget_s / max(t_cal / min(64, N), 1e-6))))
         p, t = tl.timed_fwd_bwd(sub(n), view, fx, fx, S / 2, S / 2, S, S, gi, gd, threads=threads)
         return n, p, t
 
