@@ -662,6 +662,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 // entries; this kernel walks the list in REVERSE sub-chunks, re-runs the forward inside each
 // sub-chunk from its checkpoint (parking (A_{i-1}, Phi_{i-1}) per entry in LDS), then sweeps
 // the sub-chunk back-to-front with the per-pixel adjoints Abar (init -gI.bg) and Phibar.
+// (70 VGPRs = 7 waves per SIMD; forcing 8 spills 19 registers and costs 30 %)
 __global__ __launch_bounds__(256) void k_composite_bwd_phase(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
     uint32_t dcap, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
@@ -758,10 +759,12 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                     const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
                     const float dx = (float)px - q0.x, dy = (float)py - q0.y;
                     const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
-                    float alpha = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E) * q1.y;
+                    const float Gf = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E);
+                    float alpha = Gf * q1.y;
                     float pd = fabsf(ph - Pf);
                     pd = fminf(pd, 1.0f - pd);
-                    alpha *= (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
+                    const float interf = (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
+                    alpha *= interf;
                     alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
                     alpha = in ? alpha : 0.0f;
                     const float w = alpha * (1.0f - Af);
@@ -788,13 +791,16 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                     const float Aprev = sA[k], Pprev = sP[k];
                     const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
                     const float dx = (float)px - q0.x, dy = (float)py - q0.y;
-                    const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
-                    const float G = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E);
                     const float dphi = ph - Pprev;
                     const float pd0 = fabsf(dphi);
                     const float pd = fminf(pd0, 1.0f - pd0);
+                    const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
+                    const float G = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E);
                     const float inter = (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
-                    const float raw = (G * op) * inter;
+                    // (parking G and `inter` of the re-run instead of recomputing them costs 14 VGPRs = one wave per
+                    // SIMD and was 7 % slower: this kernel lives on occupancy)
+                    const float Gop = G * op, Gint = G * inter;
+                    const float raw = Gop * inter;
                     const float alpha = in ? fminf(fmaxf(raw, 0.0f), 0.99f) : 0.0f;
                     const float T = 1.0f - Aprev;
                     const float w = alpha * T;
@@ -819,8 +825,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                     const float abar = wbar * T;
                     Ab -= wbar * alpha;
                     const float rbar = (in && raw >= 0.0f && raw <= 0.99f) ? abar : 0.0f;
-                    v_op += rbar * G * inter;
-                    const float pdbar = -(rbar * G * op) * amp * PHASE_KAPPA * phase_sin(PHASE_KAPPA * pd);
+                    v_op += rbar * Gint;
+                    const float pdbar = -(rbar * Gop) * amp * PHASE_KAPPA * phase_sin(PHASE_KAPPA * pd);
                     const float pd0bar = (pd0 < 1.0f - pd0) ? pdbar : ((pd0 > 1.0f - pd0) ? -pdbar : 0.0f);
                     const float sg = (dphi > 0.0f) ? 1.0f : ((dphi < 0.0f) ? -1.0f : 0.0f);
                     v_ph += pd0bar * sg;
@@ -828,7 +834,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
                         Pbar = Pb * (1.0f - pc) - pd0bar * sg;
                         Abar = Ab;
                     }
-                    const float dm = -0.5f * (rbar * op * inter) * G;
+                    const float dm = -0.5f * (rbar * raw);
                     v_ca += dm * dx * dx; v_cbc += dm * dx * dy; v_cd += dm * dy * dy;
                     v_u -= dm * (2.0f * ca * dx + cbc * dy);
                     v_v -= dm * (cbc * dx + 2.0f * cd * dy);
