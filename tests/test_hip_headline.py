@@ -128,3 +128,43 @@ def test_saturation_skip_vs_oracle(shape):
         assert rel_to_max(dep[b].detach().cpu().numpy(), r.depth) <= TOL
         for k, t in zip(KEYS, ts):
             assert rel_to_max(t.grad[b].cpu().numpy(), go[k]) <= TOL, (b, k)
+
+
+def test_large_frame_radix_binning_path_vs_oracle():
+    """A frame of more than 4096 tiles per image (1200 x 1100 = 75 x 69 = 5175 tiles): the direct counting sort does
+    not apply and the lists come from the emit + stable radix sort path (also what the layered ASM keys use); image,
+    depth, gradients and integer stages against the oracle."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd import _binding as B
+    from fresnel_amd.renderer import Camera
+    W, H, N = 1200, 1100, 3000
+    with pytest.raises(B.FgsError):  # direct binning cannot be forced on such a frame
+        B.workspace_bytes(B.make_dims(1, N, W, H, tuning=dict(bin_mode=1)))
+    rs = np.random.RandomState(3)
+    from helpers import synth_aniso
+    arrs = list(synth_aniso(N, 5, smax=0.08))
+    bg = (0.1, 0.2, 0.3)
+    cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), cam.fx, cam.fy, cam.cx, cam.cy, W, H)
+    r = orc.render(*arrs, ocam, bg=bg)
+    gI = rs.standard_normal((3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
+    go = orc.render_backward(r, gI, gD)
+    st = _hip_stages([a[None] for a in arrs], cam, W, H, bg)
+    _check_integer_stages(st, 0, r, W, H)
+    out = _hip_render(arrs, cam, W, H, bg, grads=(gI, gD))
+    assert rel_to_max(out["image"], r.image) <= TOL and rel_to_max(out["depth"], r.depth) <= TOL
+    for k in KEYS:
+        assert rel_to_max(out["grad_" + k], go[k]) <= TOL, k
+
+
+def test_more_than_65536_gaussians_per_image_vs_oracle():
+    """N = 70 000 Gaussians in one image (beyond 16-bit ranks; 274 blocks of depth ranks per image): small opaque-ish
+    splats over a 256 x 256 frame, long lists."""
+    from helpers import synth_saag
+    pos, scale, quat, col, opa = synth_saag(70000, 9)
+    scale[:] = 0.02
+    opa[:] = 0.05
+    worst, st = _run_batch_and_check([(pos, scale, quat, col, opa)], 256, check=[0], bg=(0.2, 0.1, 0.0), seed=36,
+                                     min_segments=4)
+    assert st["order"].shape[1] == 70000
