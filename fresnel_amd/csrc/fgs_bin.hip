@@ -337,11 +337,7 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
                 const uint32_t tile = (tyg + y) * tiles_x + txg + (t - y * wg);
                 const uint32_t pos = run[wave][tile];  // tiles of one Gaussian are distinct: plain read-modify-write
                 run[wave][tile] = pos + 1;
-#ifndef FGS_EXP_NOSTORE
                 if (pos < dcap) dup_ids[pos] = idg;
-#else
-                if (pos == 0xFFFFFFF0u) dup_ids[pos] = idg;
-#endif
             }
             __builtin_amdgcn_wave_barrier();
         }

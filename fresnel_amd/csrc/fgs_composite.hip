@@ -468,11 +468,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     float *__restrict__ grad_rows, float t_eps) {
     __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
     __shared__ uint32_t she[CH];
-#ifdef FGS_AB_OLD_REDUCE
-    __shared__ __attribute__((aligned(16))) float red[10][80];
-#else
     __shared__ __attribute__((aligned(16))) float red[10 * FGS_RED_PITCH];  // per-lane partial sums of one list entry
-#endif
     // work unit = (tile, depth segment): blockIdx.x indexes the unit list built by k_tile_order; the grid is
     // sized from the capacity, surplus blocks leave at once
     const uint32_t num_units = counters[2];
@@ -642,11 +638,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             // into this duplicate's gradient row: no atomics, fixed order, bitwise reproducible ----
             {
                 const float vals[10] = {v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d};
-#ifdef FGS_AB_OLD_REDUCE
-                const float tot = wave_sum_transposed<10>(red, vals, lane);
-#else
                 const float tot = wave_sum10_addtid(red, vals, lane);
-#endif
                 const uint32_t kk = lane >> 2, e = she[j];
                 if ((lane & 3u) == 3u && lane < 40u && e < dcap) grad_rows[(size_t)e * FGS_BLEND_ROW_FLOATS + kk] = tot;
             }

@@ -112,13 +112,8 @@ __device__ __forceinline__ uint32_t fgs_lane() { return threadIdx.x & 63u; }
 // addresses (4-byte list entries, 40-byte gradient rows) merge in that L2 instead of reaching HBM as masked
 // partial writes from several XCDs.  Bijective on [0, nwg) for any nwg; placement only, never correctness.
 __device__ __forceinline__ uint32_t fgs_xcd_remap(uint32_t bid, uint32_t nwg) {
-#ifdef FGS_NO_XCD_REMAP
-    (void)nwg;
-    return bid;
-#else
     const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, i = bid >> 3;
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + i;
-#endif
 }
 
 // order-preserving map float -> uint32 (ascending), -0.0 folded into +0.0

@@ -1,45 +1,5 @@
-// Wave64 cross-lane reductions for gfx950, shared by the composite and ASM kernels.
-//
-// wave_sumN_lane63: wave-wide sums of N floats at once; the totals are valid in lane 63.
-// Hand-written fused v_add_f32_dpp (hipcc lowers the update_dpp builtin to v_mov_dpp + add
-// pairs: 2.5x the instructions).  The N chains are interleaved so that dependent DPP reads are
-// N instructions apart (>= the 2 wait states a VALU write -> DPP read needs); the leading s_nop
-// covers the producers of the inputs.  row_shr 1,2,4,8 sum each 16-lane row into its lane 15;
-// row_bcast:15 / row_bcast:31 carry the row totals to lane 63.
+// Wave64 cross-lane reductions and list-staging helpers for gfx950, shared by the composite and ASM kernels.
 #pragma once
-
-#define FGS_DPP1(i, ctrl) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " ctrl "\n"
-#define FGS_DPP10(ctrl)                                                                                  \
-    FGS_DPP1(0, ctrl) FGS_DPP1(1, ctrl) FGS_DPP1(2, ctrl) FGS_DPP1(3, ctrl) FGS_DPP1(4, ctrl) FGS_DPP1(5, ctrl) \
-    FGS_DPP1(6, ctrl) FGS_DPP1(7, ctrl) FGS_DPP1(8, ctrl) FGS_DPP1(9, ctrl)
-#define FGS_DPP11(ctrl) FGS_DPP10(ctrl) FGS_DPP1(10, ctrl)
-#define FGS_DPP12(ctrl) FGS_DPP11(ctrl) FGS_DPP1(11, ctrl)
-#define FGS_DPP_TREE(STEP)                                                                               \
-    "s_nop 1\n" STEP("row_shr:1 row_mask:0xf bank_mask:0xf") STEP("row_shr:2 row_mask:0xf bank_mask:0xf")  \
-    STEP("row_shr:4 row_mask:0xf bank_mask:0xf") STEP("row_shr:8 row_mask:0xf bank_mask:0xf")            \
-    STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1\n"
-
-__device__ __forceinline__ void wave_sum10_lane63(float &a0, float &a1, float &a2, float &a3, float &a4,
-                                                  float &a5, float &a6, float &a7, float &a8, float &a9) {
-    asm volatile(FGS_DPP_TREE(FGS_DPP10)
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
-                   "+v"(a9));
-}
-
-__device__ __forceinline__ void wave_sum11_lane63(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
-                                                  float &a6, float &a7, float &a8, float &a9, float &a10) {
-    asm volatile(FGS_DPP_TREE(FGS_DPP11)
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
-                   "+v"(a9), "+v"(a10));
-}
-
-__device__ __forceinline__ void wave_sum12_lane63(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5,
-                                                  float &a6, float &a7, float &a8, float &a9, float &a10,
-                                                  float &a11) {
-    asm volatile(FGS_DPP_TREE(FGS_DPP12)
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8),
-                   "+v"(a9), "+v"(a10), "+v"(a11));
-}
 
 // Staging-time (per lane, parallel over the chunk) decode of a record's bbox against a 16x16 tile
 // at (X0, Y0): bit s = sub-tile s (8x8, s = 2*row + col) intersects the bbox [x0,x1) x [y0,y1).
