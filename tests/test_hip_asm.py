@@ -292,3 +292,37 @@ def test_asm_single_depth_plane_vs_oracle():
     assert np.abs(out["image"][0] - r["image"]).max() <= TOL
     for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
         assert rel_to_max(out["grad_" + k][0], r["grad_" + k]) <= TOL, k
+
+
+def test_asm_config5_frame_batched_vs_oracle():
+    """BASELINE config 5's frame and renderer defaults (512 x 512, 16 depth planes 0.1..2.0, focal 0.5, pitch 1/256,
+    per-channel wavelengths .0635/.05/.041) on a B = 2 batch of create_dummy_saag Gaussians: 2 x 16 x 1024 = 32 768
+    (image, plane, tile) lists through the layered binning, the batched 96-field FFT, one inverse FFT per channel and
+    the full backward.  (N = 1024 per image keeps the torch oracle to tens of seconds; the bench runs N = 8192.)"""
+    from oracle import asm_oracle, fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    from helpers import synth_saag
+    S, N, Bn = 512, 1024, 2
+    rs = np.random.RandomState(55)
+    per = [synth_saag(N, 500 + b) for b in range(Bn)]
+    arrs = [np.stack([p[i] for p in per]) for i in range(5)]
+    phases = (rs.random_sample((Bn, N)) * 2 * np.pi).astype(np.float32)
+    wl = np.array([0.0635, 0.05, 0.041], np.float32)
+    gI = rs.standard_normal((Bn, 3, S, S)).astype(np.float32)
+    cam = Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+    out = _hip_asm(arrs, phases, wl, cam, S, S, (0.0, 0.0, 0.0), gI=gI)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+    gw = 0.0
+    for b in range(Bn):
+        r = asm_oracle.render(*[a[b] for a in arrs], phases[b], wl, ocam, grad_out=gI[b])
+        assert np.abs(out["image"][b] - r["image"]).max() <= TOL
+        for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
+            assert rel_to_max(out["grad_" + k][b], r["grad_" + k]) <= TOL, (b, k)
+        gw = gw + r["grad_wavelengths"]
+    # wavelength 0.05 at pitch 1/256 on a 512 grid puts frequencies exactly on the evanescent boundary
+    # (1/l^2 = 400 = 12^2 + 16^2): torch's autograd of sqrt(clamp(.)) gives NaN there (0 * inf) -- the reference's own
+    # behaviour -- while the library defines dkz/dlambda = 0 on the boundary (include/fgs.h) and stays finite
+    gw = np.asarray(gw)
+    finite = np.isfinite(gw)
+    assert np.isfinite(out["grad_wavelengths"]).all() and finite.sum() >= 2
+    assert rel_to_max(out["grad_wavelengths"][finite], gw[finite]) <= 1e-3
