@@ -168,3 +168,35 @@ def test_more_than_65536_gaussians_per_image_vs_oracle():
     worst, st = _run_batch_and_check([(pos, scale, quat, col, opa)], 256, check=[0], bg=(0.2, 0.1, 0.0), seed=36,
                                      min_segments=4)
     assert st["order"].shape[1] == 70000
+
+
+def test_config4_phase_launch_vs_oracle():
+    """BASELINE config 4 as the bench launches it: 16 images x 8 192 Gaussians @256x256, depths snapped to 8 zone
+    centres (massive depth ties -> canonical stable order), edge-aware scale factors U(.5,1), scalar phases U(0,1),
+    phase blending with amplitude 0.25 -- forward, all gradients incl. dL/dphase of images 0 and 11 vs the oracle."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    from helpers import synth_saag
+    S, N, Bn = 256, 8192, 16
+    rs = np.random.RandomState(44)
+    per = []
+    for b in range(Bn):
+        pos, scale, quat, col, opa = synth_saag(N, 4000 + b)
+        pos[:, 2] = (-2.0 - 2.0 * (rs.randint(0, 8, N) + 0.5) / 8.0).astype(np.float32)
+        scale = (scale * rs.uniform(0.5, 1.0, (N, 1))).astype(np.float32)
+        per.append((pos, scale, quat, col, opa))
+    arrs = [np.stack([p[i] for p in per]) for i in range(5)]
+    phases = rs.random_sample((Bn, N)).astype(np.float32)
+    cam = Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+    gI = rs.standard_normal((Bn, 3, S, S)).astype(np.float32)
+    gD = (rs.standard_normal((Bn, S, S)) * 0.1).astype(np.float32)
+    out = _hip_render(arrs, cam, S, S, (0.0, 0.0, 0.0), phases=phases, use_phase=True, amp=0.25, grads=(gI, gD))
+    for b in (0, 11):
+        r = orc.render(*[a[b] for a in arrs], ocam, phases=phases[b], phase_amp=0.25)
+        assert len(np.unique(r.proj["depth"][r.proj["visible"].astype(bool)])) <= 8
+        go = orc.render_backward(r, gI[b], gD[b])
+        assert rel_to_max(out["image"][b], r.image) <= TOL and rel_to_max(out["depth"][b], r.depth) <= TOL
+        for k in KEYS:
+            assert rel_to_max(out["grad_" + k][b], go[k]) <= TOL, (b, k)
+        assert rel_to_max(out["grad_phases"][b], go["phases"]) <= TOL, b
