@@ -102,3 +102,25 @@ def test_tuning_fields_are_validated_and_change_only_the_split():
     with pytest.raises(B.FgsError):
         B.workspace_bytes(B.make_dims(1, 100, 2048, 2048, tuning=dict(bin_mode=1)))
     B.workspace_bytes(B.make_dims(1, 100, 2048, 2048, tuning=dict(bin_mode=2)))
+
+
+def test_new_entries_validate_arguments_without_a_gpu(lib):
+    """The round-2 entry points reject bad shapes / null pointers before touching the device (rc = FGS_EINVAL = -1,
+    message in fgs_last_error): gather hand-off, Helmholtz loss, propagator workspace."""
+    lib.fgs_last_error.restype = ctypes.c_char_p
+    i32, vp, f32 = ctypes.c_int32, ctypes.c_void_p, ctypes.c_float
+    lib.fgs_gather_forward.argtypes = [i32] * 4 + [vp] * 14
+    lib.fgs_gather_backward.argtypes = [i32] * 4 + [vp] * 14
+    nul = [None] * 14
+    assert lib.fgs_gather_forward(2, 100, 200, 0, *nul) == -1            # n_out > n_in
+    assert b"invalid dims" in lib.fgs_last_error()
+    assert lib.fgs_gather_forward(2, 100, 50, 2, *nul) == -1             # phase_channels must be 0 | 1 | 3
+    assert lib.fgs_gather_forward(2, 100, 50, 0, *nul) == -1             # null indices
+    assert b"null" in lib.fgs_last_error()
+    assert lib.fgs_gather_backward(0, 100, 50, 0, *nul) == -1
+    lib.fgs_helmholtz_loss_forward.argtypes = [i32, i32, i32, f32, f32] + [vp] * 5
+    assert lib.fgs_helmholtz_loss_forward(1, 8, 8, 0.05, 0.0, *([None] * 5)) == -1
+    lib.fgs_asm_propagate_workspace_bytes.argtypes = [i32, i32, i32, ctypes.POINTER(ctypes.c_size_t)]
+    assert lib.fgs_asm_propagate_workspace_bytes(0, 8, 1, None) == -1
+    lib.fgs_reduction_scratch_bytes.restype = ctypes.c_size_t
+    assert lib.fgs_reduction_scratch_bytes() >= 8192
