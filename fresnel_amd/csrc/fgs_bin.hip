@@ -227,8 +227,8 @@ __global__ __launch_bounds__(256) void k_bin_scan(uint32_t B, uint32_t tiles, ui
     lens[col] = run;
 }
 
-// NW waves per block of BIN_G depth ranks (NW = 4 when the counters of four waves fit in LDS, i.e. <= 1024 tiles):
-// wave w owns ranks [w, w+1) * BIN_G / NW of the block.  The walk over a wave's Gaussians is inherently serial
+// NW waves per block of BIN_G depth ranks (NW = 8 when the slot tables of eight waves fit in LDS, i.e. <= 1024 tiles;
+// else one wave): wave w owns ranks [w, w+1) * BIN_G / NW of the block.  The walk over a wave's Gaussians is inherently serial
 // (each one bumps the counters of its tiles), so what matters is how many such walks run side by side: the four
 // waves first count their own duplicates per tile, turn the counts into per-wave start slots (in rank order), and
 // then walk independently.
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
                                                          uint32_t *__restrict__ dup_ids,
                                                          const uint32_t *__restrict__ bsum,
                                                          uint32_t *__restrict__ dup_off) {
-    constexpr uint32_t T_MAX = NW == 1 ? BIN_MAX_TILES : BIN_MAX_TILES / NW;
+    constexpr uint32_t T_MAX = NW == 1 ? BIN_MAX_TILES : 1024;  // NW > 1: frames of <= 1024 tiles
     constexpr uint32_t WG = BIN_G / NW;  // ranks per wave
     __shared__ uint32_t run[NW][T_MAX];  // next free slot of every tile list, per wave
     // consecutive rank blocks append to neighbouring list slots: keep them on one XCD so that the 4-byte entries
@@ -281,8 +281,8 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     // this lane's Gaussian of each 64-rank batch of the wave (WG / 64 batches)
-    constexpr int NB = WG / 64;
-    static_assert(WG % 64 == 0, "whole 64-rank batches per wave");
+    constexpr int NB = WG >= 64 ? WG / 64 : 1;
+    static_assert(WG % 64 == 0 || WG == 32, "whole 64-rank batches per wave, or half a wave of ranks");
     uint32_t gid[NB];
     TileRect q[NB];
     uint32_t inv[NB];  // ceil(2^18 / w): (t * inv) >> 18 is t / w or one more for t < 2^12 (fixed up below)
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t ti
     for (int i = 0; i < NB; ++i) {
         const uint32_t r = blk * BIN_G + wave * WG + i * 64 + lane;
         gid[i] = 0; q[i] = TileRect{0, 0, 1, 0};
-        if (r < N) {
+        if (i * 64 + lane < WG && r < N) {
             gid[i] = b * N + order[b * N + r];
             q[i] = tile_rect(rec, gid[i], tile_count[gid[i]]);
         }
@@ -585,8 +585,10 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
             return rc;
         fgs_stage_end(ST_TILE_RANGES, st);
         fgs_stage_begin(ST_TILE_SORT, st);
-        if ((uint32_t)p.tiles <= BIN_MAX_TILES / 4)
-            hipLaunchKernelGGL(k_bin_scatter<4>, dim3(B * bpi), dim3(256), 0, st, N, (uint32_t)p.tiles,
+        // eight waves x 32 depth ranks per block when the per-wave slot tables fit (<= 1024 tiles): the walk over a
+        // wave's Gaussians is serial, so shorter walks, more of them (four waves x 64: 0.061 -> 0.054 ms at config 3)
+        if ((uint32_t)p.tiles <= 1024)
+            hipLaunchKernelGGL(k_bin_scatter<8>, dim3(B * bpi), dim3(512), 0, st, N, (uint32_t)p.tiles,
                                (uint32_t)p.L.tiles_x, bpi, dcap, order, tile_count, rec, cnt, ranges, dup_ids, bsum,
                                dup_off);
         else
