@@ -84,6 +84,15 @@ def synth_batch(n_img, N, seed0, device, distribution="saag"):
     return [torch.stack(t).to(device) for t in (pos, scl, quat, col, opa)]
 
 
+def pmc_field_traffic(run_key):
+    """config 5: HBM bytes per step of both field stages together (rocFFT + spectral kernels), same source."""
+    if not os.path.exists(PMC_SUMMARY):
+        return None
+    run = json.load(open(PMC_SUMMARY)).get("runs", {}).get(run_key) or {}
+    v = run.get("field_stages_hbm_bytes_per_step")
+    return int(v) if v else None
+
+
 def pmc_traffic(run_key, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
     (profiles/r02_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per the gfx950
@@ -341,6 +350,13 @@ def main():
         roofline["traffic_source"] = (f"profiles/r02_pmc_summary.json run {run_key}: separate rocprofv3 --pmc FETCH_SIZE / "
                                       "WRITE_SIZE passes of this command, 2*FETCH_SIZE + WRITE_SIZE per launch"
                                       if traffic is not None else None)
+        if dom_stage in ("field_fwd", "field_bwd") and pmc_field_traffic(run_key) is not None:
+            # a stage of many kernels (rocFFT's + ours): the counters are summed over BOTH field stages of a step, to
+            # be compared with the algorithmic bytes of both (2 x 0.36 GB per image)
+            roofline["traffic"] = pmc_field_traffic(run_key)
+            roofline["traffic_source"] = (f"profiles/r02_pmc_summary.json run {run_key}: 2*FETCH_SIZE + WRITE_SIZE summed over all "
+                                          "kernels of field_fwd AND field_bwd per step; algorithmic counterpart = "
+                                          f"{int(2 * ASM_BYTES_PER_IMAGE * per_gpu)} bytes")
         roofline["flop_model"] = ("SURVEY 8d: 23 flop per Gaussian-pixel forward, 60 backward (phase path: same count, its extra "
                                   "cos/sin/divide work is not credited); splat 12 / 36; peak = fp32 vector peak (plain, "
                                   "non-packed VALU code tops out at about half of it, DESIGN.md section 4)")

@@ -19,12 +19,17 @@ def match(name):
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(lambda: collections.defaultdict(set))
+# field stages of the ASM renderer (config 5): rocFFT's kernels + the spectral elementwise kernels, both directions
+FIELD = ('fft_rtc', 'k_asm_transfer', 'k_asm_accumulate', 'k_asm_max', 'k_asm_output')
+field = collections.defaultdict(float)
 for f in glob.glob(root + '/g*/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
         k = match(row['Kernel_Name'])
         if k:
             acc[k][row['Counter_Name']] += float(row['Counter_Value'])
             calls[k][row['Counter_Name']].add(row['Dispatch_Id'])
+        if any(t in row['Kernel_Name'] for t in FIELD) and row['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            field[row['Counter_Name']] += float(row['Counter_Value'])
 stats = {}
 for sf in glob.glob(root + '/stats/**/*kernel_stats.csv', recursive=True):
     for row in csv.DictReader(open(sf)):
@@ -46,6 +51,11 @@ for k in sorted(set(list(acc) + list(stats))):
     if row.get('SQ_LDS_IDX_ACTIVE'):
         row['lds_conflict_share'] = round(row.get('SQ_LDS_BANK_CONFLICT', 0.0) / row['SQ_LDS_IDX_ACTIVE'], 4)
     out['kernels'].append(row)
+if field:
+    # the PMC passes run `--steps 3 --warmup 1`: four steps per pass
+    out["field_stages_hbm_bytes_per_step"] = (2 * field['FETCH_SIZE'] + field['WRITE_SIZE']) * 1024 / 4
+    out["field_stages_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) summed over rocFFT's kernels and k_asm_transfer / accumulate[_bwd] / max / "
+                                "output[_bwd] of field_fwd AND field_bwd, per step (4 steps per PMC pass)")
 json.dump(out, open(root + '/pmc_run.json', 'w'), indent=1)
 for r in out['kernels']:
     print(r['kernel'], {k: (round(v, 1) if isinstance(v, float) else v) for k, v in r.items() if k in
