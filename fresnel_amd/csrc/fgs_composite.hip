@@ -344,11 +344,9 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const uint32_t gid = dup_ids[base + lane];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
             float4 q0 = r[0], q1 = r[1], q2 = r[2];
-            // m >= 0 everywhere (G <= 1): positive definite with a margin (as in k_composite_bwd's staging)
-            const bool conic_ok = q0.z > 0.0f && q1.x > 0.0f && 3.996f * q0.z * q1.x > q0.w * q0.w;
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
             uint32_t flags, bits;
-            stage_decode(c.X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, bits, conic_ok);
+            stage_decode(c.X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, bits);
             q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
             sh0[wave][lane] = q0; sh1[wave][lane] = q1; sh2[wave][lane] = q2;
         }
