@@ -137,9 +137,10 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
         return FGS_EINVAL;
     }
     L.seg_len = d->seg_len ? d->seg_len : ((B * N <= 200000 && !row_split) ? 64 : FGS_SEG);
-    p->direct_binning = layers == 1 && p->tiles <= FGS_BIN_MAX_TILES && d->bin_mode != 2;
+    p->direct_binning = layers == 1 && p->tiles <= FGS_BIN_MAX_TILES && tx + ty <= FGS_MASK_MAX_LINES && d->bin_mode != 2;
     if (d->bin_mode == 1 && !p->direct_binning) {
-        fgs_set_error("bin_mode=1 (direct binning) needs a single layer and <= %d tiles per image", FGS_BIN_MAX_TILES);
+        fgs_set_error("bin_mode=1 (direct binning) needs a single layer, <= %d tiles and <= %d tile columns + rows per image",
+                      FGS_BIN_MAX_TILES, FGS_MASK_MAX_LINES);
         return FGS_EINVAL;
     }
     L.reserved = 0;
@@ -157,9 +158,12 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     L.tiles_x = tx; L.tiles_y = ty;
 
     size_t nsort = dcap > B * N ? dcap : B * N;
-    // the direct binning keeps its [B][tiles][ceil(N / FGS_BIN_G)] count matrix in the first sort buffer
-    const size_t bin_words = B * (size_t)layers * p->tiles * ((N + FGS_BIN_G - 1) / FGS_BIN_G);
+    // the direct (mask) binning keeps the list lengths [B * tiles] in the second sort buffer and its
+    // [B][tile columns + rows][rank words] 64-bit masks in the first
+    const size_t bin_words = B * (size_t)layers * p->tiles;
     if (bin_words > nsort) nsort = bin_words;
+    const size_t mask_words = p->direct_binning ? B * (size_t)(tx + ty) * fgs_mask_words((uint32_t)N) * 2 : 0;
+    if (mask_words > nsort) nsort = mask_words;
     // block sums of the duplicate-offset scan: per image and block of FGS_BIN_G depth ranks (direct binning) or per
     // 256 flat elements (radix path) -- whichever is more
     const size_t nblk = B * ((N + FGS_BIN_G - 1) / FGS_BIN_G) + (B * N + 255) / 256 + 1;
@@ -175,6 +179,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     p->s_bsum = o; o = align256(o + nblk * 4);
     // gradient rows: one per duplicate; four (one per sub-tile wave) on the phase path
     p->s_grows = o; o = align256(o + dcap * FGS_GROW_FLOATS * 4 * (d->use_phase ? 4 : 1));
+    p->s_rsum = o; o = align256(o + B * N * 12 * 4);
     p->s_total = o;
     return FGS_OK;
 }
@@ -273,7 +278,8 @@ int fgs_backward(const FgsDims *dims, const float *cameras, const float *pos, co
     fgs_stage_begin(ST_PROJECT_BWD, st);
     if ((rc = fgs_launch_project_bwd(p, cameras, pos, scale, quat, sv,
                                      reinterpret_cast<const float *>(sc + p.s_grows), g_pos, g_scale, g_quat,
-                                     g_color, g_opacity, p.d.use_phase ? g_phase : nullptr, st)))
+                                     g_color, g_opacity, p.d.use_phase ? g_phase : nullptr, st,
+                                     reinterpret_cast<float *>(sc + p.s_rsum))))
         return rc;
     fgs_stage_end(ST_PROJECT_BWD, st);
     return FGS_OK;

@@ -122,24 +122,6 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Direct binning (single layer, <= BIN_MAX_TILES tiles per image): a counting sort straight from the bboxes, in
-// place of "emit (tile key, id) pairs, then two stable radix passes over them".
-//   k_bin_count    one block per BIN_G consecutive depth ranks of one image: per-tile counts in LDS
-//                  -> cnt[image][block][tile]; also the block's number of duplicates -> bsum;
-//   k_bin_scan     one thread per (image, tile): exclusive scan of its column over the blocks (in place), column
-//                  total = list length; its last block scans bsum (duplicate offsets, total D -> counters);
-//   k_tile_pre/post turn the lengths into [start, end) ranges (and launch order, depth segments);
-//   k_bin_scatter  one wave per block of depth ranks walks its Gaussians IN ORDER and drops each id at
-//                  start[tile] + cnt[image][block][tile] + (ids this block already put into the tile); also writes
-//                  dup_off[g] = first duplicate slot of Gaussian g (emission order: image, depth rank, tile row, tile
-//                  column -- the gradient-row addressing of the backward).
-// Every list comes out in depth order, exactly as the stable sort produced it, with one scattered 4-byte store
-// per duplicate instead of four (two passes x key + payload) and no key traffic at all
-// (emit 0.052 + sort 0.148 + ranges 0.012 ms -> offsets/count/scan 0.030 + scatter 0.080 ms at config 3).
-constexpr uint32_t BIN_G = FGS_BIN_G;    // depth ranks per binning block
-constexpr uint32_t BIN_MAX_TILES = FGS_BIN_MAX_TILES; // LDS counters per block (16 KB)
-
 struct TileRect { uint32_t tx0, ty0, w, cnt; };
 __device__ __forceinline__ TileRect tile_rect(const float *__restrict__ rec, uint32_t gid, uint32_t cnt) {
     TileRect r = {0, 0, 1, cnt};
@@ -153,51 +135,108 @@ __device__ __forceinline__ TileRect tile_rect(const float *__restrict__ rec, uin
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_bin_count(uint32_t N, uint32_t tiles, uint32_t tiles_x, uint32_t bpi,
-                                                   const uint32_t *__restrict__ order,
-                                                   const uint32_t *__restrict__ tile_count,
-                                                   const float *__restrict__ rec, uint32_t *__restrict__ cnt,
-                                                   uint32_t *__restrict__ bsum) {
-    __shared__ uint32_t hist[BIN_MAX_TILES];
-    __shared__ uint32_t btot;
+// ---------------------------------------------------------------------------------------------------------
+// Direct binning = MASK BINNING (single layer, <= FGS_BIN_MAX_TILES tiles, <= FGS_MASK_MAX_LINES tile columns + rows per
+// image), in place of "emit (tile key, id) pairs, then stable radix passes over them".  (Round 1's counting sort --
+// per-block tile counters in LDS, a column scan over the blocks, and a scatter whose waves walked their Gaussians one
+// after the other -- took 97 us at config 3, 54 of them in the serial walk; this one 81.)
+// A tile's list is the set of depth ranks whose tile rectangle [tx0, tx1] x [ty0, ty1] contains the tile:
+//     list(x, y) = { r : x in [tx0_r, tx1_r] }  AND  { r : y in [ty0_r, ty1_r] }
+// i.e. the bit-and of a per-tile-COLUMN and a per-tile-ROW bit mask over the depth ranks.  So:
+//   k_mask_build  one block per 256 consecutive depth ranks of one image: 64-lane ballots give, for every tile
+//                 column and row, the 64-bit word of each of its four waves -> masks[image][line][rank word]
+//                 (line = column x, or tiles_x + row y); also the block's duplicate count -> bsum;
+//   k_mask_count  one wave per (image, tile): popcount of (column mask & row mask) = list length; its last block
+//                 scans bsum (duplicate offsets, total D -> counters);
+//   k_tile_pre/post ranges, depth segments, launch order (unchanged);
+//   k_mask_emit   one wave per (image, tile): lanes take consecutive rank words, a wave scan of their popcounts
+//                 gives every lane its run of list slots; the set bits (depth ranks, ascending) are parked in LDS
+//                 and the wave then turns them into ids (order[rank]) and stores the list with the lanes side by side
+//                 -- coalesced stores, independent gathers; extra blocks write dup_off.
+// No walk over Gaussians is serial any more (the scatter's was: 54 of the 97 us list building at config 3), nothing
+// depends on the tile count fitting in LDS, and lists come out in depth order by construction.
+constexpr uint32_t MB_RANKS = FGS_BIN_G; // depth ranks per k_mask_build block (four rank words)
+static_assert(MB_RANKS == 256, "k_mask_build: one 256-thread block = four 64-bit rank words per line");
+constexpr uint32_t TO_TILES = 1024;     // tiles per block of the tile-table kernels (k_tile_pre / k_tile_post below)
+__device__ __forceinline__ uint32_t length_bucket(uint32_t len);
+constexpr uint32_t MB_MAX_LINES = FGS_MASK_MAX_LINES;  // tile columns + rows the build kernel keeps in LDS
+
+__global__ __launch_bounds__(256) void k_mask_build(uint32_t N, uint32_t tiles_x, uint32_t tiles_y, uint32_t bpi,
+                                                    uint32_t w64p, const uint32_t *__restrict__ order,
+                                                    const uint32_t *__restrict__ tile_count,
+                                                    const float *__restrict__ rec,
+                                                    unsigned long long *__restrict__ masks,
+                                                    uint32_t *__restrict__ bsum) {
+    __shared__ unsigned long long sm[MB_MAX_LINES][4];
+    __shared__ uint32_t wtot[4];
     const uint32_t b = blockIdx.x / bpi, blk = blockIdx.x - b * bpi;
-    for (uint32_t t = threadIdx.x; t < tiles; t += 256) hist[t] = 0;
-    if (threadIdx.x == 0) btot = 0;
-    __syncthreads();
-    const uint32_t r = blk * BIN_G + threadIdx.x;
-    uint32_t mine = 0;
-    if (threadIdx.x < BIN_G && r < N) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t r = blk * MB_RANKS + threadIdx.x;
+    uint32_t cnt = 0, tx0 = 0xFFFFu, tx1 = 0, ty0 = 0xFFFFu, ty1 = 0;
+    if (r < N) {
         const uint32_t gid = b * N + order[b * N + r];
         const TileRect q = tile_rect(rec, gid, tile_count[gid]);
-        mine = q.cnt;
-        const uint32_t h = q.cnt / q.w;
-        for (uint32_t y = 0; y < h; ++y)
-            for (uint32_t x = 0; x < q.w; ++x) atomicAdd(&hist[(q.ty0 + y) * tiles_x + q.tx0 + x], 1u);
+        cnt = q.cnt;
+        if (cnt) { tx0 = q.tx0; tx1 = q.tx0 + q.w - 1u; ty0 = q.ty0; ty1 = q.ty0 + cnt / q.w - 1u; }
     }
-    // duplicates of this block of depth ranks: the block sums of the duplicate-offset scan (k_bin_scan's last block
-    // scans them, k_bin_scatter adds the ranks' own prefix)
+    for (uint32_t x = 0; x < tiles_x; ++x) {
+        const unsigned long long m = __ballot(x >= tx0 && x <= tx1);
+        if (lane == 0) sm[x][wave] = m;
+    }
+    for (uint32_t y = 0; y < tiles_y; ++y) {
+        const unsigned long long m = __ballot(y >= ty0 && y <= ty1);
+        if (lane == 0) sm[tiles_x + y][wave] = m;
+    }
+    uint32_t mine = cnt;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
-    if ((threadIdx.x & 63u) == 0) atomicAdd(&btot, mine);
+    if (lane == 0) wtot[wave] = mine;
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < tiles; t += 256) cnt[((size_t)b * bpi + blk) * tiles + t] = hist[t];
-    if (threadIdx.x == 0) bsum[blockIdx.x] = btot;
+    if (threadIdx.x == 0) bsum[blockIdx.x] = (wtot[0] + wtot[1]) + (wtot[2] + wtot[3]);
+    const uint32_t lines = tiles_x + tiles_y;
+    for (uint32_t l = threadIdx.x; l < lines; l += 256) {
+        ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(masks + ((size_t)b * lines + l) * w64p + blk * 4u);
+        dst[0] = make_ulonglong2(sm[l][0], sm[l][1]);
+        dst[1] = make_ulonglong2(sm[l][2], sm[l][3]);
+        if (blk == bpi - 1)  // padding words of the line (w64p is a multiple of 8 words)
+            for (uint32_t w = bpi * 4u; w < w64p; ++w) masks[((size_t)b * lines + l) * w64p + w] = 0ull;
+    }
 }
 
-__global__ __launch_bounds__(256) void k_bin_scan(uint32_t B, uint32_t tiles, uint32_t bpi, uint32_t *__restrict__ cnt,
-                                                  uint32_t *__restrict__ lens, uint32_t *__restrict__ bsum,
-                                                  uint32_t *__restrict__ counters, uint32_t dcap) {
+// WPL consecutive 64-bit words of (column mask & row mask) for this lane
+template <int WPL>
+__device__ __forceinline__ void mask_words(const unsigned long long *__restrict__ col,
+                                           const unsigned long long *__restrict__ row, uint32_t w0,
+                                           unsigned long long (&m)[WPL]) {
+    if constexpr (WPL == 1) {
+        m[0] = col[w0] & row[w0];
+    } else {
+        const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(col + w0);
+        const ulonglong2 *r2 = reinterpret_cast<const ulonglong2 *>(row + w0);
+        ulonglong2 cv[WPL / 2], rv[WPL / 2];
+#pragma unroll
+        for (int k = 0; k < WPL / 2; ++k) { cv[k] = c2[k]; rv[k] = r2[k]; }
+#pragma unroll
+        for (int k = 0; k < WPL / 2; ++k) { m[2 * k] = cv[k].x & rv[k].x; m[2 * k + 1] = cv[k].y & rv[k].y; }
+    }
+}
+
+template <int WPL>
+__global__ __launch_bounds__(256) void k_mask_count(uint32_t B, uint32_t tiles, uint32_t tiles_x, uint32_t lines,
+                                                    uint32_t w64p, uint32_t nrb,
+                                                    const unsigned long long *__restrict__ masks,
+                                                    uint32_t *__restrict__ lens, uint32_t *__restrict__ bsum,
+                                                    uint32_t *__restrict__ counters, uint32_t dcap) {
     if (blockIdx.x == gridDim.x - 1) {
-        // last block: in-place exclusive scan of the B * bpi block sums of k_bin_count (duplicate offsets in depth
-        // order, image-major), total -> counters[0] (clamped), overflow flag -> counters[1]
-        const uint32_t n = B * bpi;
+        // last block: in-place exclusive scan of the block sums of k_mask_build (duplicate offsets in depth order,
+        // image-major), total -> counters[0] (clamped), overflow flag -> counters[1]
         unsigned long long carry = 0;
-        for (uint32_t base = 0; base < n; base += 256) {
+        for (uint32_t base = 0; base < nrb; base += 256) {
             const uint32_t i = base + threadIdx.x;
-            const uint32_t v = i < n ? bsum[i] : 0u;
+            const uint32_t v = i < nrb ? bsum[i] : 0u;
             uint32_t tot;
             const uint32_t ex = block_exclusive_scan_256(v, &tot);
-            if (i < n) bsum[i] = (uint32_t)carry + ex;
+            if (i < nrb) bsum[i] = (uint32_t)carry + ex;
             carry += tot;
             __syncthreads();
         }
@@ -207,140 +246,113 @@ __global__ __launch_bounds__(256) void k_bin_scan(uint32_t B, uint32_t tiles, ui
         }
         return;
     }
-    // thread = one (image, tile) column of cnt[image][block][tile]; walks the blocks serially (every load of a
-    // wave is one contiguous run of tiles), exclusive scan in place, column total = list length
-    const uint32_t col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= B * tiles) return;
-    const uint32_t b = col / tiles, t = col - b * tiles;
-    uint32_t *p = cnt + (size_t)b * bpi * tiles + t;
-    uint32_t run = 0;
-    for (uint32_t k0 = 0; k0 < bpi; k0 += 16) {  // 16 independent loads in flight, then the serial adds
-        uint32_t v[16];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= B * tiles) return;
+    const uint32_t b = tile / tiles, t = tile - b * tiles, y = t / tiles_x, x = t - y * tiles_x;
+    const unsigned long long *col = masks + ((size_t)b * lines + x) * w64p;
+    const unsigned long long *row = masks + ((size_t)b * lines + tiles_x + y) * w64p;
+    uint32_t c = 0;
+    for (uint32_t w0 = lane * WPL; w0 < w64p; w0 += 64u * WPL) {
+        unsigned long long m[WPL];
+        mask_words<WPL>(col, row, w0, m);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (k0 + i < bpi) ? p[(size_t)(k0 + i) * tiles] : 0u;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (k0 + i < bpi) p[(size_t)(k0 + i) * tiles] = run;
-            run += v[i];
-        }
+        for (int k = 0; k < WPL; ++k) c += (uint32_t)__popcll(m[k]);
     }
-    lens[col] = run;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if (lane == 0) lens[tile] = c;
+    // (Folding k_tile_pre in here -- two global atomics per tile into the per-1024-tile sums and bucket histograms --
+    // made this 8 us kernel take 102 us at config 3: same-address global atomics serialise at ~50 ns each.)
 }
 
-// NW waves per block of BIN_G depth ranks (NW = 8 when the slot tables of eight waves fit in LDS, i.e. <= 1024 tiles;
-// else one wave): wave w owns ranks [w, w+1) * BIN_G / NW of the block.  The walk over a wave's Gaussians is inherently serial
-// (each one bumps the counters of its tiles), so what matters is how many such walks run side by side: the four
-// waves first count their own duplicates per tile, turn the counts into per-wave start slots (in rank order), and
-// then walk independently.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_bin_scatter(uint32_t N, uint32_t tiles, uint32_t tiles_x, uint32_t bpi,
-                                                         uint32_t dcap, const uint32_t *__restrict__ order,
-                                                         const uint32_t *__restrict__ tile_count,
-                                                         const float *__restrict__ rec,
-                                                         const uint32_t *__restrict__ cnt,
-                                                         const uint32_t *__restrict__ ranges,
-                                                         uint32_t *__restrict__ dup_ids,
-                                                         const uint32_t *__restrict__ bsum,
-                                                         uint32_t *__restrict__ dup_off) {
-    constexpr uint32_t T_MAX = NW == 1 ? BIN_MAX_TILES : 1024;  // NW > 1: frames of <= 1024 tiles
-    constexpr uint32_t WG = BIN_G / NW;  // ranks per wave
-    __shared__ uint32_t run[NW][T_MAX];  // next free slot of every tile list, per wave
-    // consecutive rank blocks append to neighbouring list slots: keep them on one XCD so that the 4-byte entries
-    // merge into full lines in its L2 (the write side was 6x the list bytes without the remap)
-    const uint32_t lb = fgs_xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t b = lb / bpi, blk = lb - b * bpi;
-    // (a) duplicate offsets of this block's depth ranks: dup_off[g] = first gradient-row / emission slot of
-    //     Gaussian g = scanned block sum + prefix of the tile counts inside the block (rank order)
-    for (uint32_t r0 = 0; r0 < BIN_G; r0 += 64 * NW) {
-        __shared__ uint32_t carry_sh;
-        if (threadIdx.x == 0 && r0 == 0) carry_sh = bsum[lb];
-        const uint32_t r = blk * BIN_G + r0 + threadIdx.x;
-        uint32_t g = 0, c = 0;
-        if (r0 + threadIdx.x < BIN_G && r < N) { g = b * N + order[b * N + r]; c = tile_count[g]; }
-        // inclusive scan over the block's 64 * NW threads (wave scans + serial sum of the wave totals)
-        __shared__ uint32_t wtot[NW];
-        uint32_t x = c;
+constexpr uint32_t ME_CAP = 2048;       // list entries a wave parks in LDS per flush (k_mask_emit)
+
+// (Staging `order` in LDS per block of eight tiles, to turn the sparse ids gather into coalesced loads, was tried: no
+// faster at config 3 -- 43.7 us -- and slower on long lists, 150 vs 110 us on the decoder-like scene: the per-lane
+// 4-byte stores it needs cost more than the gather it removes.)
+template <int WPL>
+__global__ __launch_bounds__(256) void k_mask_emit(uint32_t B, uint32_t N, uint32_t tiles, uint32_t tiles_x,
+                                                   uint32_t lines, uint32_t w64p, uint32_t nrb, uint32_t bpi,
+                                                   uint32_t dcap, const unsigned long long *__restrict__ masks,
+                                                   const uint32_t *__restrict__ order,
+                                                   const uint32_t *__restrict__ tile_count,
+                                                   const uint32_t *__restrict__ ranges,
+                                                   const uint32_t *__restrict__ bsum,
+                                                   uint32_t *__restrict__ dup_ids, uint32_t *__restrict__ dup_off) {
+    __shared__ uint32_t park[4][ME_CAP];
+    if (blockIdx.x < nrb) {
+        // duplicate offsets of one block of depth ranks: dup_off[g] = first gradient-row / emission slot of Gaussian
+        // g = scanned block sum + prefix of the tile counts inside the block (rank order)
+        const uint32_t b = blockIdx.x / bpi, blk = blockIdx.x - b * bpi;
+        const uint32_t r = blk * MB_RANKS + threadIdx.x;
+        uint32_t g = 0, c = 0, tot;
+        if (r < N) { g = b * N + order[b * N + r]; c = tile_count[g]; }
+        const uint32_t ex = block_exclusive_scan_256(c, &tot);
+        if (r < N) dup_off[g] = bsum[blockIdx.x] + ex;
+        return;
+    }
+    // consecutive tiles' lists are adjacent in dup_ids: an XCD gets a contiguous run of tiles (whole images at B = 8)
+    const uint32_t ntb = gridDim.x - nrb;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile = fgs_xcd_remap(blockIdx.x - nrb, ntb) * 4u + wave;
+    if (tile >= B * tiles) return;
+    const uint32_t b = tile / tiles, t = tile - b * tiles, y = t / tiles_x, x = t - y * tiles_x;
+    const unsigned long long *col = masks + ((size_t)b * lines + x) * w64p;
+    const unsigned long long *row = masks + ((size_t)b * lines + tiles_x + y) * w64p;
+    const uint32_t *ord = order + (size_t)b * N;
+    uint32_t *pk = park[wave];
+    uint32_t base = ranges[2 * tile];  // next list slot
+    for (uint32_t c0 = 0; c0 < w64p; c0 += 64u * WPL) {
+        const uint32_t w0 = c0 + lane * WPL;
+        unsigned long long m[WPL];
+#pragma unroll
+        for (int k = 0; k < WPL; ++k) m[k] = 0ull;
+        if (w0 < w64p) mask_words<WPL>(col, row, w0, m);
+        uint32_t cl = 0;
+#pragma unroll
+        for (int k = 0; k < WPL; ++k) cl += (uint32_t)__popcll(m[k]);
+        uint32_t inc = cl;  // inclusive wave scan of the lanes' entry counts
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o, 64);
-            if ((int)(threadIdx.x & 63u) >= o) x += y;
+            const uint32_t v = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += v;
         }
-        __syncthreads();
-        if ((threadIdx.x & 63u) == 63u) wtot[threadIdx.x >> 6] = x;
-        __syncthreads();
-        uint32_t pre = carry_sh, all = 0;
+        const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
+        const uint32_t ex = inc - cl;
+        // flush windows of ME_CAP entries (one window unless a tile collects more than ME_CAP of these ranks)
+        for (uint32_t win = 0; win < total; win += ME_CAP) {
+            // (1) park the ranks of this window's entries in list order
+            uint32_t e = ex;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            pre += (w < (int)(threadIdx.x >> 6)) ? wtot[w] : 0u;
-            all += wtot[w];
-        }
-        if (r0 + threadIdx.x < BIN_G && r < N) dup_off[g] = pre + x - c;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_sh += all;
-    }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
-    // this lane's Gaussian of each 64-rank batch of the wave (WG / 64 batches)
-    constexpr int NB = WG >= 64 ? WG / 64 : 1;
-    static_assert(WG % 64 == 0 || WG == 32, "whole 64-rank batches per wave, or half a wave of ranks");
-    uint32_t gid[NB];
-    TileRect q[NB];
-    uint32_t inv[NB];  // ceil(2^18 / w): (t * inv) >> 18 is t / w or one more for t < 2^12 (fixed up below)
+            for (int k = 0; k < WPL; ++k) {
+                unsigned long long mm = m[k];
+                const uint32_t rank0 = (w0 + k) * 64u;
+                while (mm) {
+                    const uint32_t bit = (uint32_t)__ffsll((long long)mm) - 1u;
+                    mm &= mm - 1ull;
+                    if (e - win < ME_CAP) pk[e - win] = rank0 + bit;  // unsigned: e < win wraps past ME_CAP
+                    ++e;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // (2) ranks -> ids, lanes side by side
+            const uint32_t n = min(ME_CAP, total - win);
+            for (uint32_t i = lane; i < n; i += 256) {
+                uint32_t rk[4], id[4];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const uint32_t r = blk * BIN_G + wave * WG + i * 64 + lane;
-        gid[i] = 0; q[i] = TileRect{0, 0, 1, 0};
-        if (i * 64 + lane < WG && r < N) {
-            gid[i] = b * N + order[b * N + r];
-            q[i] = tile_rect(rec, gid[i], tile_count[gid[i]]);
-        }
-        inv[i] = ((1u << 18) + q[i].w - 1u) / q[i].w;
-    }
-    if (NW > 1) {
-        for (uint32_t t = threadIdx.x; t < tiles; t += 64 * NW)
+                for (int u = 0; u < 4; ++u) rk[u] = (i + 64u * u < n) ? pk[i + 64u * u] : 0u;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) run[w][t] = 0;
-        __syncthreads();
+                for (int u = 0; u < 4; ++u) id[u] = ord[rk[u]];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {  // this wave's duplicates per tile
-            const uint32_t h = q[i].cnt / q[i].w;
-            for (uint32_t y = 0; y < h; ++y)
-                for (uint32_t x = 0; x < q[i].w; ++x) atomicAdd(&run[wave][(q[i].ty0 + y) * tiles_x + q[i].tx0 + x], 1u);
-        }
-        __syncthreads();
-    }
-    for (uint32_t t = threadIdx.x; t < tiles; t += 64 * NW) {
-        uint32_t base = ranges[2 * ((size_t)b * tiles + t)] + cnt[((size_t)b * bpi + blk) * tiles + t];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {  // counts -> start slots, waves in rank order
-            const uint32_t c = NW > 1 ? run[w][t] : 0u;
-            run[w][t] = base;
-            base += c;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        unsigned long long m = __ballot(q[i].cnt != 0);
-        while (m) {  // the wave's Gaussians one after the other, in depth order; lanes = tiles of the current one
-            const int g = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const uint32_t cg = __builtin_amdgcn_readlane(q[i].cnt, g), wg = __builtin_amdgcn_readlane(q[i].w, g);
-            const uint32_t txg = __builtin_amdgcn_readlane(q[i].tx0, g), tyg = __builtin_amdgcn_readlane(q[i].ty0, g);
-            const uint32_t idg = __builtin_amdgcn_readlane(gid[i], g);
-            const uint32_t ivg = __builtin_amdgcn_readlane(inv[i], g);
-            for (uint32_t t = lane; t < cg; t += 64) {  // one trip for up to 64 tiles
-                // t / wg: the reciprocal is rounded up, so the estimate is exact for wg <= 64 tile columns and at
-                // most one too high beyond (t < 4096 <= 2^18 / 64); one compare makes it exact for any frame
-                uint32_t y = __umul24(t, ivg) >> 18;
-                y -= (y * wg > t) ? 1u : 0u;
-                const uint32_t tile = (tyg + y) * tiles_x + txg + (t - y * wg);
-                const uint32_t pos = run[wave][tile];  // tiles of one Gaussian are distinct: plain read-modify-write
-                run[wave][tile] = pos + 1;
-                if (pos < dcap) dup_ids[pos] = idg;
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t pos = base + win + i + 64u * u;
+                    if (i + 64u * u < n && pos < dcap) dup_ids[pos] = b * N + id[u];
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
+        base += total;
     }
 }
 
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t *__restrict_
 // k_tile_pre: per block of TO_TILES tiles, the sums of (length, units) and the bucket histogram.
 // k_tile_post: every block adds up the sums / histograms of the blocks before it (a few hundred values), scans its
 // own tiles and writes their rows of all tables.
-constexpr uint32_t TO_TILES = 1024;  // tiles per block (256 threads x 4 consecutive tiles)
+// (TO_TILES: 256 threads x 4 consecutive tiles)
 
 __device__ __forceinline__ uint32_t length_bucket(uint32_t len) {
     // 63 - quarter-octave of the length: longer lists get smaller bucket numbers (4 buckets per power of two)
@@ -509,6 +521,8 @@ static int launch_tile_tables(uint32_t ntiles, uint32_t *ranges, const uint32_t 
     const uint32_t nblk = (ntiles + TO_TILES - 1) / TO_TILES;
     unsigned long long *pre64 = reinterpret_cast<unsigned long long *>(scratch_words);
     uint32_t *bhist = scratch_words + 2 * (size_t)nblk;
+    // (k_tile_post walking all lengths itself instead of this launch: 21.6 us against 4.8 + 9.2 at config 3 -- the
+    // bucket histogram's same-address LDS atomics)
     hipLaunchKernelGGL(k_tile_pre, dim3(nblk), dim3(256), 0, st, ntiles, ranges, lens, seg_len, pre64, bhist);
     FGS_LAUNCH_CHECK("k_tile_pre");
     hipLaunchKernelGGL(k_tile_post, dim3(nblk), dim3(256), 0, st, ntiles, ranges, lens, tile_order, seg_off, seg_tile,
@@ -566,18 +580,24 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     uint32_t *seg_off = p.L.seg_capacity ? reinterpret_cast<uint32_t *>(saved + p.L.seg_off) : nullptr;
     uint32_t *seg_tile = p.L.seg_capacity ? reinterpret_cast<uint32_t *>(saved + p.L.seg_tile) : nullptr;
     if (p.direct_binning) {
-        // direct binning: counting sort straight from the bboxes (see k_bin_count): 4 launches
-        const uint32_t bpi = (N + BIN_G - 1) / BIN_G;
-        uint32_t *cnt = keys0;               // [B][tiles][bpi], fits: keys0 holds >= Dcap words
-        uint32_t *lens = keys1;              // [B * tiles]
+        // mask binning (see k_mask_build): 5 launches, none of them serial over Gaussians
+        const uint32_t bpi = (N + MB_RANKS - 1) / MB_RANKS, nrb = B * bpi;
+        const uint32_t tiles_x = (uint32_t)p.L.tiles_x, tiles_y = (uint32_t)p.L.tiles_y, lines = tiles_x + tiles_y;
+        const uint32_t w64p = fgs_mask_words(N);
+        unsigned long long *masks = reinterpret_cast<unsigned long long *>(keys0);  // [B][lines][w64p]
+        uint32_t *lens = keys1;                                                     // [B * tiles]
         uint32_t *dup_off = reinterpret_cast<uint32_t *>(saved + p.L.dup_off);
+        const uint32_t ntb = (ntiles_all + 3) / 4;  // four tiles (waves) per block
+        const int wpl = w64p <= 64 ? 1 : (w64p <= 128 ? 2 : (w64p <= 256 ? 4 : 8));
         fgs_stage_begin(ST_DUP_EMIT, st);
-        hipLaunchKernelGGL(k_bin_count, dim3(B * bpi), dim3(256), 0, st, N, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
-                           bpi, order, tile_count, rec, cnt, bsum);
-        FGS_LAUNCH_CHECK("k_bin_count");
-        hipLaunchKernelGGL(k_bin_scan, dim3((ntiles_all + 255) / 256 + 1), dim3(256), 0, st, B, (uint32_t)p.tiles, bpi,
-                           cnt, lens, bsum, counters, dcap);
-        FGS_LAUNCH_CHECK("k_bin_scan");
+        hipLaunchKernelGGL(k_mask_build, dim3(nrb), dim3(256), 0, st, N, tiles_x, tiles_y, bpi, w64p, order,
+                           tile_count, rec, masks, bsum);
+        FGS_LAUNCH_CHECK("k_mask_build");
+#define FGS_MASK_COUNT(W) hipLaunchKernelGGL(k_mask_count<W>, dim3(ntb + 1), dim3(256), 0, st, B, (uint32_t)p.tiles, \
+                                             tiles_x, lines, w64p, nrb, masks, lens, bsum, counters, dcap)
+        if (wpl == 1) FGS_MASK_COUNT(1); else if (wpl == 2) FGS_MASK_COUNT(2); else if (wpl == 4) FGS_MASK_COUNT(4); else FGS_MASK_COUNT(8);
+#undef FGS_MASK_COUNT
+        FGS_LAUNCH_CHECK("k_mask_count");
         fgs_stage_end(ST_DUP_EMIT, st);
         fgs_stage_begin(ST_TILE_RANGES, st);
         if ((rc = launch_tile_tables(ntiles_all, ranges, lens, tile_order, seg_off, seg_tile, counters,
@@ -585,17 +605,12 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
             return rc;
         fgs_stage_end(ST_TILE_RANGES, st);
         fgs_stage_begin(ST_TILE_SORT, st);
-        // eight waves x 32 depth ranks per block when the per-wave slot tables fit (<= 1024 tiles): the walk over a
-        // wave's Gaussians is serial, so shorter walks, more of them (four waves x 64: 0.061 -> 0.054 ms at config 3)
-        if ((uint32_t)p.tiles <= 1024)
-            hipLaunchKernelGGL(k_bin_scatter<8>, dim3(B * bpi), dim3(512), 0, st, N, (uint32_t)p.tiles,
-                               (uint32_t)p.L.tiles_x, bpi, dcap, order, tile_count, rec, cnt, ranges, dup_ids, bsum,
-                               dup_off);
-        else
-            hipLaunchKernelGGL(k_bin_scatter<1>, dim3(B * bpi), dim3(64), 0, st, N, (uint32_t)p.tiles,
-                               (uint32_t)p.L.tiles_x, bpi, dcap, order, tile_count, rec, cnt, ranges, dup_ids, bsum,
-                               dup_off);
-        FGS_LAUNCH_CHECK("k_bin_scatter");
+#define FGS_MASK_EMIT(W) hipLaunchKernelGGL(k_mask_emit<W>, dim3(nrb + ntb), dim3(256), 0, st, B, N, (uint32_t)p.tiles, \
+                                            tiles_x, lines, w64p, nrb, bpi, dcap, masks, order, tile_count, ranges, bsum, \
+                                            dup_ids, dup_off)
+        if (wpl == 1) FGS_MASK_EMIT(1); else if (wpl == 2) FGS_MASK_EMIT(2); else if (wpl == 4) FGS_MASK_EMIT(4); else FGS_MASK_EMIT(8);
+#undef FGS_MASK_EMIT
+        FGS_LAUNCH_CHECK("k_mask_emit");
         fgs_stage_end(ST_TILE_SORT, st);
         return FGS_OK;
     }

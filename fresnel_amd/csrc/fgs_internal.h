@@ -36,6 +36,7 @@ struct FgsPlan {
     size_t s_hist;            // uint32 radix histograms
     size_t s_bsum;            // uint32 block sums for the duplicate-offset scan
     size_t s_grows;           // float [Dcap][12]: per-duplicate gradient rows (composite bwd -> reduce)
+    size_t s_rsum;            // float [B*N][12]: per-Gaussian totals of the blend path's rows (k_row_sum -> k_project_bwd)
 };
 
 // `segment_ckpt`: reserve the per-segment forward checkpoints of the tile-based compositing path (the splat
@@ -55,7 +56,10 @@ void fgs_set_error(const char *fmt, ...);
 enum FgsStage { ST_PROJECT = 0, ST_DEPTH_SORT, ST_DUP_EMIT, ST_TILE_SORT, ST_TILE_RANGES, ST_COMPOSITE_FWD,
                 ST_COMPOSITE_BWD, ST_PROJECT_BWD, ST_SPLAT_FWD, ST_FIELD_FWD, ST_FIELD_BWD, ST_SPLAT_BWD };
 static_assert(ST_SPLAT_BWD + 1 == FGS_NUM_STAGES, "stage list and FGS_NUM_STAGES disagree");
-#define FGS_BIN_MAX_TILES 4096  /* direct binning: LDS counters per block (16 KB) */
+#define FGS_BIN_MAX_TILES 4096  /* direct binning: tiles per image */
+#define FGS_MASK_MAX_LINES 512  /* mask binning: tile columns + tile rows per image (LDS of k_mask_build: 16 KB) */
+/* 64-bit rank words per mask line of the mask binning (fgs_bin.hip), padded to a multiple of 8 */
+static inline uint32_t fgs_mask_words(uint32_t n) { return (((n + 63u) / 64u) + 7u) & ~7u; }
 void fgs_stage_begin(int stage, hipStream_t st);  // no-ops unless fgs_stage_timing_enable(1)
 void fgs_stage_end(int stage, hipStream_t st);
 
@@ -68,7 +72,7 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
 int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                            const float *quat, const char *saved, const float *grad_rows, float *g_pos,
                            float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
-                           hipStream_t st);
+                           hipStream_t st, float *row_sums = nullptr /* scratch [B*N][12]: blend path row totals */);
 
 int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                                const float *quat, const float *color, const float *phase, int phase_channels,

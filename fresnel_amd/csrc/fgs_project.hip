@@ -157,6 +157,65 @@ __global__ __launch_bounds__(256) void k_project(
 }
 
 // Gradient-row reduction + projection backward (autograd of DR:98-195 + DR:578-579).
+// Blend path, first half of the projection backward: sum every Gaussian's contiguous 40-byte gradient rows (moments
+// of dL/dG about the mean, colour and depth sums; k_composite_bwd) in a fixed order -- FOUR lanes per Gaussian in
+// DEPTH-RANK order (rows are laid out in emission order, so neighbouring lanes read neighbouring rows), lane `sub`
+// takes rows sub, sub + 4, ..., two rows in flight per lane; moments in double; two quad shuffles combine the partial
+// sums.  The totals get the factors of the chain through m' = K m, G = exp2(m'), alpha = G opacity (first moments x
+// ln2 opacity, second moments x K ln2 opacity) and go to sums[input index][12].  Streaming kernel: ~40 VGPRs, full occupancy.
+__global__ __launch_bounds__(256) void k_row_sum(int32_t total, int32_t N, uint32_t dcap,
+                                                 const uint32_t *__restrict__ order,
+                                                 const uint32_t *__restrict__ dup_off,
+                                                 const uint32_t *__restrict__ tile_count,
+                                                 const float *__restrict__ grad_rows, const float *__restrict__ rec,
+                                                 float *__restrict__ sums) {
+    const int32_t tid = blockIdx.x * 256 + threadIdx.x;
+    const int32_t ri = tid >> 2;
+    const uint32_t sub = threadIdx.x & 3u;
+    const bool live = ri < total;
+    float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t idx = 0;
+    if (live) {
+        idx = ri / N * N + (int32_t)order[ri];
+        const uint32_t off = dup_off[idx];
+        uint32_t cnt = tile_count[idx];
+        if (off >= dcap) cnt = 0; else if (cnt > dcap - off) cnt = dcap - off;
+        double m[6] = {0, 0, 0, 0, 0, 0};
+        const float *base = grad_rows + (size_t)off * FGS_BLEND_ROW_FLOATS;
+        uint32_t k = sub;
+        for (; k + 4 < cnt; k += 8) {  // rows k and k + 4
+            const float2 *r = reinterpret_cast<const float2 *>(base + (size_t)k * FGS_BLEND_ROW_FLOATS);
+            const float2 *r2 = reinterpret_cast<const float2 *>(base + (size_t)(k + 4) * FGS_BLEND_ROW_FLOATS);
+            const float2 a = r[0], bq = r[1], cq = r[2], dq = r[3], eq = r[4];
+            const float2 a2 = r2[0], bq2 = r2[1], cq2 = r2[2], dq2 = r2[3], eq2 = r2[4];
+            m[0] += a.x; m[1] += a.y; m[2] += bq.x; m[3] += bq.y; m[4] += cq.x; m[5] += cq.y;
+            acc[6] += dq.x; acc[7] += dq.y; acc[8] += eq.x; acc[9] += eq.y;
+            m[0] += a2.x; m[1] += a2.y; m[2] += bq2.x; m[3] += bq2.y; m[4] += cq2.x; m[5] += cq2.y;
+            acc[6] += dq2.x; acc[7] += dq2.y; acc[8] += eq2.x; acc[9] += eq2.y;
+        }
+        if (k < cnt) {
+            const float2 *r = reinterpret_cast<const float2 *>(base + (size_t)k * FGS_BLEND_ROW_FLOATS);
+            const float2 a = r[0], bq = r[1], cq = r[2], dq = r[3], eq = r[4];
+            m[0] += a.x; m[1] += a.y; m[2] += bq.x; m[3] += bq.y; m[4] += cq.x; m[5] += cq.y;
+            acc[6] += dq.x; acc[7] += dq.y; acc[8] += eq.x; acc[9] += eq.y;
+        }
+        const double hp = 0.69314718055994530942 * (double)rec[(size_t)idx * FGS_REC_FLOATS + R_OP];
+        acc[0] = (float)(hp * m[0]); acc[1] = (float)(hp * m[1]);
+        acc[2] = (float)(-0.72134752044448170368 * hp * m[2]); acc[3] = (float)(-0.72134752044448170368 * hp * m[3]);
+        acc[4] = (float)(-0.72134752044448170368 * hp * m[4]); acc[5] = (float)m[5];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        acc[k] += __shfl_xor(acc[k], 1, 64);
+        acc[k] += __shfl_xor(acc[k], 2, 64);
+    }
+    if (!live || sub != 0) return;
+    float4 *o = reinterpret_cast<float4 *>(sums + (size_t)idx * 12);  // by input index: the adjoint kernel runs in input order
+    o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    o[2] = make_float4(acc[8], acc[9], 0.0f, 0.0f);
+}
+
 // One thread per Gaussian, walked in DEPTH-RANK order so that the rows read by neighbouring
 // lanes are neighbours in memory (rows are laid out in emission order).  Sums the Gaussian's
 // contiguous 48-byte gradient rows in a fixed order (deterministic), then chains
@@ -167,7 +226,10 @@ __global__ __launch_bounds__(256) void k_project(
 // colour and phase gradients are formed here and no gradient flows through depth (the depth
 // only selects the plane, DR:1147-1148).
 // MODE 2 (WaveFieldRenderer): ASM rows widened to 16 floats, slot 12 = dL/ddepth (amplitude-weighted depth map)
-template <int MODE>
+// PRESUM: the rows were already summed by k_row_sum (blend path): ONE thread per Gaussian reads its ten totals from
+// `grad_rows` (= the per-Gaussian sums, [input index][12] floats) -- all 64 lanes of a wave run the double-precision adjoint
+// instead of every fourth, and the streaming part no longer runs at this kernel's 3 waves per SIMD (160 VGPRs).
+template <int MODE, bool PRESUM = false>
 __global__ __launch_bounds__(256) void k_project_bwd(
     int32_t total, int32_t N, int32_t num_cameras, uint32_t dcap, const float *__restrict__ cams,
     const float *__restrict__ pos, const float *__restrict__ scale, const float *__restrict__ quat,
@@ -180,16 +242,26 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     // four lanes per Gaussian: lane `sub` sums rows sub, sub+4, ... (neighbouring lanes read
     // neighbouring 48-byte rows), then two quad shuffles combine the partial sums in a fixed order
     const int32_t tid = blockIdx.x * 256 + threadIdx.x;
-    const int32_t ri = tid >> 2;
-    const uint32_t sub = threadIdx.x & 3u;
+    const int32_t ri = PRESUM ? tid : tid >> 2;
+    const uint32_t sub = PRESUM ? 0u : threadIdx.x & 3u;
     const bool live = ri < total;
     const int32_t b = live ? ri / N : 0;
-    const int32_t idx = live ? b * N + (int32_t)order[ri] : 0;
+    // PRESUM: Gaussians in INPUT order -- every load and store of this kernel is then coalesced (k_row_sum scattered
+    // its totals to sums[input index]); in depth-rank order the ~28 scattered 4-12 byte accesses per Gaussian made
+    // the adjoint take 29 us at config 3
+    const int32_t idx = live ? (PRESUM ? ri : b * N + (int32_t)order[ri]) : 0;
     float gp[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0};
     constexpr bool ASM = MODE != 0;
     constexpr int ROWF = MODE == 2 ? 16 : FGS_GROW_FLOATS;
     float acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (live) {
+    if constexpr (PRESUM) {
+        if (live) {
+            const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)idx * 12);
+            const float4 a = r[0], bq = r[1], cq = r[2];
+            acc[0] = a.x; acc[1] = a.y; acc[2] = a.z; acc[3] = a.w; acc[4] = bq.x; acc[5] = bq.y; acc[6] = bq.z;
+            acc[7] = bq.w; acc[8] = cq.x; acc[9] = cq.y;
+        }
+    } else if (live) {
         // rows_per_dup gradient rows per duplicate (4 on the phase path: one per sub-tile wave), contiguous
         const uint32_t cnt = tile_count[idx] * rows_per_dup, off = dup_off[idx] * rows_per_dup;
         if (MODE == 0 && phase_channels) {
@@ -237,10 +309,12 @@ __global__ __launch_bounds__(256) void k_project_bwd(
             acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z; acc[11] += cq.w;
         }
     }
+    if constexpr (!PRESUM) {
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        acc[k] += __shfl_xor(acc[k], 1, 64);
-        acc[k] += __shfl_xor(acc[k], 2, 64);
+        for (int k = 0; k < 13; ++k) {
+            acc[k] += __shfl_xor(acc[k], 1, 64);
+            acc[k] += __shfl_xor(acc[k], 2, 64);
+        }
     }
     if (!live || sub != 0) return;
     const float4 s0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -289,8 +363,9 @@ __global__ __launch_bounds__(256) void k_project_bwd(
         const double yc = V[1][0] * p[0] + V[1][1] * p[1] + V[1][2] * p[2] + V[1][3];
         const double zc = V[2][0] * p[0] + V[2][1] * p[1] + V[2][2] * p[2] + V[2][3];
         const double nrm = sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
-        const double nn = nrm < 1e-12 ? 1e-12 : nrm;
-        const double w = q0[0] / nn, x = q0[1] / nn, y = q0[2] / nn, z = q0[3] / nn;
+        // (one reciprocal per denominator instead of a double division per use: 21 divisions -> 3)
+        const double inn = 1.0 / (nrm < 1e-12 ? 1e-12 : nrm);
+        const double w = q0[0] * inn, x = q0[1] * inn, y = q0[2] * inn, z = q0[3] * inn;
         const double R[3][3] = {{1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * x * z + 2 * w * y},
                                 {2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x},
                                 {2 * x * z - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y}};
@@ -308,8 +383,9 @@ __global__ __launch_bounds__(256) void k_project_bwd(
             for (int j = 0; j < 3; ++j) S[i][j] = M[i][0] * M[j][0] + M[i][1] * M[j][1] + M[i][2] * M[j][2];
         const double az = fabs(zc);
         const double sg = (double)sgnf((float)zc + 1e-8f);  // same sign convention as the fp32 forward
-        const double zs = (az < 0.01 ? 0.01 : az) * sg, z2 = zs * zs, z3 = z2 * zs;
-        const double J[2][3] = {{fx / (-zs), 0.0, fx * xc / z2}, {0.0, fy / zs, fy * yc / z2}};
+        const double zs = (az < 0.01 ? 0.01 : az) * sg;
+        const double izs = 1.0 / zs, iz2 = izs * izs, iz3 = iz2 * izs;
+        const double J[2][3] = {{-fx * izs, 0.0, fx * xc * iz2}, {0.0, fy * izs, fy * yc * iz2}};
         double T[2][3], C2[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -368,10 +444,10 @@ __global__ __launch_bounds__(256) void k_project_bwd(
             gu = kc * (2.0 * Y[0][0] * (double)g_mean[0] + cbc * (double)g_mean[1]);
             gv = kc * (cbc * (double)g_mean[0] + 2.0 * Y[1][1] * (double)g_mean[1]);
         }
-        const double gxc = GJ[0][2] * fx / z2 + gu * (-fx / zs);
-        const double gyc = GJ[1][2] * fy / z2 + gv * (fy / zs);
-        const double gzs = GJ[0][0] * fx / z2 + GJ[0][2] * (-2.0 * fx * xc / z3) + GJ[1][1] * (-fy / z2) +
-                           GJ[1][2] * (-2.0 * fy * yc / z3) + gu * (fx * xc / z2) + gv * (-fy * yc / z2);
+        const double gxc = GJ[0][2] * fx * iz2 + gu * (-fx * izs);
+        const double gyc = GJ[1][2] * fy * iz2 + gv * (fy * izs);
+        const double gzs = GJ[0][0] * fx * iz2 + GJ[0][2] * (-2.0 * fx * xc * iz3) + GJ[1][1] * (-fy * iz2) +
+                           GJ[1][2] * (-2.0 * fy * yc * iz3) + gu * (fx * xc * iz2) + gv * (-fy * yc * iz2);
         const double dzs = (az >= 0.01 ? (double)sgnf((float)zc) : 0.0) * sg;
         const double gpc[3] = {gxc, gyc, gzs * dzs - (double)g_depth};
 #pragma unroll
@@ -405,7 +481,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
         if (nrm >= 1e-12) {
             const double dot = qh[0] * gh[0] + qh[1] * gh[1] + qh[2] * gh[2] + qh[3] * gh[3];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gq[i] = (float)((gh[i] - qh[i] * dot) / nrm);
+            for (int i = 0; i < 4; ++i) gq[i] = (float)((gh[i] - qh[i] * dot) * inn);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) gq[i] = (float)(gh[i] * 1e12);
@@ -437,17 +513,30 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
 int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                            const float *quat, const char *saved, const float *grad_rows, float *g_pos,
                            float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
-                           hipStream_t st) {
+                           hipStream_t st, float *row_sums) {
     const int32_t total = p.d.batch * p.d.num_gaussians;
     const int grid = (int)(((size_t)total * 4 + 255) / 256);
+    const uint32_t *depth_key = reinterpret_cast<const uint32_t *>(saved + p.L.depth_key);
+    const uint32_t *order = reinterpret_cast<const uint32_t *>(saved + p.L.order);
+    const uint32_t *dup_off = reinterpret_cast<const uint32_t *>(saved + p.L.dup_off);
+    const uint32_t *tile_count = reinterpret_cast<const uint32_t *>(saved + p.L.tile_count);
+    const float *rec = reinterpret_cast<const float *>(saved + p.L.rec);
+    if (!p.d.use_phase && row_sums) {
+        // blend path: streaming row sums at full occupancy, then one thread per Gaussian for the adjoint
+        hipLaunchKernelGGL(k_row_sum, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
+                           (uint32_t)p.L.dup_capacity, order, dup_off, tile_count, grad_rows, rec, row_sums);
+        FGS_LAUNCH_CHECK("k_row_sum");
+        hipLaunchKernelGGL((k_project_bwd<0, true>), dim3((total + 255) / 256), dim3(256), 0, st, total,
+                           p.d.num_gaussians, p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat,
+                           depth_key, order, dup_off, tile_count, row_sums, g_pos, g_scale, g_quat, g_color, g_opacity,
+                           g_phase, nullptr, nullptr, 1, 1u, rec);
+        FGS_LAUNCH_CHECK("k_project_bwd");
+        return FGS_OK;
+    }
     hipLaunchKernelGGL(k_project_bwd<0>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
-                       p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat,
-                       reinterpret_cast<const uint32_t *>(saved + p.L.depth_key),
-                       reinterpret_cast<const uint32_t *>(saved + p.L.order),
-                       reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
-                       reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                       g_quat, g_color, g_opacity, g_phase, nullptr, nullptr, p.d.use_phase ? 0 : 1,
-                       p.d.use_phase ? 4u : 1u, reinterpret_cast<const float *>(saved + p.L.rec));  // rec: row geometry
+                       p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat, depth_key, order, dup_off,
+                       tile_count, grad_rows, g_pos, g_scale, g_quat, g_color, g_opacity, g_phase, nullptr, nullptr,
+                       p.d.use_phase ? 0 : 1, p.d.use_phase ? 4u : 1u, rec);  // rec: row geometry
     FGS_LAUNCH_CHECK("k_project_bwd");
     return FGS_OK;
 }

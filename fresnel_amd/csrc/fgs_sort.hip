@@ -82,16 +82,36 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t seg_len,
     const uint32_t *__restrict__ seg_len_dev, uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift,
     uint32_t dmask, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ dtot, uint32_t idx_mod) {
-    // dtot == nullptr: `hist` holds the RAW per-block digit counts of k_radix_upsweep and this block forms its own
-    // prefix (sum over the blocks before it, total over all of them) -- no k_radix_scan launch; used when a segment
-    // has few blocks (the depth sort: 13 launches -> 8, every one of them at the ~4.5 us launch floor).
+    // dtot == nullptr: `hist` holds the RAW per-block digit counts and this block forms its own prefix (sum over the
+    // blocks before it, total over all of them) -- no k_radix_scan launch; used when a segment has few blocks (the
+    // depth sort, every launch of which sits at the launch floor).
     // vals_in == nullptr: the payload is the element's index modulo idx_mod (first pass of the depth sort).
+    // (Accumulating the NEXT pass's per-block digit counts here, one global atomic per key at its destination block --
+    // which would make the upsweep launches of passes 1-3 unnecessary -- was tried: the atomics cost 19 us per pass,
+    // 10 -> 30 us per downsweep at config 3, against 5 us for the upsweep they replace.)
     __shared__ uint32_t run_off[256];
     __shared__ uint32_t wcnt[RS_WAVES][256];
-    __shared__ uint32_t scan_tmp[256];
+    __shared__ uint32_t wtot[RS_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const SegInfo r = block_range(seg_len, seg_len_dev, seg_capacity, seg_stride);
-    // exclusive scan of the 256 digit totals of this segment (Hillis-Steele in LDS)
+    const uint32_t seg0 = blockIdx.y * seg_stride;
+    constexpr uint32_t ROUND = RS_THREADS * 4;
+    uint32_t key[4], val[4];
+    bool valid[4];
+    // Rounds of 1024 keys: wave w owns the contiguous 256 keys [base + 256 w, +256) and walks them
+    // in four 64-key sub-rounds.  The first round's keys are requested BEFORE the prefix below is formed, so the
+    // two memory round trips overlap.
+    auto load_round = [&](uint32_t base) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t i = base + wave * 256u + it * 64u + lane;
+            valid[it] = i < r.end;
+            key[it] = valid[it] ? keys_in[i] : 0u;
+            val[it] = valid[it] ? (vals_in ? vals_in[i] : i % idx_mod) : 0u;
+        }
+    };
+    load_round(r.begin);
+    // exclusive scan of the 256 digit totals of this segment: wave scans + the four wave totals
     {
         uint32_t t, mine;
         if (dtot) {
@@ -106,37 +126,27 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
                 t += c;
             }
         }
-        scan_tmp[tid] = t;
-        __syncthreads();
         uint32_t s = t;
-        for (int o = 1; o < 256; o <<= 1) {
-            const uint32_t add = tid >= (uint32_t)o ? scan_tmp[tid - o] : 0u;
-            __syncthreads();
-            s += add;
-            scan_tmp[tid] = s;
-            __syncthreads();
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(s, o, 64);
+            if ((int)lane >= o) s += v;
         }
-        const uint32_t seg0 = blockIdx.y * seg_stride;
-        run_off[tid] = seg0 + (s - t) + mine;
+        if (lane == 63) wtot[wave] = s;
 #pragma unroll
         for (int w = 0; w < RS_WAVES; ++w) wcnt[w][tid] = 0;
+        __syncthreads();
+        uint32_t pre = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) pre += (w < (int)wave) ? wtot[w] : 0u;
+        run_off[tid] = seg0 + pre + (s - t) + mine;
     }
     __syncthreads();
-    // Rounds of 1024 keys: wave w owns the contiguous 256 keys [base + 256 w, +256) and walks them
-    // in four 64-key sub-rounds, ranking against its OWN running digit counters in LDS (a wave's LDS
-    // operations execute in program order, so read-count-then-bump needs no barrier); one block
-    // barrier per round then turns the four waves' counts into global positions.
-    constexpr uint32_t ROUND = RS_THREADS * 4;
+    // Ranking against the wave's OWN running digit counters in LDS (a wave's LDS operations execute in program
+    // order, so read-count-then-bump needs no barrier); one block barrier per round then turns the four waves'
+    // counts into global positions.
     for (uint32_t base = r.begin; base < r.end; base += ROUND) {
-        uint32_t key[4], val[4], lrank[4];
-        bool valid[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const uint32_t i = base + wave * 256u + it * 64u + lane;
-            valid[it] = i < r.end;
-            key[it] = valid[it] ? keys_in[i] : 0u;
-            val[it] = valid[it] ? (vals_in ? vals_in[i] : i % idx_mod) : 0u;
-        }
+        uint32_t lrank[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const uint32_t digit = (key[it] >> shift) & dmask;
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
             for (int w = 0; w < RS_WAVES; ++w) { tot += wcnt[w][tid]; wcnt[w][tid] = 0; }
             run_off[tid] += tot;
         }
+        if (base + ROUND < r.end) load_round(base + ROUND);
         __syncthreads();
     }
 }
