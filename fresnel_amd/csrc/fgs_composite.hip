@@ -25,6 +25,8 @@ namespace {
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float FGS_SATURATION_EPS = 2.98023223876953125e-8f;  // 2^-25: 1 - T rounds to 1.0f below it
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;  // exp(-m/2) = exp2(m * this)
+constexpr float ALPHA_MAX = 0.99f;                          // DR:647
+constexpr float INV_ALPHA_MAX = 1.0f / 0.99f;
 constexpr float PHASE_KAPPA = 2.0f * 3.14159f;              // DR:642 uses the literal 3.14159
 
 // cos / sin of x = kappa * pd, pd in [0, 0.5], i.e. x in [0, pi]: Taylor polynomials around pi/2 (|y| <= pi/2,
@@ -348,6 +350,12 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
             uint32_t flags, bits;
             stage_decode(c.X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, bits);
             q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
+            // alpha = min(G op, 0.99) = 0.99 clamp01(G op / 0.99): the list loop forms a' = clamp01(G op') with the
+            // FREE clamp modifier of v_mul instead of a v_min (4.3 issue cycles on gfx950), the 0.99 rides on the
+            // colours / depth (w c = (a' T)(0.99 c)) and on the transmittance update (T -= 0.99 a' T, one v_fmac with a
+            // literal): one instruction and ~10 % of the pass's issue cycles less
+            q1.y = q1.y / ALPHA_MAX;
+            q1.z *= ALPHA_MAX; q1.w *= ALPHA_MAX; q2.x *= ALPHA_MAX; q2.y *= ALPHA_MAX;
             sh0[wave][lane] = q0; sh1[wave][lane] = q1; sh2[wave][lane] = q2;
         }
         __builtin_amdgcn_wave_barrier();  // wave-private LDS: one wave's LDS instructions execute in order
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
             // (Skipping the lane masks for entries whose bbox covers the tile, or the min for opacities <= 0.98, behind
             // wave-uniform branches -- what pays in the backward -- made this loop 10 % SLOWER: 0.68 -> 0.75 ms at config 3;
             // its passes are too short to amortise a branch.)
-            constexpr bool inside = false, clamp = true;
+            constexpr bool inside = false;
             const uint32_t bits = __float_as_uint(q2.z);
             // the lane's two column masks once per entry (3.3 sub-tile passes per entry on average: -2.8 %)
             const uint32_t mxc[2] = {(uint32_t)__builtin_amdgcn_sbfe((int)bits, shx, 1), (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u, 1)};
@@ -381,11 +389,11 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
                         const uint32_t mk = my & mxc[col];
                         G = __uint_as_float(__float_as_uint(G) & mk);
                     }
-                    float alpha = G * q1.y;  // opacity >= 0 here: no lower clamp needed
-                    if (clamp) alpha = fminf(alpha, 0.99f);
-                    const float w = alpha * T[s];
+                    float a1;  // alpha / 0.99, opacity >= 0 here
+                    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(a1) : "v"(G), "v"(q1.y));
+                    const float w = a1 * T[s];  // (alpha T) / 0.99
                     Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
-                    T[s] -= w;
+                    T[s] = fmaf(w, -ALPHA_MAX, T[s]);
                 }
             }
         }
@@ -576,6 +584,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             stage_decode(c.X0, c.Y0, bbx, bby, q1.y, flags, bits, conic_ok);
             q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;  // conic in exp2 units
+            // alpha = 0.99 a', a' = clamp01(G op / 0.99) (free clamp modifier instead of a v_min, as in the forward); the
+            // list loop works with w' = a' T = w / 0.99 and colours c' = 0.99 c, so that w q = w' q'; its sums come out
+            // as 0.99 x (moments, sum dG) and 1 / 0.99 x (colour, depth) and k_row_sum puts the factors back
+            q1.y = q1.y / ALPHA_MAX;
+            q1.z *= ALPHA_MAX; q1.w *= ALPHA_MAX; q2.x *= ALPHA_MAX; q2.y *= ALPHA_MAX;
             sh0[lane] = q0; sh1[lane] = q1; sh2[lane] = q2;
         }
         __syncthreads();
@@ -616,14 +629,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     const float t = ca * dx + ((s >> 1) ? bdyb : bdya);
                     const float Gu = __builtin_amdgcn_exp2f(t * dx + ((s >> 1) ? cyyb : cyya));
                     const float G = __uint_as_float(__float_as_uint(Gu) & mk);
-                    const float raw = G * op;
-                    const float alpha = fminf(raw, 0.99f);  // a no-op unless `clamp` (then only the select below differs)
-                    const float w = alpha * T[s];
-                    const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;
+                    float a1;  // alpha / 0.99
+                    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(a1) : "v"(G), "v"(op));
+                    const float w = a1 * T[s];  // w / 0.99
+                    const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;  // 0.99 q
                     S[s] -= w * q;
-                    float dalpha = T[s] * q - S[s] * __builtin_amdgcn_rcpf(1.0f - alpha);
-                    T[s] -= w;
-                    if (clamp) dalpha = select_le(raw, 0.99f, dalpha);
+                    // 0.99 dL/dalpha: 0.99 / (1 - alpha) = 1 / (1 / 0.99 - a')
+                    float dalpha = T[s] * q - S[s] * __builtin_amdgcn_rcpf(INV_ALPHA_MAX - a1);
+                    T[s] = fmaf(w, -ALPHA_MAX, T[s]);
+                    if (clamp) dalpha = select_lt(a1, 1.0f, dalpha);  // the clamp binds where G op / 0.99 reaches 1
                     const float dG = dalpha * G;
                     v_op += dG;
                     const float dmx = dG * dx, dmy = dG * dy;

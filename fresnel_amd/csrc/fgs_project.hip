@@ -199,10 +199,14 @@ __global__ __launch_bounds__(256) void k_row_sum(int32_t total, int32_t N, uint3
             m[0] += a.x; m[1] += a.y; m[2] += bq.x; m[3] += bq.y; m[4] += cq.x; m[5] += cq.y;
             acc[6] += dq.x; acc[7] += dq.y; acc[8] += eq.x; acc[9] += eq.y;
         }
-        const double hp = 0.69314718055994530942 * (double)rec[(size_t)idx * FGS_REC_FLOATS + R_OP];
+        // k_composite_bwd works with alpha / 0.99 and 0.99 x colours: its moment and sum-dG rows carry a factor 0.99, its
+        // colour / depth rows 1 / 0.99
+        const double ia = 1.0 / (double)0.99f;
+        const double hp = 0.69314718055994530942 * (double)rec[(size_t)idx * FGS_REC_FLOATS + R_OP] * ia;
         acc[0] = (float)(hp * m[0]); acc[1] = (float)(hp * m[1]);
         acc[2] = (float)(-0.72134752044448170368 * hp * m[2]); acc[3] = (float)(-0.72134752044448170368 * hp * m[3]);
-        acc[4] = (float)(-0.72134752044448170368 * hp * m[4]); acc[5] = (float)m[5];
+        acc[4] = (float)(-0.72134752044448170368 * hp * m[4]); acc[5] = (float)(m[5] * ia);
+        acc[6] *= 0.99f; acc[7] *= 0.99f; acc[8] *= 0.99f; acc[9] *= 0.99f;
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
@@ -264,23 +268,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     } else if (live) {
         // rows_per_dup gradient rows per duplicate (4 on the phase path: one per sub-tile wave), contiguous
         const uint32_t cnt = tile_count[idx] * rows_per_dup, off = dup_off[idx] * rows_per_dup;
-        if (MODE == 0 && phase_channels) {
-            // blend path: 10-float rows = moments of dL/dG about the Gaussian's mean (sum dG {dx, dy, dx^2, dx dy, dy^2,
-            // 1}), colour and depth sums (k_composite_bwd), summed in double.  The totals get the factors of the chain
-            // through m' = K m, G = exp2(m'), alpha = G opacity: first moments x ln2 opacity (then dL/d(u,v) =
-            // -K conic_sym M below), dL/dconic = K ln2 opacity x second moments.
-            double m[6] = {0, 0, 0, 0, 0, 0};
-            for (uint32_t k = sub; k < cnt && off + k < dcap; k += 4) {
-                const float2 *r = reinterpret_cast<const float2 *>(grad_rows + (size_t)(off + k) * FGS_BLEND_ROW_FLOATS);
-                const float2 a = r[0], bq = r[1], cq = r[2], dq = r[3], eq = r[4];
-                m[0] += a.x; m[1] += a.y; m[2] += bq.x; m[3] += bq.y; m[4] += cq.x; m[5] += cq.y;
-                acc[6] += dq.x; acc[7] += dq.y; acc[8] += eq.x; acc[9] += eq.y;
-            }
-            const double hp = 0.69314718055994530942 * (double)rec[(size_t)idx * FGS_REC_FLOATS + R_OP];
-            acc[0] = (float)(hp * m[0]); acc[1] = (float)(hp * m[1]);
-            acc[2] = (float)(-0.72134752044448170368 * hp * m[2]); acc[3] = (float)(-0.72134752044448170368 * hp * m[3]);
-            acc[4] = (float)(-0.72134752044448170368 * hp * m[4]); acc[5] = (float)m[5];
-        } else if (MODE == 0) {
+        if (MODE == 0) {  // (the blend path's rows are summed by k_row_sum: PRESUM)
             // phase path: FOUR rows per duplicate, one per 8x8 sub-tile wave of k_composite_bwd_phase, which writes
             // only the rows of sub-tiles the bbox touches -- the same integer test decides here which rows exist
             // (lane `sub` of the quad owns sub-tile `sub` of every duplicate)
@@ -521,7 +509,8 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
     const uint32_t *dup_off = reinterpret_cast<const uint32_t *>(saved + p.L.dup_off);
     const uint32_t *tile_count = reinterpret_cast<const uint32_t *>(saved + p.L.tile_count);
     const float *rec = reinterpret_cast<const float *>(saved + p.L.rec);
-    if (!p.d.use_phase && row_sums) {
+    if (!p.d.use_phase) {
+        if (!row_sums) { fgs_set_error("fgs_launch_project_bwd: the blend path needs the row-sum scratch"); return FGS_EINVAL; }
         // blend path: streaming row sums at full occupancy, then one thread per Gaussian for the adjoint
         hipLaunchKernelGGL(k_row_sum, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
                            (uint32_t)p.L.dup_capacity, order, dup_off, tile_count, grad_rows, rec, row_sums);
@@ -536,7 +525,7 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
     hipLaunchKernelGGL(k_project_bwd<0>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
                        p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat, depth_key, order, dup_off,
                        tile_count, grad_rows, g_pos, g_scale, g_quat, g_color, g_opacity, g_phase, nullptr, nullptr,
-                       p.d.use_phase ? 0 : 1, p.d.use_phase ? 4u : 1u, rec);  // rec: row geometry
+                       0, 4u, rec);  // phase path: four rows per duplicate; rec: row geometry
     FGS_LAUNCH_CHECK("k_project_bwd");
     return FGS_OK;
 }

@@ -33,12 +33,12 @@ __device__ __forceinline__ void stage_decode(uint32_t X0, uint32_t Y0, uint32_t 
     bits = xm | (ym << 16);
 }
 
-// (x <= lim) ? v : 0.  The compare and the select are kept ADJACENT in one asm block: a v_cndmask reading VCC
+// (x < lim) ? v : 0.  The compare and the select are kept ADJACENT in one asm block: a v_cndmask reading VCC
 // straight after the v_cmp that wrote it issues in ~2.6 cycles on gfx950, any other VCC-reading v_cndmask in
 // 14-23 (scratch/ubench/valu3.hip, valu4.hip).
-__device__ __forceinline__ float select_le(float x, float lim, float v) {
+__device__ __forceinline__ float select_lt(float x, float lim, float v) {
     float o;
-    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(o) : "v"(x), "v"(lim), "v"(v) : "vcc");
+    asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(o) : "v"(x), "v"(lim), "v"(v) : "vcc");
     return o;
 }
 
