@@ -293,6 +293,7 @@ def inspect_saved(saved: torch.Tensor, dims) -> dict:
     out["depth_key"] = view(L.depth_key, Bn * N, torch.int32).view(Bn, N)
     out["tile_count"] = view(L.tile_count, Bn * N, torch.int32).view(Bn, N)
     out["order"] = view(L.order, Bn * N, torch.int32).view(Bn, N)
+    out["dup_off"] = view(L.dup_off, Bn * N, torch.int32).view(Bn, N)
     out["counters"] = view(L.counters, 16, torch.int32)
     out["ranges"] = view(L.ranges, Bn * T * 2, torch.int32).view(Bn, T, 2)
     out["dup_ids"] = view(L.dup_ids, L.dup_capacity, torch.int32)

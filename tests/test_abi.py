@@ -102,6 +102,12 @@ def test_tuning_fields_are_validated_and_change_only_the_split():
     with pytest.raises(B.FgsError):
         B.workspace_bytes(B.make_dims(1, 100, 2048, 2048, tuning=dict(bin_mode=1)))
     B.workspace_bytes(B.make_dims(1, 100, 2048, 2048, tuning=dict(bin_mode=2)))
+    # ... and <= 512 tile columns + rows (the mask binning keeps one mask line per column / row in LDS): a
+    # 8192 x 16 frame (512 + 1 lines) takes the radix path
+    with pytest.raises(B.FgsError):
+        B.workspace_bytes(B.make_dims(1, 100, 8192, 16, tuning=dict(bin_mode=1)))
+    B.workspace_bytes(B.make_dims(1, 100, 8192, 16))
+    B.workspace_bytes(B.make_dims(1, 100, 8176, 16, tuning=dict(bin_mode=1)))
 
 
 def test_new_entries_validate_arguments_without_a_gpu(lib):

@@ -275,7 +275,7 @@ def test_full_size_properties_config3_shape():
 
 
 def test_direct_binning_equals_radix_binning():
-    """Two list builders: the counting sort straight from the bboxes (default for a single layer and <= 4096 tiles
+    """Two list builders: the mask binning straight from the bboxes (default for a single layer and <= 4096 tiles
     per image) and the emit + stable radix sort path (kept for the layered ASM keys and larger frames), selected
     here with FgsDims.bin_mode.  Both must produce bit-identical lists, ranges, segment tables and images."""
     from fresnel_amd.renderer import Camera
@@ -288,6 +288,51 @@ def test_direct_binning_equals_radix_binning():
     assert np.array_equal(outs[0]["dup_ids"][:D], outs[1]["dup_ids"][:D])
     for k in ("ranges", "seg_off", "image", "depth"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("N", [1, 63, 65, 257, 777])
+def test_mask_binning_ragged_counts_vs_oracle(N):
+    """The mask binning packs the depth ranks into 64-bit words, four words per 256-rank block, lines padded to eight
+    words: Gaussian counts that are not multiples of 64 / 256, on a frame that is not a whole number of tiles
+    (72 x 40 -> 5 x 3 tiles).  Lists, ranges and order bit-exact against the oracle, two images per call."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    W, H = 72, 40
+    a0, a1 = synth_aniso(N, 400 + N, smax=0.25), synth_aniso(N, 900 + N, smax=0.1)
+    cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    st = _hip_stages([np.stack([x, y]) for x, y in zip(a0, a1)], cam, W, H, tuning=dict(bin_mode=1))
+    for b, arrs in enumerate((a0, a1)):
+        r = _oracle(list(arrs), ocam, (0, 0, 0))
+        _check_integer_stages(st, b, r, W, H)
+        assert rel_to_max(st["image"][b], r.image) <= TOL
+
+
+def test_mask_binning_dense_tiles_flush_in_windows():
+    """6000 wide Gaussians over 3 x 2 tiles: every tile collects several thousand entries out of ONE chunk of depth
+    ranks, more than the 2048 a wave of k_mask_emit parks in LDS per flush -- the windowed flush must keep the list
+    order.  Bit-exact against the oracle and against the radix path."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    N, W, H = 6000, 48, 32
+    rs = np.random.RandomState(77)
+    pos = (rs.randn(N, 3) * [0.3, 0.25, 0.3] + [0, 0, -2.0]).astype(np.float32)
+    scale = (0.25 * rs.uniform(0.5, 1.5, (N, 3))).astype(np.float32)
+    quat = rs.randn(N, 4).astype(np.float32)
+    col = rs.rand(N, 3).astype(np.float32)
+    opa = rs.uniform(0.002, 0.02, N).astype(np.float32)
+    arrs = [pos, scale, quat, col, opa]
+    cam = Camera(0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+    outs = [_hip_stages([a[None] for a in arrs], cam, W, H, tuning=dict(bin_mode=m)) for m in (1, 2)]
+    lens = outs[0]["ranges"][0][:, 1] - outs[0]["ranges"][0][:, 0]
+    assert lens.max() > 2 * 2048
+    r = _oracle(arrs, ocam, (0, 0, 0))
+    _check_integer_stages(outs[0], 0, r, W, H)
+    D = int(outs[0]["counters"][0])
+    assert np.array_equal(outs[0]["dup_ids"][:D], outs[1]["dup_ids"][:D])
+    assert np.array_equal(outs[0]["ranges"], outs[1]["ranges"])
+    assert np.array_equal(outs[0]["dup_off"], outs[1]["dup_off"])
 
 
 def test_wide_frame_direct_binning_division_is_exact():
