@@ -4,7 +4,7 @@ import sys, glob, csv, collections, json
 root, key = sys.argv[1], sys.argv[2]
 KEYS = ('k_composite_bwd_phase', 'k_composite_bwd', 'k_blend_fwd_parts', 'k_composite_fwd', 'k_asm_splat', 'k_asm_accumulate_bwd',
         'k_asm_accumulate', 'k_asm_transfer', 'k_project_bwd', 'k_project', 'k_sort_image', 'k_radix_downsweep', 'k_radix_upsweep',
-        'k_bin_scatter', 'k_bin_count', 'k_tile_order', 'k_tile_scan', 'k_dup_emit')
+        'k_mask_build', 'k_mask_count', 'k_mask_emit', 'k_row_sum', 'k_tile_pre', 'k_tile_post', 'k_dup_emit')
 
 
 def match(name):
