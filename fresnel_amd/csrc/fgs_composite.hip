@@ -371,6 +371,9 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const uint32_t bits = __float_as_uint(q2.z);
             // the lane's two column masks once per entry (3.3 sub-tile passes per entry on average: -2.8 %)
             const uint32_t mxc[2] = {(uint32_t)__builtin_amdgcn_sbfe((int)bits, shx, 1), (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u, 1)};
+            // ... and its two column offsets (3.3 passes per entry: one subtraction per pass would be more)
+            float dxc[2] = {fx0 - q0.x, fx1 - q0.x};
+            asm("" : "+v"(dxc[0]), "+v"(dxc[1]));
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
                 if (!((msk >> (2 * row)) & 3u)) continue;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 for (int col = 0; col < 2; ++col) {
                     const int s = 2 * row + col;
                     if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
-                    const float dx = (col ? fx1 : fx0) - q0.x;
+                    const float dx = dxc[col];
                     const float t = q0.z * dx + bdy;
                     float G = __builtin_amdgcn_exp2f(t * dx + cyy);
                     if (!inside) {
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 // entries; this kernel walks the list in REVERSE sub-chunks, re-runs the forward inside each
 // sub-chunk from its checkpoint (parking (A_{i-1}, Phi_{i-1}) per entry in LDS), then sweeps
 // the sub-chunk back-to-front with the per-pixel adjoints Abar (init -gI.bg) and Phibar.
-// (70 VGPRs = 7 waves per SIMD; forcing 8 spills 19 registers and costs 30 %)
+// (76 VGPRs = 6 waves per SIMD; forcing 7 spills 3 registers and costs 8 %, forcing 8 spills 19 and costs 30 %)
 __global__ __launch_bounds__(256) void k_composite_bwd_phase(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
     uint32_t dcap, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
