@@ -612,17 +612,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             // per-lane constants -- were 4 % faster but lose the second moments of sub-pixel Gaussians to
             // cancellation in fp32: up to 4e-2 on dL/dscale in the randomized sweeps.)
             float v_mx = 0, v_my = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0;
-            {   // ONE code path for every kind of entry; what differs is handled by wave-uniform branches around a few
-                // ops: `inside` (bbox covers the tile, flag bit 5): no lane masks to extract; `clamp` (flag bit 4
-                // clear: opacity > 0.98 or a doubtful conic): alpha = min(G op, 0.99) and the clamp-gradient select.
+            {   // ONE code path for every kind of entry; what differs is handled by a wave-uniform branch around two
+                // ops: `clamp` (flag bit 4 clear: opacity > 0.98 or a doubtful conic): the clamp-gradient select.
                 // (Four specialised instantiations of this loop body made the compiler carry T and S through eight
                 // v_mov per list entry and were 5 % slower.)
-                const bool inside = (msk & 32u) != 0u, clamp = (msk & 16u) == 0u;
-                uint32_t mx0 = ~0u, mx1 = ~0u, my0 = ~0u, my1 = ~0u;
-                if (!inside) {
-                    mx0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx, 1); mx1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u, 1);
-                    my0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy, 1); my1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u, 1);
-                }
+                uint32_t cflag = msk & 16u;  // clear: `clamp`.  Kept as a scalar and tested where it is used: as a bool the
+                asm("" : "+s"(cflag));       // compiler materialised it through a v_cndmask / v_cmp pair per list entry
+                // the lane masks of every entry, also of those whose bbox covers the tile (all bits set): skipping the four
+                // v_bfe behind a branch needed four v_mov of the default and was 0.9 % slower
+                const uint32_t mx0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx, 1), mx1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u, 1);
+                const uint32_t my0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy, 1), my1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u, 1);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
@@ -640,7 +639,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     // 0.99 dL/dalpha: 0.99 / (1 - alpha) = 1 / (1 / 0.99 - a')
                     float dalpha = T[s] * q - S[s] * __builtin_amdgcn_rcpf(INV_ALPHA_MAX - a1);
                     T[s] = fmaf(w, -ALPHA_MAX, T[s]);
-                    if (clamp) dalpha = select_lt(a1, 1.0f, dalpha);  // the clamp binds where G op / 0.99 reaches 1
+                    uint32_t cf = cflag;
+                    asm("" : "+s"(cf));  // an opaque scalar per use: one s_cmp + branch, nothing on the vector side
+                    if (!cf) dalpha = select_lt(a1, 1.0f, dalpha);  // the clamp binds where G op / 0.99 reaches 1
                     const float dG = dalpha * G;
                     v_op += dG;
                     const float dmx = dG * dx, dmy = dG * dy;
