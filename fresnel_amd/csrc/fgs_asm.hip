@@ -26,6 +26,7 @@ namespace {
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;
 constexpr int ACH = 64;
 constexpr int ASM_FWD_PARTS = 4;  // list parts (waves) per (image, plane, tile) in the forward splat
+constexpr int RED_BLOCKS = 128;   // blocks (= partials) per image of the per-image scalar reductions, see below
 
 struct AsmPlan {
     FgsAsmDims a;
@@ -39,6 +40,7 @@ struct AsmPlan {
     size_t v_total_bytes;
     // scratch sections (after base.s_total)
     size_t c_acc;        // float2 [B][3][H][W]
+    size_t c_part;       // float2 [B][RED_BLOCKS] block partials of the per-image scalars | float [3][B*HW/256] of dL/dlambda
     size_t c_fftwork;
     size_t c_total_bytes;
     size_t work_big, work_small;
@@ -79,6 +81,7 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     }
     o = p->base.s_total;
     p->c_acc = o; o = align256(o + B * 3 * HW * 8);
+    p->c_part = o; o = align256(o + B * RED_BLOCKS * 8 + 3 * ((B * HW + 255) / 256) * 4);
     p->c_fftwork = o; o = align256(o + (p->work_big > p->work_small ? p->work_big : p->work_small) + 256);
     p->c_total_bytes = o;
     return FGS_OK;
@@ -100,15 +103,20 @@ __device__ __forceinline__ float plane_depth(int k, int P, float near_, float fa
 }
 
 // H[c][p][ky][kx] = exp(i * ((2 pi * z_p) * kz)), kz = sqrt(max(1/l_c^2 - fx^2 - fy^2, 0))   DR:989-999
+// fftfreq(n - k) = -fftfreq(k) exactly, and H depends on fx^2, fy^2 only: one thread evaluates the quadrant entry
+// (ky <= H/2, kx <= W/2) -- the accurate sincosf is what this kernel costs -- and stores it at its up to four mirror
+// positions, bit-identical to evaluating every entry (58 -> 20 us for 3 x 16 planes of 512^2).
 __global__ __launch_bounds__(256) void k_asm_transfer(int W, int H, int P, float near_, float far_, float focal,
                                                       float inv_ndx, float inv_ndy,
                                                       const float *__restrict__ wavelengths,
                                                       float2 *__restrict__ htab) {
     const size_t HW = (size_t)W * H;
+    const int QW = W / 2 + 1, QH = H / 2 + 1;
+    const size_t QHW = (size_t)QW * QH;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= 3 * (size_t)P * HW) return;
-    const int kx = (int)(i % W), ky = (int)((i / W) % H);
-    const int p = (int)((i / HW) % P), c = (int)(i / (HW * P));
+    if (i >= 3 * (size_t)P * QHW) return;
+    const int kx = (int)(i % QW), ky = (int)((i / QW) % QH);
+    const int p = (int)((i / QHW) % P), c = (int)(i / (QHW * P));
     const float fx = fftfreq(kx, W, inv_ndx), fy = fftfreq(ky, H, inv_ndy);
     const float il = 1.0f / wavelengths[c];
     float kz2 = il * il - fx * fx - fy * fy;
@@ -118,7 +126,15 @@ __global__ __launch_bounds__(256) void k_asm_transfer(int W, int H, int P, float
     const float theta = (6.28318530717958647692f * z) * kz;
     float sn, cs;
     sincosf(theta, &sn, &cs);
-    htab[i] = make_float2(cs, sn);
+    const float2 h = make_float2(cs, sn);
+    float2 *plane = htab + ((size_t)c * P + p) * HW;
+    const int mx = (kx > 0 && W - kx != kx) ? W - kx : -1, my = (ky > 0 && H - ky != ky) ? H - ky : -1;
+    plane[(size_t)ky * W + kx] = h;
+    if (mx >= 0) plane[(size_t)ky * W + mx] = h;
+    if (my >= 0) {
+        plane[(size_t)my * W + kx] = h;
+        if (mx >= 0) plane[(size_t)my * W + mx] = h;
+    }
 }
 
 // One wave per (image, plane, tile); lane = one pixel of each of the four 8x8 sub-tiles.
@@ -321,10 +337,39 @@ __global__ __launch_bounds__(256) void k_asm_accumulate(size_t HW, int B, int P,
     acc[i] = s;
 }
 
-// per-image max of sqrt(|U|^2 + 1e-8) over pixels and channels (DR:1316-1322); r >= 0, so the
-// float ordering equals the ordering of the bit patterns and atomicMax(uint) is exact
+// ---- per-image scalars (maximum, dL/dM, number of maxima, dL/dlambda) as TWO-LEVEL reductions -------------------
+// One partial per block, RED_BLOCKS blocks per image; the consumers' blocks fold the partials themselves (one value per
+// thread, fixed order).  Round 1 reduced these with one device-scope atomic per wave on a single address per image;
+// such atomics serialise at ~50 ns each on this part: k_asm_output_bwd1 took 54 us for one image and 419 us for
+// eight, k_asm_max 26 / 191 us -- both read 6-9 MB per image -- and the float sums came out in arrival order.
+
+__device__ __forceinline__ float block_max_256(float v) {  // all 256 threads call; every thread gets the result
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();  // (protects wmax against the previous use)
+    if ((threadIdx.x & 63u) == 0) wmax[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+}
+__device__ __forceinline__ float2 block_sum2_256(float a, float b) {  // fixed order: xor tree, then waves 0..3
+    __shared__ float2 wsum[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = make_float2(a, b);
+    __syncthreads();
+    return make_float2((wsum[0].x + wsum[1].x) + (wsum[2].x + wsum[3].x), (wsum[0].y + wsum[1].y) + (wsum[2].y + wsum[3].y));
+}
+// maximum of an image's RED_BLOCKS block maxima (every thread of the block gets it)
+__device__ __forceinline__ float image_max(const float *__restrict__ pmax, int b) {
+    static_assert(RED_BLOCKS <= 256, "one partial per thread");
+    return block_max_256(threadIdx.x < RED_BLOCKS ? pmax[(size_t)b * RED_BLOCKS + threadIdx.x] : 0.0f);
+}
+
+// per-image max of sqrt(|U|^2 + 1e-8) over pixels and channels (DR:1316-1322): block maxima -> pmax[b][block]
 __global__ __launch_bounds__(256) void k_asm_max(size_t HW, float inv_hw, const float2 *__restrict__ total,
-                                                 float *__restrict__ scal) {
+                                                 float *__restrict__ pmax) {
     const int b = blockIdx.y;
     float mx = 0.0f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < 3 * HW; i += (size_t)gridDim.x * 256) {
@@ -332,9 +377,8 @@ __global__ __launch_bounds__(256) void k_asm_max(size_t HW, float inv_hw, const 
         const float ur = u.x * inv_hw, ui = u.y * inv_hw;
         mx = fmaxf(mx, sqrtf(ur * ur + ui * ui + 1e-8f));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63u) == 0) atomicMax(reinterpret_cast<unsigned int *>(scal + b), __float_as_uint(mx));
+    mx = block_max_256(mx);
+    if (threadIdx.x == 0) pmax[(size_t)b * RED_BLOCKS + blockIdx.x] = mx;
 }
 
 struct PixOut {
@@ -362,15 +406,18 @@ __device__ __forceinline__ void pixel_forward(const float2 u[3], float inv_hw, f
 
 __global__ __launch_bounds__(256) void k_asm_output(size_t HW, float inv_hw, float bg0, float bg1, float bg2,
                                                     const float2 *__restrict__ total,
-                                                    const float *__restrict__ scal, float *__restrict__ out) {
+                                                    const float *__restrict__ pmax, float *__restrict__ scal,
+                                                    float *__restrict__ out) {
     const int b = blockIdx.y;
+    const float maxval = image_max(pmax, b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[b] = maxval;  // kept for the backward
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
     const float2 u[3] = {total[((size_t)b * 3 + 0) * HW + i], total[((size_t)b * 3 + 1) * HW + i],
                          total[((size_t)b * 3 + 2) * HW + i]};
     const float bg[3] = {bg0, bg1, bg2};
     PixOut o;
-    pixel_forward(u, inv_hw, scal[b], bg, o);
+    pixel_forward(u, inv_hw, maxval, bg, o);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = o.v[c];
@@ -378,19 +425,19 @@ __global__ __launch_bounds__(256) void k_asm_output(size_t HW, float inv_hw, flo
     }
 }
 
-// backward of k_asm_output, pass 1: gM = dL/dM and the number of maxima (torch.max() spreads
-// the gradient evenly over equal maxima)
+// backward of k_asm_output, pass 1: gM = dL/dM and the number of maxima (torch.max() spreads the gradient evenly over
+// equal maxima): RED_BLOCKS block partials per image -> psum[b][block] = (gM, count)
 __global__ __launch_bounds__(256) void k_asm_output_bwd1(size_t HW, float inv_hw, float bg0, float bg1, float bg2,
                                                          const float2 *__restrict__ total,
-                                                         float *__restrict__ scal, const float *__restrict__ g_out) {
+                                                         const float *__restrict__ scal, const float *__restrict__ g_out,
+                                                         float2 *__restrict__ psum) {
     const int b = blockIdx.y;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     float gM = 0.0f, cnt = 0.0f;
-    if (i < HW) {
+    const float bg[3] = {bg0, bg1, bg2};
+    const float maxval = scal[b];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
         const float2 u[3] = {total[((size_t)b * 3 + 0) * HW + i], total[((size_t)b * 3 + 1) * HW + i],
                              total[((size_t)b * 3 + 2) * HW + i]};
-        const float bg[3] = {bg0, bg1, bg2};
-        const float maxval = scal[b];
         PixOut o;
         pixel_forward(u, inv_hw, maxval, bg, o);
 #pragma unroll
@@ -403,28 +450,32 @@ __global__ __launch_bounds__(256) void k_asm_output_bwd1(size_t HW, float inv_hw
             if (o.r[c] == maxval) cnt += 1.0f;
         }
     }
-#pragma unroll
-    for (int of = 32; of > 0; of >>= 1) { gM += __shfl_xor(gM, of, 64); cnt += __shfl_xor(cnt, of, 64); }
-    if ((threadIdx.x & 63u) == 0) {
-        if (gM != 0.0f) atomicAdd(scal + gridDim.y + b, gM);
-        if (cnt != 0.0f) atomicAdd(scal + 2 * gridDim.y + b, cnt);
-    }
+    const float2 t = block_sum2_256(gM, cnt);
+    if (threadIdx.x == 0) psum[(size_t)b * RED_BLOCKS + blockIdx.x] = t;
+}
+
+// (gM, count) of image b from the block partials (every thread of the block gets them)
+__device__ __forceinline__ float2 image_sums(const float2 *__restrict__ psum, int b) {
+    const float2 v = threadIdx.x < RED_BLOCKS ? psum[(size_t)b * RED_BLOCKS + threadIdx.x] : make_float2(0.0f, 0.0f);
+    return block_sum2_256(v.x, v.y);
 }
 
 // pass 2: gradient w.r.t. the (unnormalised) total field, written over `gtot`
 __global__ __launch_bounds__(256) void k_asm_output_bwd2(size_t HW, float inv_hw, float bg0, float bg1, float bg2,
                                                          const float2 *__restrict__ total,
                                                          const float *__restrict__ scal,
+                                                         const float2 *__restrict__ psum,
                                                          const float *__restrict__ g_out, float2 *__restrict__ gtot) {
     const int b = blockIdx.y;
+    const float2 sums = image_sums(psum, b);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
     const float2 u[3] = {total[((size_t)b * 3 + 0) * HW + i], total[((size_t)b * 3 + 1) * HW + i],
                          total[((size_t)b * 3 + 2) * HW + i]};
     const float bg[3] = {bg0, bg1, bg2};
     const float maxval = scal[b];
-    const float cntm = scal[2 * gridDim.y + b];
-    const float gMshare = (maxval >= 1.0f && cntm > 0.0f) ? scal[gridDim.y + b] / cntm : 0.0f;
+    const float cntm = sums.y;
+    const float gMshare = (maxval >= 1.0f && cntm > 0.0f) ? sums.x / cntm : 0.0f;
     PixOut o;
     pixel_forward(u, inv_hw, maxval, bg, o);
     float gv[3], gta = 0.0f;
@@ -454,7 +505,7 @@ __global__ __launch_bounds__(256) void k_asm_accumulate_bwd(int W, int H, int B,
                                                             const float2 *__restrict__ gacc,
                                                             const float2 *__restrict__ htab,
                                                             float2 *__restrict__ field,
-                                                            float *__restrict__ g_wavelengths) {
+                                                            float *__restrict__ pwl /* [3][gridDim.x] block partials */) {
     const size_t HW = (size_t)W * H;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y;
@@ -487,10 +538,20 @@ __global__ __launch_bounds__(256) void k_asm_accumulate_bwd(int W, int H, int B,
     __shared__ float part[4];
     if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = gl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float s = (part[0] + part[1]) + (part[2] + part[3]);
-        if (s != 0.0f) atomicAdd(g_wavelengths + c, s);
-    }
+    if (threadIdx.x == 0) pwl[(size_t)c * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// dL/dlambda_c = the sum of k_asm_accumulate_bwd's block partials, in a fixed order, in double (one block per channel)
+__global__ __launch_bounds__(256) void k_asm_wavelength_grad(uint32_t n, const float *__restrict__ pwl,
+                                                             float *__restrict__ g_wavelengths) {
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s += (double)pwl[(size_t)blockIdx.x * n + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) g_wavelengths[blockIdx.x] = (float)((part[0] + part[1]) + (part[2] + part[3]));
 }
 
 
@@ -520,30 +581,31 @@ __device__ __forceinline__ void wave_pixel_forward(const float2 u[3], float maxv
     for (int c = 0; c < 3; ++c) o.v[c] = o.n[c] + bg[c] * (1.0f - o.ta);
 }
 
-__global__ __launch_bounds__(256) void k_wave_max(size_t HW, const float2 *__restrict__ field, float *__restrict__ scal) {
+__global__ __launch_bounds__(256) void k_wave_max(size_t HW, const float2 *__restrict__ field, float *__restrict__ pmax) {
     const int b = blockIdx.y;
     float mx = 0.0f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < 3 * HW; i += (size_t)gridDim.x * 256) {
         const float2 u = field[(size_t)b * 3 * HW + i];
         mx = fmaxf(mx, sqrtf(u.x * u.x + u.y * u.y + 1e-8f));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63u) == 0) atomicMax(reinterpret_cast<unsigned int *>(scal + b), __float_as_uint(mx));
+    mx = block_max_256(mx);
+    if (threadIdx.x == 0) pmax[(size_t)b * RED_BLOCKS + blockIdx.x] = mx;
 }
 
 __global__ __launch_bounds__(256) void k_wave_output(size_t HW, float bg0, float bg1, float bg2,
                                                      const float2 *__restrict__ field, const float2 *__restrict__ dw,
-                                                     const float *__restrict__ scal, float *__restrict__ out,
-                                                     float *__restrict__ out_depth) {
+                                                     const float *__restrict__ pmax, float *__restrict__ scal,
+                                                     float *__restrict__ out, float *__restrict__ out_depth) {
     const int b = blockIdx.y;
+    const float maxval = image_max(pmax, b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[b] = maxval;  // kept for the backward
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
     const float2 u[3] = {field[((size_t)b * 3 + 0) * HW + i], field[((size_t)b * 3 + 1) * HW + i],
                          field[((size_t)b * 3 + 2) * HW + i]};
     const float bg[3] = {bg0, bg1, bg2};
     WavePix o;
-    wave_pixel_forward(u, scal[b], bg, o);
+    wave_pixel_forward(u, maxval, bg, o);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = o.v[c];
@@ -554,16 +616,15 @@ __global__ __launch_bounds__(256) void k_wave_output(size_t HW, float bg0, float
 }
 
 __global__ __launch_bounds__(256) void k_wave_output_bwd1(size_t HW, float bg0, float bg1, float bg2,
-                                                          const float2 *__restrict__ field, float *__restrict__ scal,
-                                                          const float *__restrict__ g_out) {
+                                                          const float2 *__restrict__ field, const float *__restrict__ scal,
+                                                          const float *__restrict__ g_out, float2 *__restrict__ psum) {
     const int b = blockIdx.y;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     float gM = 0.0f, cnt = 0.0f;
-    if (i < HW) {
+    const float bg[3] = {bg0, bg1, bg2};
+    const float maxval = scal[b];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
         const float2 u[3] = {field[((size_t)b * 3 + 0) * HW + i], field[((size_t)b * 3 + 1) * HW + i],
                              field[((size_t)b * 3 + 2) * HW + i]};
-        const float bg[3] = {bg0, bg1, bg2};
-        const float maxval = scal[b];
         WavePix o;
         wave_pixel_forward(u, maxval, bg, o);
 #pragma unroll
@@ -575,29 +636,27 @@ __global__ __launch_bounds__(256) void k_wave_output_bwd1(size_t HW, float bg0, 
             if (o.r[c] == maxval) cnt += 1.0f;
         }
     }
-#pragma unroll
-    for (int of = 32; of > 0; of >>= 1) { gM += __shfl_xor(gM, of, 64); cnt += __shfl_xor(cnt, of, 64); }
-    if ((threadIdx.x & 63u) == 0) {
-        if (gM != 0.0f) atomicAdd(scal + gridDim.y + b, gM);
-        if (cnt != 0.0f) atomicAdd(scal + 2 * gridDim.y + b, cnt);
-    }
+    const float2 t = block_sum2_256(gM, cnt);
+    if (threadIdx.x == 0) psum[(size_t)b * RED_BLOCKS + blockIdx.x] = t;
 }
 
 __global__ __launch_bounds__(256) void k_wave_output_bwd2(size_t HW, float bg0, float bg1, float bg2,
                                                           const float2 *__restrict__ field,
                                                           const float2 *__restrict__ dw, const float *__restrict__ scal,
+                                                          const float2 *__restrict__ psum,
                                                           const float *__restrict__ g_out,
                                                           const float *__restrict__ g_depth, float2 *__restrict__ gfield,
                                                           float2 *__restrict__ gdw) {
     const int b = blockIdx.y;
+    const float2 sums = image_sums(psum, b);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
     const float2 u[3] = {field[((size_t)b * 3 + 0) * HW + i], field[((size_t)b * 3 + 1) * HW + i],
                          field[((size_t)b * 3 + 2) * HW + i]};
     const float bg[3] = {bg0, bg1, bg2};
     const float maxval = scal[b];
-    const float cntm = scal[2 * gridDim.y + b];
-    const float gMshare = (maxval >= 1.0f && cntm > 0.0f) ? scal[gridDim.y + b] / cntm : 0.0f;
+    const float cntm = sums.y;
+    const float gMshare = (maxval >= 1.0f && cntm > 0.0f) ? sums.x / cntm : 0.0f;
     WavePix o;
     wave_pixel_forward(u, maxval, bg, o);
     float gv[3], gta = 0.0f;
@@ -626,7 +685,7 @@ __global__ __launch_bounds__(256) void k_wave_output_bwd2(size_t HW, float bg0, 
 struct WavePlan {
     FgsWaveDims w;
     FgsPlan base;
-    size_t HW, v_field, v_dw, v_scal, v_total_bytes, c_gfield, c_gdw, c_rows, c_total_bytes;
+    size_t HW, v_field, v_dw, v_scal, v_total_bytes, c_gfield, c_gdw, c_rows, c_part, c_total_bytes;
 };
 
 int make_wave_plan(const FgsWaveDims *w, WavePlan *p) {
@@ -651,6 +710,7 @@ int make_wave_plan(const FgsWaveDims *w, WavePlan *p) {
     p->c_gfield = o; o = align256(o + B * 3 * HW * 8);
     p->c_gdw = o; o = align256(o + B * HW * 8);
     p->c_rows = o; o = align256(o + p->base.L.dup_capacity * 16 * 4);
+    p->c_part = o; o = align256(o + B * RED_BLOCKS * 8);  // float2 [B][RED_BLOCKS] block partials of the per-image scalars
     p->c_total_bytes = o;
     return FGS_OK;
 }
@@ -713,7 +773,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
-    const size_t nh = 3 * (size_t)P * HW;
+    const size_t nh = 3 * (size_t)P * (size_t)(W / 2 + 1) * (size_t)(H / 2 + 1);  // one quadrant, mirrored
     hipLaunchKernelGGL(k_asm_transfer, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st, W, H, P, a.depth_near,
                        a.depth_far, a.focal_depth, inv_ndx, inv_ndy, wavelengths, htab);
     FGS_LAUNCH_CHECK("k_asm_transfer");
@@ -722,15 +782,12 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
                        total);
     FGS_LAUNCH_CHECK("k_asm_accumulate");
     if ((rc = fgs_fft_exec(H, W, B * 3, total, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
-    hipError_t e = hipMemsetAsync(scal, 0, (size_t)B * 4 * sizeof(float), st);
-    if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     const float inv_hw = 1.0f / (float)HW;
-    unsigned gx = (unsigned)((3 * HW + 255) / 256);
-    if (gx > 512) gx = 512;
-    hipLaunchKernelGGL(k_asm_max, dim3(gx, B), dim3(256), 0, st, HW, inv_hw, total, scal);
+    float *pmax = reinterpret_cast<float *>(sc + p.c_part);
+    hipLaunchKernelGGL(k_asm_max, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, inv_hw, total, pmax);
     FGS_LAUNCH_CHECK("k_asm_max");
     hipLaunchKernelGGL(k_asm_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, inv_hw,
-                       a.background[0], a.background[1], a.background[2], total, scal, out_rgb);
+                       a.background[0], a.background[1], a.background[2], total, pmax, scal, out_rgb);
     FGS_LAUNCH_CHECK("k_asm_output");
     fgs_stage_end(ST_FIELD_FWD, st);
     return FGS_OK;
@@ -759,24 +816,25 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     float2 *gtot = reinterpret_cast<float2 *>(sc + p.c_acc);
     const float inv_hw = 1.0f / (float)HW;
     fgs_stage_begin(ST_FIELD_BWD, st);
-    hipError_t e = hipMemsetAsync(g_wavelengths, 0, 3 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(scal + B, 0, 2 * (size_t)B * sizeof(float), st);
-    if (e != hipSuccess) { fgs_set_error("memset g_wavelengths: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     const dim3 gpix((unsigned)((HW + 255) / 256), B);
-    hipLaunchKernelGGL(k_asm_output_bwd1, gpix, dim3(256), 0, st, HW, inv_hw, a.background[0], a.background[1],
-                       a.background[2], total, scal, g_rgb);
+    float2 *psum = reinterpret_cast<float2 *>(sc + p.c_part);
+    float *pwl = reinterpret_cast<float *>(sc + p.c_part + (size_t)B * RED_BLOCKS * 8);
+    hipLaunchKernelGGL(k_asm_output_bwd1, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, inv_hw, a.background[0],
+                       a.background[1], a.background[2], total, scal, g_rgb, psum);
     FGS_LAUNCH_CHECK("k_asm_output_bwd1");
     hipLaunchKernelGGL(k_asm_output_bwd2, gpix, dim3(256), 0, st, HW, inv_hw, a.background[0], a.background[1],
-                       a.background[2], total, scal, g_rgb, gtot);
+                       a.background[2], total, scal, psum, g_rgb, gtot);
     FGS_LAUNCH_CHECK("k_asm_output_bwd2");
     // adjoint of the unnormalised inverse FFT is the unnormalised forward FFT
     if ((rc = fgs_fft_exec(H, W, B * 3, gtot, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
-    hipLaunchKernelGGL(k_asm_accumulate_bwd, dim3((unsigned)(((size_t)B * HW + 255) / 256), 3), dim3(256), 0, st, W, H,
-                       B, P, a.depth_near, a.depth_far, a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, field,
-                       g_wavelengths);
+    const unsigned nwl = (unsigned)(((size_t)B * HW + 255) / 256);
+    hipLaunchKernelGGL(k_asm_accumulate_bwd, dim3(nwl, 3), dim3(256), 0, st, W, H, B, P, a.depth_near, a.depth_far,
+                       a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, field, pwl);
     FGS_LAUNCH_CHECK("k_asm_accumulate_bwd");
+    hipLaunchKernelGGL(k_asm_wavelength_grad, dim3(3), dim3(256), 0, st, nwl, pwl, g_wavelengths);
+    FGS_LAUNCH_CHECK("k_asm_wavelength_grad");
     // adjoint of the forward FFT is the unnormalised inverse FFT
     if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
     fgs_stage_end(ST_FIELD_BWD, st);
@@ -845,14 +903,11 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
     FGS_LAUNCH_CHECK("k_wave_splat");
     fgs_stage_end(ST_SPLAT_FWD, st);
     fgs_stage_begin(ST_FIELD_FWD, st);
-    hipError_t e = hipMemsetAsync(scal, 0, (size_t)B * 4 * sizeof(float), st);
-    if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
-    unsigned gx = (unsigned)((3 * HW + 255) / 256);
-    if (gx > 512) gx = 512;
-    hipLaunchKernelGGL(k_wave_max, dim3(gx, B), dim3(256), 0, st, HW, field, scal);
+    float *pmax = reinterpret_cast<float *>(sc + p.c_part);
+    hipLaunchKernelGGL(k_wave_max, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, field, pmax);
     FGS_LAUNCH_CHECK("k_wave_max");
     hipLaunchKernelGGL(k_wave_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, p.w.background[0],
-                       p.w.background[1], p.w.background[2], field, dw, scal, out_rgb, out_depth);
+                       p.w.background[1], p.w.background[2], field, dw, pmax, scal, out_rgb, out_depth);
     FGS_LAUNCH_CHECK("k_wave_output");
     fgs_stage_end(ST_FIELD_FWD, st);
     return FGS_OK;
@@ -880,14 +935,13 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
     float2 *gdw = reinterpret_cast<float2 *>(sc + p.c_gdw);
     float *rows = reinterpret_cast<float *>(sc + p.c_rows);
     fgs_stage_begin(ST_FIELD_BWD, st);
-    hipError_t e = hipMemsetAsync(scal + B, 0, 2 * (size_t)B * sizeof(float), st);
-    if (e != hipSuccess) { fgs_set_error("memset scal: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     const dim3 gpix((unsigned)((HW + 255) / 256), B);
-    hipLaunchKernelGGL(k_wave_output_bwd1, gpix, dim3(256), 0, st, HW, p.w.background[0], p.w.background[1],
-                       p.w.background[2], field, scal, g_rgb);
+    float2 *psum = reinterpret_cast<float2 *>(sc + p.c_part);
+    hipLaunchKernelGGL(k_wave_output_bwd1, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, p.w.background[0],
+                       p.w.background[1], p.w.background[2], field, scal, g_rgb, psum);
     FGS_LAUNCH_CHECK("k_wave_output_bwd1");
     hipLaunchKernelGGL(k_wave_output_bwd2, gpix, dim3(256), 0, st, HW, p.w.background[0], p.w.background[1],
-                       p.w.background[2], field, dw, scal, g_rgb, g_depth, gfield, gdw);
+                       p.w.background[2], field, dw, scal, psum, g_rgb, g_depth, gfield, gdw);
     FGS_LAUNCH_CHECK("k_wave_output_bwd2");
     fgs_stage_end(ST_FIELD_BWD, st);
     fgs_stage_begin(ST_SPLAT_BWD, st);
