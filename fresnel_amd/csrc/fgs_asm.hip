@@ -26,6 +26,7 @@ namespace {
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;
 constexpr int ACH = 64;
 constexpr int ASM_FWD_PARTS = 4;  // list parts (waves) per (image, plane, tile) in the forward splat
+constexpr uint32_t ASM_ONE_WAVE_LISTS = 24576;  // from this many lists per launch on: one wave per list in the forward splat (measured: 16 384 lists 0.105 ms with four parts vs 0.139 with one, 131 072 lists 0.83 vs 0.345)
 constexpr int RED_BLOCKS = 128;   // blocks (= partials) per image of the per-image scalar reductions, see below
 
 struct AsmPlan {
@@ -36,7 +37,8 @@ struct AsmPlan {
     size_t v_field;      // float2 [B][P][3][H][W]  plane fields -> spectra (kept for the backward)
     size_t v_htab;       // float2 [3][P][H][W]     transfer functions
     size_t v_total;      // float2 [B][3][H][W]     total field U (unnormalised inverse FFT)
-    size_t v_scal;       // float  [3][B]           per-image maxval | dL/dM | number of maxima
+    size_t v_scal;       // float  [B]              per-image maxval
+    size_t v_ccs;        // float  [B][N][8]        phasors c cos(phi), c sin(phi) per channel (k_asm_phasors)
     size_t v_total_bytes;
     // scratch sections (after base.s_total)
     size_t c_acc;        // float2 [B][3][H][W]
@@ -71,6 +73,7 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     p->v_htab = o; o = align256(o + 3 * P * HW * 8);
     p->v_total = o; o = align256(o + B * 3 * HW * 8);
     p->v_scal = o; o = align256(o + B * 4 * 4);
+    p->v_ccs = o; o = align256(o + B * (size_t)a->num_gaussians * 8 * 4);
     p->v_total_bytes = o;
     p->work_big = p->work_small = 0;
     if (need_fft) {
@@ -137,26 +140,50 @@ __global__ __launch_bounds__(256) void k_asm_transfer(int W, int H, int P, float
     }
 }
 
+// ccs[g] = (c_r cos phi_r, c_g cos phi_g, c_b cos phi_b, c_r sin phi_r | c_g sin phi_g, c_b sin phi_b, 0, 0)  DR:1274-1283
+__global__ __launch_bounds__(256) void k_asm_phasors(uint32_t total, int phase_channels, const float *__restrict__ color,
+                                                     const float *__restrict__ phase, float *__restrict__ ccs) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    float cc[3], cs[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float ph = phase_channels == 3 ? phase[3 * (size_t)g + c] : phase[g];
+        float sn, co;
+        sincosf(ph, &sn, &co);
+        const float col = color[3 * (size_t)g + c];
+        cc[c] = col * co; cs[c] = col * sn;
+    }
+    float4 *o = reinterpret_cast<float4 *>(ccs + (size_t)g * 8);
+    o[0] = make_float4(cc[0], cc[1], cc[2], cs[0]);
+    o[1] = make_float4(cs[1], cs[2], 0.0f, 0.0f);
+}
+
 // One wave per (image, plane, tile); lane = one pixel of each of the four 8x8 sub-tiles.
 // BWD = false: accumulate field += a * c * (cos phi, sin phi) with a = exp(-m/2) * opacity (DR:1263-1283).
 // BWD = true : read the field gradient and reduce the twelve per-Gaussian sums into a gradient row.
 // WAVE = true (WaveFieldRenderer, DR:832-891): a single layer, and additionally the amplitude-weighted
 // depth sums (sum a*depth, sum a) in `dw`; gradient rows are 16 floats wide (slot 12 = dL/ddepth).
-template <bool BWD, bool WAVE>
-__global__ __launch_bounds__(BWD ? 64 : 64 * ASM_FWD_PARTS) void k_asm_splat(
-    uint32_t tiles, uint32_t tiles_x, uint32_t P, uint32_t W, uint32_t H, uint32_t dcap, int phase_channels,
+// NP = waves per block of the forward (list parts), 1 for the backward.  `ccs` = the Gaussians' phasors c cos(phi),
+// c sin(phi) per channel ([B*N][8] floats, k_asm_phasors): the accurate sincosf runs once per Gaussian instead of three
+// times per (tile, plane) duplicate at staging time, forward and backward.
+template <bool BWD, bool WAVE, int NP>
+__global__ __launch_bounds__(64 * NP) void k_asm_splat(
+    uint32_t tiles, uint32_t tiles_x, uint32_t P, uint32_t W, uint32_t H, uint32_t dcap,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
-    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
+    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ ccs,
     const uint32_t *__restrict__ dup_off, float2 *__restrict__ field, float *__restrict__ grad_rows,
     float2 *__restrict__ dw, const uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg_off,
     const uint32_t *__restrict__ seg_tile, uint32_t seg_len) {
     // Forward: the splat is a plain sum, so the list is cut into NP parts, one per wave (own LDS staging, no block
-    // barrier in the walk) and the partial fields are added in part order at the end -- the launch is latency-bound
-    // by its longest lists.  Backward: one wave per depth-segment unit.
-    constexpr int NP = BWD ? 1 : ASM_FWD_PARTS;
+    // barrier in the walk) and the partial fields are added in part order at the end -- a launch of few, long lists is
+    // latency-bound by the longest (NP = 4); a launch with enough lists to fill the chip (the ASM renderer's (image,
+    // plane, tile) lists of a few dozen entries) runs one wave per list with 4 KB of LDS instead of 35 (NP = 1).
+    // Backward: one wave per depth-segment unit.
+    static_assert(!BWD || NP == 1, "the backward is one wave per unit");
     __shared__ float4 sh0[NP * ACH], sh1[NP * ACH], sh2[NP * ACH], sh3[NP * ACH];
     __shared__ uint32_t shm[NP * ACH], she[BWD ? ACH : 1];
-    __shared__ float part[BWD ? 1 : (NP - 1) * (WAVE ? 32 : 24) * 64];
+    __shared__ float part[NP == 1 ? 1 : (NP - 1) * (WAVE ? 32 : 24) * 64];
     __shared__ __attribute__((aligned(16))) float red[BWD ? 13 : 1][80];  // wave_sum_transposed scratch (backward)
     // Forward: one block per (image, plane, tile), longest lists first.  Backward: the splat carries no state
     // along a list, so the work unit is a depth segment of FGS_SEG list entries (unit list of k_tile_order;
@@ -216,20 +243,13 @@ __global__ __launch_bounds__(BWD ? 64 : 64 * ASM_FWD_PARTS) void k_asm_splat(
                 const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
                 she[lane] = dup_off[gid] + (ty - ty0) * (tx1 - tx0 + 1) + (tx - tx0);
             }
-            float cc[3], cs[3];
-            const float col[3] = {q1.z, q1.w, q2.x};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float ph = phase_channels == 3 ? phase[3 * (size_t)gid + c] : phase[gid];
-                float sn, co;
-                sincosf(ph, &sn, &co);
-                cc[c] = col[c] * co; cs[c] = col[c] * sn;
-            }
+            const float4 *pz = reinterpret_cast<const float4 *>(ccs + (size_t)gid * 8);
+            const float4 z0 = pz[0], z1 = pz[1];  // cc[0..2], cs[0] | cs[1..2]
             sh0[wofs + lane] = make_float4(q0.x, q0.y, q0.z, q0.w);                       // u, v, ca, cbc
             sh1[wofs + lane] = make_float4(q1.x, q1.y, __uint_as_float(bx0 | ((bx1 - bx0) << 16)),
                                     __uint_as_float(by0 | ((by1 - by0) << 16)));   // cd, op, bbx', bby'
-            sh2[wofs + lane] = make_float4(cc[0], cc[1], cc[2], cs[0]);
-            sh3[wofs + lane] = make_float4(cs[1], cs[2], q2.y, 0.0f);  // .z = depth (WAVE)
+            sh2[wofs + lane] = z0;
+            sh3[wofs + lane] = make_float4(z1.x, z1.y, q2.y, 0.0f);  // .z = depth (WAVE)
         }
         __builtin_amdgcn_wave_barrier();  // wave-private staging: one wave's LDS instructions execute in order
         for (uint32_t j = 0; j < n; ++j) {
@@ -685,7 +705,7 @@ __global__ __launch_bounds__(256) void k_wave_output_bwd2(size_t HW, float bg0, 
 struct WavePlan {
     FgsWaveDims w;
     FgsPlan base;
-    size_t HW, v_field, v_dw, v_scal, v_total_bytes, c_gfield, c_gdw, c_rows, c_part, c_total_bytes;
+    size_t HW, v_field, v_dw, v_scal, v_ccs, v_total_bytes, c_gfield, c_gdw, c_rows, c_part, c_total_bytes;
 };
 
 int make_wave_plan(const FgsWaveDims *w, WavePlan *p) {
@@ -705,6 +725,7 @@ int make_wave_plan(const FgsWaveDims *w, WavePlan *p) {
     p->v_field = o; o = align256(o + B * 3 * HW * 8);
     p->v_dw = o; o = align256(o + B * HW * 8);
     p->v_scal = o; o = align256(o + B * 4 * 4);
+    p->v_ccs = o; o = align256(o + B * (size_t)w->num_gaussians * 8 * 4);
     p->v_total_bytes = o;
     o = p->base.s_total;
     p->c_gfield = o; o = align256(o + B * 3 * HW * 8);
@@ -758,15 +779,21 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     float2 *total = reinterpret_cast<float2 *>(sv + p.v_total);
     float *scal = reinterpret_cast<float *>(sv + p.v_scal);
     const uint32_t grid = (uint32_t)B * P * p.base.tiles;
-    hipLaunchKernelGGL((k_asm_splat<false, false>), dim3(grid), dim3(64 * ASM_FWD_PARTS), 0, st, (uint32_t)p.base.tiles,
-                       (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
-                       (uint32_t)p.base.L.dup_capacity, a.phase_channels,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
-                       reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, (float2 *)nullptr,
-                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
+    float *ccs = reinterpret_cast<float *>(sv + p.v_ccs);
+    const uint32_t ngauss = (uint32_t)B * (uint32_t)a.num_gaussians;
+    hipLaunchKernelGGL(k_asm_phasors, dim3((ngauss + 255) / 256), dim3(256), 0, st, ngauss, a.phase_channels, color, phase, ccs);
+    FGS_LAUNCH_CHECK("k_asm_phasors");
+#define FGS_SPLAT_FWD(WV, NPV, DW)                                                                                     \
+    hipLaunchKernelGGL((k_asm_splat<false, WV, NPV>), dim3(grid), dim3(64 * NPV), 0, st, (uint32_t)p.base.tiles,       \
+                       (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,                              \
+                       (uint32_t)p.base.L.dup_capacity, reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),  \
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),                                       \
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),                                      \
+                       reinterpret_cast<const float *>(sv + p.base.L.rec), ccs,                                        \
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, DW,         \
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u)
+    // one wave per list once the launch has enough lists to fill the chip, else four list parts per list
+    if (grid >= ASM_ONE_WAVE_LISTS) FGS_SPLAT_FWD(false, 1, (float2 *)nullptr); else FGS_SPLAT_FWD(false, ASM_FWD_PARTS, (float2 *)nullptr);
     FGS_LAUNCH_CHECK("k_asm_splat");
     fgs_stage_end(ST_SPLAT_FWD, st);
     fgs_stage_begin(ST_FIELD_FWD, st);
@@ -841,13 +868,13 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     fgs_stage_begin(ST_SPLAT_BWD, st);
     const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units
     float *rows = reinterpret_cast<float *>(sc + p.base.s_grows);
-    hipLaunchKernelGGL((k_asm_splat<true, false>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+    hipLaunchKernelGGL((k_asm_splat<true, false, 1>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
-                       (uint32_t)p.base.L.dup_capacity, a.phase_channels,
+                       (uint32_t)p.base.L.dup_capacity,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
-                       reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
+                       reinterpret_cast<const float *>(sv + p.base.L.rec), reinterpret_cast<const float *>(sv + p.v_ccs),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows, (float2 *)nullptr,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.counters),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),
@@ -891,15 +918,13 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
     float2 *field = reinterpret_cast<float2 *>(sv + p.v_field);
     float2 *dw = reinterpret_cast<float2 *>(sv + p.v_dw);
     float *scal = reinterpret_cast<float *>(sv + p.v_scal);
-    const uint32_t grid = (uint32_t)B * p.base.tiles;
-    hipLaunchKernelGGL((k_asm_splat<false, true>), dim3(grid), dim3(64 * ASM_FWD_PARTS), 0, st, (uint32_t)p.base.tiles,
-                       (uint32_t)p.base.L.tiles_x, 1u, (uint32_t)W, (uint32_t)H, (uint32_t)p.base.L.dup_capacity,
-                       p.w.phase_channels, reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
-                       reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, (float *)nullptr, dw,
-                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
+    const uint32_t grid = (uint32_t)B * p.base.tiles, P = 1;
+    float *ccs = reinterpret_cast<float *>(sv + p.v_ccs);
+    const uint32_t ngauss = (uint32_t)B * (uint32_t)p.w.num_gaussians;
+    hipLaunchKernelGGL(k_asm_phasors, dim3((ngauss + 255) / 256), dim3(256), 0, st, ngauss, p.w.phase_channels, color, phase, ccs);
+    FGS_LAUNCH_CHECK("k_asm_phasors");
+    if (grid >= ASM_ONE_WAVE_LISTS) FGS_SPLAT_FWD(true, 1, dw); else FGS_SPLAT_FWD(true, ASM_FWD_PARTS, dw);
+#undef FGS_SPLAT_FWD
     FGS_LAUNCH_CHECK("k_wave_splat");
     fgs_stage_end(ST_SPLAT_FWD, st);
     fgs_stage_begin(ST_FIELD_FWD, st);
@@ -946,12 +971,12 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
     fgs_stage_end(ST_FIELD_BWD, st);
     fgs_stage_begin(ST_SPLAT_BWD, st);
     const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units
-    hipLaunchKernelGGL((k_asm_splat<true, true>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
+    hipLaunchKernelGGL((k_asm_splat<true, true, 1>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, 1u, (uint32_t)W, (uint32_t)H, (uint32_t)p.base.L.dup_capacity,
-                       p.w.phase_channels, reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.tile_order),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),
-                       reinterpret_cast<const float *>(sv + p.base.L.rec), phase,
+                       reinterpret_cast<const float *>(sv + p.base.L.rec), reinterpret_cast<const float *>(sv + p.v_ccs),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), gfield, rows, gdw,
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.counters),
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),
