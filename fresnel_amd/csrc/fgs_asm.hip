@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
     __shared__ float4 sh0[NP * ACH], sh1[NP * ACH], sh2[NP * ACH], sh3[NP * ACH];
     __shared__ uint32_t shm[NP * ACH], she[BWD ? ACH : 1];
     __shared__ float part[NP == 1 ? 1 : (NP - 1) * (WAVE ? 32 : 24) * 64];
-    __shared__ __attribute__((aligned(16))) float red[BWD ? 13 : 1][80];  // wave_sum_transposed scratch (backward)
+    __shared__ __attribute__((aligned(16))) float red[BWD ? 13 * FGS_RED_PITCH : 4];  // wave_sum_addtid scratch (backward)
     // Forward: one block per (image, plane, tile), longest lists first.  Backward: the splat carries no state
     // along a list, so the work unit is a depth segment of FGS_SEG list entries (unit list of k_tile_order;
     // the grid is sized from the capacity, surplus blocks leave at once) -- balanced however uneven the lists.
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
                 constexpr int NV = WAVE ? 13 : 12;
                 float vals[NV] = {v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_cc[0], v_cc[1], v_cc[2], v_cs[0], v_cs[1], v_cs[2]};
                 if (WAVE) vals[NV - 1] = v_dep;
-                const float tot = wave_sum_transposed<NV>(red, vals, lane);
+                const float tot = wave_sum_addtid<NV>(red, vals, lane);  // conflict-free parking, as in the blend backward
                 const uint32_t e = she[j];
                 if ((lane & 3u) == 3u && lane < 4u * NV && e < dcap)
                     grad_rows[(size_t)e * (WAVE ? 16 : FGS_GROW_FLOATS) + (lane >> 2)] = tot;

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
 //
 // Gradient accumulation is atomic-free and deterministic: each lane sums its (up to four)
 // pixels' contributions to the ten per-Gaussian sums, the wave adds them up through LDS in a fixed
-// order (wave_sum_transposed, fgs_wave.h) and ten lanes store ONE 48-byte row at the duplicate's
+// order (wave_sum10_addtid, fgs_wave.h) and ten lanes store ONE 48-byte row at the duplicate's
 // emission slot (dup_off[gaussian] + index of this tile inside the Gaussian's tile rectangle).  A
 // Gaussian's rows are contiguous and k_project_bwd sums them in a fixed order.
 //
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     v_r += w * gr[s]; v_g += w * gg[s]; v_b += w * gb[s]; v_d += w * gd[s];
                 }
             }
-            // ---- reduce the ten sums over the 64 lanes (wave_sum_transposed, fgs_wave.h) and store them straight
+            // ---- reduce the ten sums over the 64 lanes (wave_sum10_addtid, fgs_wave.h) and store them straight
             // into this duplicate's gradient row: no atomics, fixed order, bitwise reproducible ----
             {
                 const float vals[10] = {v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d};

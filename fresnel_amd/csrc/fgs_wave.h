@@ -48,33 +48,12 @@ __device__ __forceinline__ void quad_sum1(float &a) {
                  "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n" : "+v"(a));
 }
 
-// Sum NV per-lane values over the 64 lanes of a wave through LDS, transposed (NV <= 16):
-//   every lane parks its NV partial sums in red[value][16-lane part][16 + 4 pad]; lane 4 k + p then adds the 16
-//   partials of part p of value k (four ds_read_b128, 15 adds) and two DPP steps fold the four parts.
-// Returns, in lanes with (lane & 3) == 3 and lane < 4 NV, the total of value lane >> 2 (other lanes: junk).
-// Cost ~10 LDS stores + 15 plain adds + 2 DPP adds per call, against NV x 6 DPP adds (4.3 issue cycles each on
-// gfx950) for a full DPP tree.  One wave's LDS instructions execute in order, so no barrier is needed; `red` is
-// private to the calling wave.
-template <int NV>
-__device__ __forceinline__ float wave_sum_transposed(float (*red)[80], const float (&v)[NV], uint32_t lane) {
-    static_assert(NV <= 16, "four lanes per value");
-    float *wp = &red[0][(lane >> 4) * 20u + (lane & 15u)];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) wp[k * 80] = v[k];
-    __builtin_amdgcn_wave_barrier();
-    float tot = 0.0f;
-    if (lane < 4u * NV) {
-        const float4 *src = reinterpret_cast<const float4 *>(&red[lane >> 2][(lane & 3u) * 20u]);
-        const float4 s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
-        tot = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
-              (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-        quad_sum1(tot);
-    }
-    __builtin_amdgcn_wave_barrier();
-    return tot;
-}
-
-// ---- the same reduction with ds_write_addtid_b32 parking (blend backward) -------------------------------------
+// Sum NV per-lane values over the 64 lanes of a wave through LDS, transposed (NV <= 16): every lane parks its NV
+// partial sums; lane 4 k + p then adds the 16 partials of part p of value k (four ds_read_b128, 15 adds) and two DPP
+// steps fold the four parts -- ~NV LDS stores + 15 plain adds + 2 DPP adds per call, against NV x 6 DPP adds (4.3 issue
+// cycles each on gfx950) for a full DPP tree.  One wave's LDS instructions execute in order, so no barrier is needed;
+// the scratch is private to the calling wave.
+// ---- parking with ds_write_addtid_b32 ----------------------------------------------------------------------------
 // Layout: value k at dword 68 k, lane l's partial at 68 k + l (ds_write_addtid_b32: address = M0 + offset + 4 lane,
 // no address VGPR, 2 store-path cycles per instruction instead of 4-6, MI355X_MICROARCH.md "LDS").  Lane 4 k + p then
 // reads the 16 partials [16 p, 16 p + 16) of value k with four ds_read_b128; with the 68-dword pitch the 16 lanes of
@@ -113,6 +92,34 @@ __device__ __forceinline__ void addtid_park11(uint32_t lds_base, const float (&v
                  : "memory");
 }
 
+// twelve / thirteen values (ASM / wave splat backward).  ONE asm block per variant: M0 must not be live across
+// compiler-scheduled code (every DS instruction reads it).
+#define FGS_PARK12_BODY                                                                              \
+    "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %2 offset:272\n\t"                       \
+    "ds_write_addtid_b32 %3 offset:544\n\tds_write_addtid_b32 %4 offset:816\n\t"                     \
+    "ds_write_addtid_b32 %5 offset:1088\n\tds_write_addtid_b32 %6 offset:1360\n\t"                   \
+    "ds_write_addtid_b32 %7 offset:1632\n\tds_write_addtid_b32 %8 offset:1904\n\t"                   \
+    "ds_write_addtid_b32 %9 offset:2176\n\tds_write_addtid_b32 %10 offset:2448\n\t"                  \
+    "ds_write_addtid_b32 %11 offset:2720\n\tds_write_addtid_b32 %12 offset:2992\n\t"
+__device__ __forceinline__ void addtid_park12(uint32_t lds_base, const float (&v)[12]) {
+    uint32_t m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %13\n\ts_nop 0\n\t" FGS_PARK12_BODY "s_mov_b32 m0, %0"
+                 : "=&s"(m0_save)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+                   "v"(v[9]), "v"(v[10]), "v"(v[11]), "s"(lds_base)
+                 : "memory");
+}
+__device__ __forceinline__ void addtid_park13(uint32_t lds_base, const float (&v)[13]) {
+    uint32_t m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %14\n\ts_nop 0\n\t" FGS_PARK12_BODY
+                 "ds_write_addtid_b32 %13 offset:3264\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_save)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+                   "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "s"(lds_base)
+                 : "memory");
+}
+#undef FGS_PARK12_BODY
+
 // Sum ten per-lane values over the wave; returns, in lanes with (lane & 3) == 3 and lane < 40, the total of value
 // lane >> 2 (other lanes: junk).  `red` = FGS_RED_PITCH * 10 floats of LDS private to the calling wave, 16-B aligned.
 __device__ __forceinline__ float wave_sum_addtid_finish(const float *red, uint32_t lane, uint32_t nv) {
@@ -131,6 +138,14 @@ __device__ __forceinline__ float wave_sum_addtid_finish(const float *red, uint32
 __device__ __forceinline__ float wave_sum10_addtid(float *red, const float (&v)[10], uint32_t lane) {
     addtid_park10((uint32_t)(uintptr_t)(fgs_lds_float *)red, v);
     return wave_sum_addtid_finish(red, lane, 10u);
+}
+// NV = 12 | 13 values (ASM / wave splat backward); `red` = FGS_RED_PITCH * NV floats
+template <int NV>
+__device__ __forceinline__ float wave_sum_addtid(float *red, const float (&v)[NV], uint32_t lane) {
+    static_assert(NV == 12 || NV == 13, "park helpers written for 12 / 13 values");
+    if constexpr (NV == 12) addtid_park12((uint32_t)(uintptr_t)(fgs_lds_float *)red, v);
+    else addtid_park13((uint32_t)(uintptr_t)(fgs_lds_float *)red, v);
+    return wave_sum_addtid_finish(red, lane, (uint32_t)NV);
 }
 // eleven values (phase backward); `red` = FGS_RED_PITCH * 11 floats
 __device__ __forceinline__ float wave_sum11_addtid(float *red, const float (&v)[11], uint32_t lane) {
