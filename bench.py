@@ -340,8 +340,8 @@ def main():
         kernel_names = {"composite_fwd": "k_blend_fwd_parts" if args.workload != "config4" and not args.saturation_skip else "k_composite_fwd",
                         "composite_bwd": "k_composite_bwd_phase" if args.workload == "config4" else "k_composite_bwd",
                         "splat_fwd": "k_asm_splat<false>", "splat_bwd": "k_asm_splat<true>",
-                        "field_fwd": "hipFFT C2C + k_asm_transfer/accumulate/max/output",
-                        "field_bwd": "k_asm_output_bwd + hipFFT C2C + k_asm_accumulate_bwd"}
+                        "field_fwd": "rocFFT rows + k_colfft_fwd (column FFT x transfer function, plane sum) + k_asm_transfer/max/output",
+                        "field_bwd": "k_asm_output_bwd + k_colfft_bwd (gAcc conj(H), inverse column FFT) + rocFFT rows"}
         run_key = f"{args.workload}_{args.distribution}_b{per_gpu}"
         roofline = {"kernel": kernel_names[dom_stage], "stage": dom_stage}
         roofline.update(stage_roofline(dom_stage))

@@ -39,6 +39,8 @@ struct AsmPlan {
     size_t v_total;      // float2 [B][3][H][W]     total field U (unnormalised inverse FFT)
     size_t v_scal;       // float  [B]              per-image maxval
     size_t v_ccs;        // float  [B][N][8]        phasors c cos(phi), c sin(phi) per channel (k_asm_phasors)
+    size_t v_tw;         // float2 [H/2]            twiddles of the column-fused transforms
+    int col_logn;        // log2(H) when the column direction runs in k_colfft_* (H = 64 ... 1024, a power of two), else 0
     size_t v_total_bytes;
     // scratch sections (after base.s_total)
     size_t c_acc;        // float2 [B][3][H][W]
@@ -74,10 +76,15 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     p->v_total = o; o = align256(o + B * 3 * HW * 8);
     p->v_scal = o; o = align256(o + B * 4 * 4);
     p->v_ccs = o; o = align256(o + B * (size_t)a->num_gaussians * 8 * 4);
+    p->v_tw = o; o = align256(o + 512 * 8);
+    p->col_logn = 0;
+    for (int lg = 6; lg <= 10; ++lg)
+        if (a->height == (1 << lg)) p->col_logn = lg;
     p->v_total_bytes = o;
     p->work_big = p->work_small = 0;
     if (need_fft) {
-        int r2 = fgs_fft_work_bytes(a->height, a->width, (int)(B * P * 3), &p->work_big);
+        int r2 = p->col_logn ? fgs_fft_rows_work_bytes(a->width, (int)(B * P * 3) * a->height, &p->work_big)
+                             : fgs_fft_work_bytes(a->height, a->width, (int)(B * P * 3), &p->work_big);
         if (r2) return r2;
         r2 = fgs_fft_work_bytes(a->height, a->width, (int)(B * 3), &p->work_small);
         if (r2) return r2;
@@ -385,6 +392,223 @@ __device__ __forceinline__ float2 block_sum2_256(float a, float b) {  // fixed o
 __device__ __forceinline__ float image_max(const float *__restrict__ pmax, int b) {
     static_assert(RED_BLOCKS <= 256, "one partial per thread");
     return block_max_256(threadIdx.x < RED_BLOCKS ? pmax[(size_t)b * RED_BLOCKS + threadIdx.x] : 0.0f);
+}
+
+// ---- column-fused 2-D transforms (power-of-two heights) ------------------------------------------------------------
+// rocFFT's 2-D C2C transform of the B*P*3 plane fields is a row kernel (0.30 ms for 805 MB at 8 images, 5.4 TB/s) and a
+// column kernel (0.80 ms, 2 TB/s), followed here by k_asm_accumulate, which reads the spectra once more (0.23 ms).  For
+// H = 64 ... 1024 the column direction is done by our own kernels instead, fused with what follows / precedes it:
+//   forward   rocFFT 1-D rows, then k_colfft_fwd: per (image, channel, tile of TC columns) and plane -- load the H x TC
+//             tile into LDS (rows of TC complex: 128-byte segments), radix-4 decimation-in-frequency FFT down the columns
+//             (output in bit-reversed row order, undone by the store addresses), store the spectrum F (the backward needs
+//             it for dL/dlambda), multiply by H_pc and accumulate over the planes in registers; acc_c is written once;
+//   backward  k_colfft_bwd: gF = gAcc conj(H_pc) per plane (and the dL/dlambda terms from the saved F) straight into LDS
+//             in bit-reversed row order, radix-4 decimation-in-time inverse FFT (natural order out), store; then rocFFT
+//             1-D inverse rows.
+// Both directions: one read and one write of the plane data in the column pass instead of two reads and one write plus
+// the accumulate kernel's pass.  Unnormalised, like hipFFT.  Twiddles w_N^n = exp(-2 pi i n / N) from a global table.
+__global__ __launch_bounds__(256) void k_fft_twiddles(int N, float2 *__restrict__ tw) {
+    for (int n = threadIdx.x; n < N / 2; n += 256) {
+        float sn, cs;
+        sincospif(-2.0f * (float)n / (float)N, &sn, &cs);
+        tw[n] = make_float2(cs, sn);
+    }
+}
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a conj(b)
+
+// In-LDS FFT of the TC columns of x[N][TC], N = 2^LOGN, all NT threads of the block; tw = w_N^n, n < N/2, in LDS.
+// INV = false: forward (e^-), decimation in frequency, natural order in, bit-reversed order out.  INV = true: inverse
+// (e^+), decimation in time, bit-reversed order in, natural order out.  Two radix-2 stages per pass over the data
+// (block sizes M and M/2), one more radix-2 pass when LOGN is odd.  (Consecutive lanes = the TC columns of a row, then
+// the next butterfly: a 32-lane group reads two whole rows, conflict-free except in the last pass.)
+template <int LOGN, int TC, int NT, bool INV>
+__device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *tw) {
+    constexpr int N = 1 << LOGN;
+    auto pair_pass = [&]() {  // block size 2: x[2k] = a + b, x[2k+1] = a - b
+#pragma unroll 1
+        for (int idx = threadIdx.x; idx < (N / 2) * TC; idx += NT) {
+            const int col = idx % TC, k = idx / TC;
+            const float2 a = x[2 * k][col], b = x[2 * k + 1][col];
+            x[2 * k][col] = cadd(a, b); x[2 * k + 1][col] = csub(a, b);
+        }
+        __syncthreads();
+    };
+    auto quad_pass = [&](int M) {  // block sizes M and M / 2 on the points i, i + M/4, i + M/2, i + 3M/4
+        const int Q = M / 4, step = N / M;
+#pragma unroll 1
+        for (int idx = threadIdx.x; idx < (N / 4) * TC; idx += NT) {
+            const int col = idx % TC, q = idx / TC;
+            const int i = q % Q, p0 = (q / Q) * M + i, p1 = p0 + Q, p2 = p0 + 2 * Q, p3 = p0 + 3 * Q;
+            const float2 w1 = tw[i * step], w2 = tw[2 * i * step];  // w_M^i, w_M^(2i) = w_(M/2)^i
+            const float2 a0 = x[p0][col], a1 = x[p1][col], a2 = x[p2][col], a3 = x[p3][col];
+            if (!INV) {
+                const float2 s02 = cadd(a0, a2), s13 = cadd(a1, a3), d02 = csub(a0, a2), d13 = csub(a1, a3);
+                const float2 u2 = cmul(d02, w1), u3 = cmul(make_float2(d13.y, -d13.x), w1);  // w_M^(i + M/4) = -i w_M^i
+                x[p0][col] = cadd(s02, s13);
+                x[p1][col] = cmul(csub(s02, s13), w2);
+                x[p2][col] = cadd(u2, u3);
+                x[p3][col] = cmul(csub(u2, u3), w2);
+            } else {
+                const float2 t1 = cmulc(a1, w2), t3 = cmulc(a3, w2);
+                const float2 r0 = cadd(a0, t1), r1 = csub(a0, t1), r2 = cadd(a2, t3), r3 = csub(a2, t3);
+                const float2 v2 = cmulc(r2, w1), v3t = cmulc(r3, w1);
+                const float2 v3 = make_float2(-v3t.y, v3t.x);  // conj(-i w_M^i) = +i conj(w_M^i)
+                x[p0][col] = cadd(r0, v2);
+                x[p2][col] = csub(r0, v2);
+                x[p1][col] = cadd(r1, v3);
+                x[p3][col] = csub(r1, v3);
+            }
+        }
+        __syncthreads();
+    };
+    if (!INV) {
+#pragma unroll
+        for (int lg = LOGN; lg >= 2; lg -= 2) quad_pass(1 << lg);
+        if (LOGN & 1) pair_pass();
+    } else {
+        if (LOGN & 1) pair_pass();
+#pragma unroll
+        for (int lg = (LOGN & 1) ? 3 : 2; lg <= LOGN; lg += 2) quad_pass(1 << lg);
+    }
+}
+
+template <int LOGN>
+__device__ __forceinline__ int bitrev(int r) { return (int)(__brev((unsigned)r) >> (32 - LOGN)); }
+
+// Eight tile elements per thread: NT = N * TC / 8 threads per block (1024 for a 512 x 16 tile).  (The first version ran
+// 256 threads with 32 elements each: 270 / 458 VGPRs, one wave per SIMD, 1.9 / 1.3 ms at 8 images.)
+constexpr int COLFFT_PER = 8;
+
+template <int NT>
+__device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restrict__ tw_g, int n) {
+    for (int i = threadIdx.x; i < n; i += NT) tw[i] = tw_g[i];
+}
+
+// forward: spectra F (in place, for the backward) and acc[b][c] = sum_p F_pc H_pc.  grid (column tiles, 3, B)
+template <int LOGN, int TC>
+__global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(int W, int P, float2 *__restrict__ field,
+                                                                           const float2 *__restrict__ htab,
+                                                                           const float2 *__restrict__ tw_g,
+                                                                           float2 *__restrict__ acc) {
+    constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
+    __shared__ float2 x[N][TC];
+    __shared__ float2 tw[N / 2];
+    load_twiddles<NT>(tw, tw_g, N / 2);
+    const int c = blockIdx.y, b = blockIdx.z, c0 = blockIdx.x * TC;
+    const size_t HW = (size_t)N * W;
+    const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;  // this thread's elements: rows r0 + e * (NT / TC)
+    const bool live = c0 + col < W;
+    float2 sum[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) sum[e] = make_float2(0.0f, 0.0f);
+    for (int p = 0; p < P; ++p) {
+        float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
+        const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int r = r0 + e * (NT / TC);
+            x[r][col] = live ? f[(size_t)r * W] : make_float2(0.0f, 0.0f);
+        }
+        __syncthreads();
+        lds_fft_columns<LOGN, TC, NT, false>(x, tw);
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const int r = r0 + e * (NT / TC);
+                const size_t o = (size_t)bitrev<LOGN>(r) * W;  // LDS row r holds frequency bitrev(r)
+                const float2 F = x[r][col];
+                f[o] = F;
+                const float2 t = cmul(F, h[o]);
+                sum[e].x += t.x; sum[e].y += t.y;
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        float2 *a = acc + ((size_t)b * 3 + c) * HW + c0 + col;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) a[(size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W] = sum[e];
+    }
+}
+
+// backward: gF_pc = gAcc_c conj(H_pc), inverse-transformed down the columns, over the saved spectra; the block's part of
+// dL/dlambda_c -> pwl[c][block] (see k_asm_accumulate_bwd for the maths).  grid (column tiles, 3, B)
+template <int LOGN, int TC>
+__global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
+    int W, int P, float near_, float far_, float focal, float inv_ndx, float inv_ndy,
+    const float *__restrict__ wavelengths, const float2 *__restrict__ gacc, const float2 *__restrict__ htab,
+    const float2 *__restrict__ tw_g, float2 *__restrict__ field, float *__restrict__ pwl) {
+    constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
+    __shared__ float2 x[N][TC];
+    __shared__ float2 tw[N / 2];
+    __shared__ float wpart[NT / 64];
+    load_twiddles<NT>(tw, tw_g, N / 2);
+    const int c = blockIdx.y, b = blockIdx.z, c0 = blockIdx.x * TC;
+    const size_t HW = (size_t)N * W;
+    const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;
+    const bool live = c0 + col < W;
+    float2 g[PER];
+    float zs[PER];  // sum_p z_p dL/dtheta_p per frequency
+    const float2 *ga = gacc + ((size_t)b * 3 + c) * HW + c0 + col;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        g[e] = live ? ga[(size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W] : make_float2(0.0f, 0.0f);
+        zs[e] = 0.0f;
+    }
+    __syncthreads();  // twiddles
+    for (int p = 0; p < P; ++p) {
+        float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
+        const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
+        const float z = focal - plane_depth(p, P, near_, far_);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int r = r0 + e * (NT / TC);
+            float2 gF = make_float2(0.0f, 0.0f);
+            if (live) {
+                const size_t o = (size_t)bitrev<LOGN>(r) * W;
+                const float2 F = f[o], hh = h[o];
+                const float2 gH = cmul(make_float2(F.x, -F.y), g[e]);      // conj(F) * gAcc
+                zs[e] += -(hh.y * gH.x - hh.x * gH.y) * z;                  // -Im(H * conj(gH)) z_p
+                gF = cmul(g[e], make_float2(hh.x, -hh.y));
+            }
+            x[r][col] = gF;
+        }
+        __syncthreads();
+        lds_fft_columns<LOGN, TC, NT, true>(x, tw);
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const int r = r0 + e * (NT / TC);
+                f[(size_t)r * W] = x[r][col];
+            }
+        }
+        __syncthreads();
+    }
+    // dL/dlambda: sum_k (2 pi sum_p z_p dL/dtheta_pk) d kz_k / d lambda
+    const float wl = wavelengths[c], il = 1.0f / wl;
+    float gl = 0.0f;
+    if (live) {
+        const float fx = fftfreq(c0 + col, W, inv_ndx);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const float fy = fftfreq(bitrev<LOGN>(r0 + e * (NT / TC)), N, inv_ndy);
+            const float kz2 = il * il - fx * fx - fy * fy;
+            const float dkz = kz2 > 0.0f ? -(il * il * il) / sqrtf(kz2) : 0.0f;
+            gl += 6.28318530717958647692f * zs[e] * dkz;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gl += __shfl_xor(gl, o, 64);
+    if ((threadIdx.x & 63u) == 0) wpart[threadIdx.x >> 6] = gl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < NT / 64; ++w) t += wpart[w];
+        pwl[(size_t)c * (gridDim.x * gridDim.z) + blockIdx.z * gridDim.x + blockIdx.x] = t;
+    }
 }
 
 // per-image max of sqrt(|U|^2 + 1e-8) over pixels and channels (DR:1316-1322): block maxima -> pmax[b][block]
@@ -797,17 +1021,37 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     FGS_LAUNCH_CHECK("k_asm_splat");
     fgs_stage_end(ST_SPLAT_FWD, st);
     fgs_stage_begin(ST_FIELD_FWD, st);
-    if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
     const size_t nh = 3 * (size_t)P * (size_t)(W / 2 + 1) * (size_t)(H / 2 + 1);  // one quadrant, mirrored
     hipLaunchKernelGGL(k_asm_transfer, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st, W, H, P, a.depth_near,
                        a.depth_far, a.focal_depth, inv_ndx, inv_ndy, wavelengths, htab);
     FGS_LAUNCH_CHECK("k_asm_transfer");
-    const size_t na = (size_t)B * 3 * HW;
-    hipLaunchKernelGGL(k_asm_accumulate, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, HW, B, P, field, htab,
-                       total);
-    FGS_LAUNCH_CHECK("k_asm_accumulate");
+    if (p.col_logn) {
+        // rows by rocFFT, columns + transfer function + plane sum in one pass of our own (k_colfft_fwd)
+        if ((rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
+        float2 *tw = reinterpret_cast<float2 *>(sv + p.v_tw);
+        hipLaunchKernelGGL(k_fft_twiddles, dim3(1), dim3(256), 0, st, H, tw);
+        FGS_LAUNCH_CHECK("k_fft_twiddles");
+#define FGS_COLFFT_FWD(LG, TCV)                                                                                       \
+    hipLaunchKernelGGL((k_colfft_fwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B),                         \
+                       dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, field, htab, tw, total)
+        switch (p.col_logn) {
+            case 6: FGS_COLFFT_FWD(6, 16); break;
+            case 7: FGS_COLFFT_FWD(7, 16); break;
+            case 8: FGS_COLFFT_FWD(8, 16); break;
+            case 9: FGS_COLFFT_FWD(9, 16); break;
+            default: FGS_COLFFT_FWD(10, 8); break;
+        }
+#undef FGS_COLFFT_FWD
+        FGS_LAUNCH_CHECK("k_colfft_fwd");
+    } else {
+        if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
+        const size_t na = (size_t)B * 3 * HW;
+        hipLaunchKernelGGL(k_asm_accumulate, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, HW, B, P, field, htab,
+                           total);
+        FGS_LAUNCH_CHECK("k_asm_accumulate");
+    }
     if ((rc = fgs_fft_exec(H, W, B * 3, total, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_hw = 1.0f / (float)HW;
     float *pmax = reinterpret_cast<float *>(sc + p.c_part);
@@ -856,14 +1100,39 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     if ((rc = fgs_fft_exec(H, W, B * 3, gtot, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
-    const unsigned nwl = (unsigned)(((size_t)B * HW + 255) / 256);
-    hipLaunchKernelGGL(k_asm_accumulate_bwd, dim3(nwl, 3), dim3(256), 0, st, W, H, B, P, a.depth_near, a.depth_far,
-                       a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, field, pwl);
-    FGS_LAUNCH_CHECK("k_asm_accumulate_bwd");
+    unsigned nwl = (unsigned)(((size_t)B * HW + 255) / 256);
+    if (p.col_logn) {
+        // gF = gAcc conj(H) and the inverse transform down the columns in one pass (k_colfft_bwd), then rocFFT rows
+        const float2 *tw = reinterpret_cast<const float2 *>(sv + p.v_tw);
+#define FGS_COLFFT_BWD(LG, TCV)                                                                                       \
+    do {                                                                                                              \
+        nwl = (unsigned)((W + TCV - 1) / TCV) * (unsigned)B;                                                          \
+        hipLaunchKernelGGL((k_colfft_bwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B),                     \
+                           dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, a.depth_near, a.depth_far, a.focal_depth, \
+                           inv_ndx, inv_ndy, wavelengths, gtot, htab, tw, field, pwl);                                \
+    } while (0)
+        switch (p.col_logn) {
+            case 6: FGS_COLFFT_BWD(6, 16); break;
+            case 7: FGS_COLFFT_BWD(7, 16); break;
+            case 8: FGS_COLFFT_BWD(8, 16); break;
+            case 9: FGS_COLFFT_BWD(9, 16); break;
+            default: FGS_COLFFT_BWD(10, 8); break;
+        }
+#undef FGS_COLFFT_BWD
+        FGS_LAUNCH_CHECK("k_colfft_bwd");
+    } else {
+        hipLaunchKernelGGL(k_asm_accumulate_bwd, dim3(nwl, 3), dim3(256), 0, st, W, H, B, P, a.depth_near, a.depth_far,
+                           a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, field, pwl);
+        FGS_LAUNCH_CHECK("k_asm_accumulate_bwd");
+    }
     hipLaunchKernelGGL(k_asm_wavelength_grad, dim3(3), dim3(256), 0, st, nwl, pwl, g_wavelengths);
     FGS_LAUNCH_CHECK("k_asm_wavelength_grad");
     // adjoint of the forward FFT is the unnormalised inverse FFT
-    if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
+    if (p.col_logn) {
+        if ((rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
+    } else if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) {
+        return rc;
+    }
     fgs_stage_end(ST_FIELD_BWD, st);
     fgs_stage_begin(ST_SPLAT_BWD, st);
     const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units

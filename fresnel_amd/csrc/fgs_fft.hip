@@ -34,8 +34,12 @@ int get_fft_plan(int H, int W, int batch, FftPlan **out) {
     int n[2] = {H, W};
     if (hipfftCreate(&pl->handle) != HIPFFT_SUCCESS) { fgs_set_error("hipfftCreate failed"); return FGS_ELAUNCH; }
     hipfftResult r = hipfftSetAutoAllocation(pl->handle, 0);
-    if (r == HIPFFT_SUCCESS)
-        r = hipfftMakePlanMany(pl->handle, 2, n, nullptr, 1, H * W, nullptr, 1, H * W, HIPFFT_C2C, batch, &pl->work);
+    if (r == HIPFFT_SUCCESS) {
+        if (H > 0)
+            r = hipfftMakePlanMany(pl->handle, 2, n, nullptr, 1, H * W, nullptr, 1, H * W, HIPFFT_C2C, batch, &pl->work);
+        else  // H == 0: `batch` contiguous rows of length W, 1-D transforms (the row pass of a 2-D transform)
+            r = hipfftMakePlanMany(pl->handle, 1, n + 1, nullptr, 1, W, nullptr, 1, W, HIPFFT_C2C, batch, &pl->work);
+    }
     if (r != HIPFFT_SUCCESS) {
         (void)hipfftDestroy(pl->handle);
         fgs_set_error("hipfftMakePlanMany(%dx%d x%d) failed: %d", H, W, batch, (int)r);
@@ -71,3 +75,10 @@ int fgs_fft_work_bytes(int H, int W, int batch, size_t *bytes) {
     *bytes = pl->work;
     return FGS_OK;
 }
+
+// 1-D C2C transforms of `rows` contiguous rows of length W, in place (the row pass of the column-fused 2-D transforms
+// of the angular-spectrum renderer; plans cached like the 2-D ones, key H = 0).
+int fgs_fft_rows_exec(int W, int rows, float2 *data, int dir, void *work, hipStream_t st) {
+    return fgs_fft_exec(0, W, rows, data, dir, work, st);
+}
+int fgs_fft_rows_work_bytes(int W, int rows, size_t *bytes) { return fgs_fft_work_bytes(0, W, rows, bytes); }

@@ -2,7 +2,7 @@
 by scratch/profile_r02_merge.py)."""
 import sys, glob, csv, collections, json
 root, key = sys.argv[1], sys.argv[2]
-KEYS = ('k_composite_bwd_phase', 'k_composite_bwd', 'k_blend_fwd_parts', 'k_composite_fwd', 'k_asm_splat', 'k_asm_accumulate_bwd',
+KEYS = ('k_colfft_fwd', 'k_colfft_bwd', 'k_composite_bwd_phase', 'k_composite_bwd', 'k_blend_fwd_parts', 'k_composite_fwd', 'k_asm_splat', 'k_asm_accumulate_bwd',
         'k_asm_accumulate', 'k_asm_transfer', 'k_project_bwd', 'k_project', 'k_sort_image', 'k_radix_downsweep', 'k_radix_upsweep',
         'k_mask_build', 'k_mask_count', 'k_mask_emit', 'k_row_sum', 'k_tile_pre', 'k_tile_post', 'k_dup_emit')
 
@@ -20,7 +20,7 @@ def match(name):
 
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(lambda: collections.defaultdict(set))
 # field stages of the ASM renderer (config 5): rocFFT's kernels + the spectral elementwise kernels, both directions
-FIELD = ('fft_rtc', 'k_asm_transfer', 'k_asm_accumulate', 'k_asm_max', 'k_asm_output')
+FIELD = ('fft_rtc', 'k_asm_transfer', 'k_asm_accumulate', 'k_asm_max', 'k_asm_output', 'k_colfft', 'k_asm_wavelength_grad', 'k_fft_twiddles')
 field = collections.defaultdict(float)
 for f in glob.glob(root + '/g*/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
