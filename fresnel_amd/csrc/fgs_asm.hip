@@ -41,6 +41,8 @@ struct AsmPlan {
     size_t v_ccs;        // float  [B][N][8]        phasors c cos(phi), c sin(phi) per channel (k_asm_phasors)
     size_t v_tw;         // float2 [H/2]            twiddles of the column-fused transforms
     int col_logn;        // log2(H) when the column direction runs in k_colfft_* (H = 64 ... 1024, a power of two), else 0
+    int col_tc, col_pg;  // its column tile width, and plane groups per image (> 1 for launches that would not fill the chip)
+    size_t c_accp;       // float2 [B][col_pg][3][H][W] partial plane sums (col_pg > 1)
     size_t v_total_bytes;
     // scratch sections (after base.s_total)
     size_t c_acc;        // float2 [B][3][H][W]
@@ -80,6 +82,13 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     p->col_logn = 0;
     for (int lg = 6; lg <= 10; ++lg)
         if (a->height == (1 << lg)) p->col_logn = lg;
+    p->col_tc = p->col_logn == 10 ? 8 : 16;
+    p->col_pg = 1;
+    if (p->col_logn) {
+        const size_t blocks = (size_t)((a->width + p->col_tc - 1) / p->col_tc) * 3 * B;
+        if (blocks < 512) p->col_pg = (int)((512 + blocks - 1) / blocks);
+        if (p->col_pg > (int)P) p->col_pg = (int)P;
+    }
     p->v_total_bytes = o;
     p->work_big = p->work_small = 0;
     if (need_fft) {
@@ -91,7 +100,14 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     }
     o = p->base.s_total;
     p->c_acc = o; o = align256(o + B * 3 * HW * 8);
-    p->c_part = o; o = align256(o + B * RED_BLOCKS * 8 + 3 * ((B * HW + 255) / 256) * 4);
+    {
+        size_t nwl = (B * HW + 255) / 256;  // dL/dlambda partials: per block of k_asm_accumulate_bwd / k_colfft_bwd
+        const size_t nwl2 = (size_t)((a->width + p->col_tc - 1) / p->col_tc) * B * p->col_pg;
+        if (nwl2 > nwl) nwl = nwl2;
+        p->c_part = o; o = align256(o + B * RED_BLOCKS * 8 + 3 * nwl * 4);
+    }
+    p->c_accp = o;
+    if (p->col_pg > 1) o = align256(o + B * p->col_pg * 3 * HW * 8);
     p->c_fftwork = o; o = align256(o + (p->work_big > p->work_small ? p->work_big : p->work_small) + 256);
     p->c_total_bytes = o;
     return FGS_OK;
@@ -489,56 +505,82 @@ __device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restri
 
 // forward: spectra F (in place, for the backward) and acc[b][c] = sum_p F_pc H_pc.  grid (column tiles, 3, B)
 template <int LOGN, int TC>
-__global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(int W, int P, float2 *__restrict__ field,
+__global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(int W, int P, int PG, float2 *__restrict__ field,
                                                                            const float2 *__restrict__ htab,
                                                                            const float2 *__restrict__ tw_g,
                                                                            float2 *__restrict__ acc) {
+    // PG plane groups per image (launches of few images: more blocks, each summing its planes into its own partial
+    // acc[(b, group)]; k_sum_groups adds them up): blockIdx.z = b * PG + group
     constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
     __shared__ float2 x[N][TC];
     __shared__ float2 tw[N / 2];
     load_twiddles<NT>(tw, tw_g, N / 2);
-    const int c = blockIdx.y, b = blockIdx.z, c0 = blockIdx.x * TC;
+    const int c = blockIdx.y, b = blockIdx.z / PG, grp = blockIdx.z - b * PG, c0 = blockIdx.x * TC;
+    const int ppg = (P + PG - 1) / PG, p_lo = grp * ppg, p_hi = min(P, p_lo + ppg);
     const size_t HW = (size_t)N * W;
     const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;  // this thread's elements: rows r0 + e * (NT / TC)
     const bool live = c0 + col < W;
-    float2 sum[PER];
+    float2 sum[PER], nx[PER];  // nx: the next plane's tile elements, in flight while the current plane is transformed
 #pragma unroll
-    for (int e = 0; e < PER; ++e) sum[e] = make_float2(0.0f, 0.0f);
-    for (int p = 0; p < P; ++p) {
+    for (int e = 0; e < PER; ++e) {
+        sum[e] = make_float2(0.0f, 0.0f);
+        nx[e] = (live && p_lo < p_hi) ? field[(((size_t)b * P + p_lo) * 3 + c) * HW + c0 + col + (size_t)(r0 + e * (NT / TC)) * W]
+                                      : make_float2(0.0f, 0.0f);
+    }
+    for (int p = p_lo; p < p_hi; ++p) {
         float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
         const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
 #pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const int r = r0 + e * (NT / TC);
-            x[r][col] = live ? f[(size_t)r * W] : make_float2(0.0f, 0.0f);
-        }
+        for (int e = 0; e < PER; ++e) x[r0 + e * (NT / TC)][col] = nx[e];
         __syncthreads();
+        if (live && p + 1 < p_hi) {
+            const float2 *fn = f + 3 * HW;  // plane p + 1 of this image and channel
+#pragma unroll
+            for (int e = 0; e < PER; ++e) nx[e] = fn[(size_t)(r0 + e * (NT / TC)) * W];
+        }
+        float2 hh[PER];  // this plane's transfer-function values, also in flight during the transform
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            hh[e] = live ? h[(size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W] : make_float2(0.0f, 0.0f);
         lds_fft_columns<LOGN, TC, NT, false>(x, tw);
         if (live) {
 #pragma unroll
             for (int e = 0; e < PER; ++e) {
                 const int r = r0 + e * (NT / TC);
-                const size_t o = (size_t)bitrev<LOGN>(r) * W;  // LDS row r holds frequency bitrev(r)
                 const float2 F = x[r][col];
-                f[o] = F;
-                const float2 t = cmul(F, h[o]);
+                f[(size_t)bitrev<LOGN>(r) * W] = F;  // LDS row r holds frequency bitrev(r)
+                const float2 t = cmul(F, hh[e]);
                 sum[e].x += t.x; sum[e].y += t.y;
             }
         }
         __syncthreads();
     }
     if (live) {
-        float2 *a = acc + ((size_t)b * 3 + c) * HW + c0 + col;
+        float2 *a = acc + ((size_t)blockIdx.z * 3 + c) * HW + c0 + col;
 #pragma unroll
         for (int e = 0; e < PER; ++e) a[(size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W] = sum[e];
     }
+}
+
+// total[b][c][k] = sum over the PG plane groups of part[b][group][c][k] (fixed order)
+__global__ __launch_bounds__(256) void k_sum_groups(size_t n_per_image, int PG, const float2 *__restrict__ part,
+                                                    float2 *__restrict__ total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= n_per_image) return;
+    float2 s = part[((size_t)b * PG) * n_per_image + i];
+    for (int g = 1; g < PG; ++g) {
+        const float2 v = part[((size_t)b * PG + g) * n_per_image + i];
+        s.x += v.x; s.y += v.y;
+    }
+    total[(size_t)b * n_per_image + i] = s;
 }
 
 // backward: gF_pc = gAcc_c conj(H_pc), inverse-transformed down the columns, over the saved spectra; the block's part of
 // dL/dlambda_c -> pwl[c][block] (see k_asm_accumulate_bwd for the maths).  grid (column tiles, 3, B)
 template <int LOGN, int TC>
 __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
-    int W, int P, float near_, float far_, float focal, float inv_ndx, float inv_ndy,
+    int W, int P, int PG, float near_, float far_, float focal, float inv_ndx, float inv_ndy,
     const float *__restrict__ wavelengths, const float2 *__restrict__ gacc, const float2 *__restrict__ htab,
     const float2 *__restrict__ tw_g, float2 *__restrict__ field, float *__restrict__ pwl) {
     constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
@@ -546,7 +588,8 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     __shared__ float2 tw[N / 2];
     __shared__ float wpart[NT / 64];
     load_twiddles<NT>(tw, tw_g, N / 2);
-    const int c = blockIdx.y, b = blockIdx.z, c0 = blockIdx.x * TC;
+    const int c = blockIdx.y, b = blockIdx.z / PG, grp = blockIdx.z - b * PG, c0 = blockIdx.x * TC;
+    const int ppg = (P + PG - 1) / PG, p_lo = grp * ppg, p_hi = min(P, p_lo + ppg);
     const size_t HW = (size_t)N * W;
     const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;
     const bool live = c0 + col < W;
@@ -559,7 +602,8 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
         zs[e] = 0.0f;
     }
     __syncthreads();  // twiddles
-    for (int p = 0; p < P; ++p) {
+    // (requesting the next plane's spectrum before the transform, as the forward does, needs 16 more registers: spills, +10 %)
+    for (int p = p_lo; p < p_hi; ++p) {
         float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
         const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
         const float z = focal - plane_depth(p, P, near_, far_);
@@ -1031,11 +1075,13 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
         // rows by rocFFT, columns + transfer function + plane sum in one pass of our own (k_colfft_fwd)
         if ((rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
         float2 *tw = reinterpret_cast<float2 *>(sv + p.v_tw);
+        float2 *accp = reinterpret_cast<float2 *>(sc + p.c_accp);
+        const int PG = p.col_pg;
         hipLaunchKernelGGL(k_fft_twiddles, dim3(1), dim3(256), 0, st, H, tw);
         FGS_LAUNCH_CHECK("k_fft_twiddles");
 #define FGS_COLFFT_FWD(LG, TCV)                                                                                       \
-    hipLaunchKernelGGL((k_colfft_fwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B),                         \
-                       dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, field, htab, tw, total)
+    hipLaunchKernelGGL((k_colfft_fwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B * PG),                    \
+                       dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, PG, field, htab, tw, PG > 1 ? accp : total)
         switch (p.col_logn) {
             case 6: FGS_COLFFT_FWD(6, 16); break;
             case 7: FGS_COLFFT_FWD(7, 16); break;
@@ -1045,6 +1091,10 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
         }
 #undef FGS_COLFFT_FWD
         FGS_LAUNCH_CHECK("k_colfft_fwd");
+        if (PG > 1) {
+            hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((3 * HW + 255) / 256), B), dim3(256), 0, st, 3 * HW, PG, accp, total);
+            FGS_LAUNCH_CHECK("k_sum_groups");
+        }
     } else {
         if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
         const size_t na = (size_t)B * 3 * HW;
@@ -1106,10 +1156,10 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
         const float2 *tw = reinterpret_cast<const float2 *>(sv + p.v_tw);
 #define FGS_COLFFT_BWD(LG, TCV)                                                                                       \
     do {                                                                                                              \
-        nwl = (unsigned)((W + TCV - 1) / TCV) * (unsigned)B;                                                          \
-        hipLaunchKernelGGL((k_colfft_bwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B),                     \
-                           dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, a.depth_near, a.depth_far, a.focal_depth, \
-                           inv_ndx, inv_ndy, wavelengths, gtot, htab, tw, field, pwl);                                \
+        nwl = (unsigned)((W + TCV - 1) / TCV) * (unsigned)(B * p.col_pg);                                             \
+        hipLaunchKernelGGL((k_colfft_bwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B * p.col_pg),          \
+                           dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, p.col_pg, a.depth_near, a.depth_far,      \
+                           a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, tw, field, pwl);                 \
     } while (0)
         switch (p.col_logn) {
             case 6: FGS_COLFFT_BWD(6, 16); break;
