@@ -82,6 +82,9 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     p->col_logn = 0;
     for (int lg = 6; lg <= 10; ++lg)
         if (a->height == (1 << lg)) p->col_logn = lg;
+#ifdef FGS_NO_COLFFT  // experiment builds: rocFFT's 2-D plans for every frame
+    p->col_logn = 0;
+#endif
     p->col_tc = p->col_logn == 10 ? 8 : 16;
     p->col_pg = 1;
     if (p->col_logn) {
@@ -225,6 +228,8 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
     const uint32_t lane = threadIdx.x & 63u, lx = lane & 7u, ly = lane >> 3;
     const uint32_t wave = NP > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     const uint32_t wofs = wave * ACH;  // this wave's slice of the staging arrays
+    float fx0 = (float)(X0 + lx), fy0 = (float)(Y0 + ly);
+    asm("" : "+v"(fx0), "+v"(fy0));  // hoisted for good
     uint32_t start = ranges[2 * key] + seg * seg_len;
     uint32_t end = BWD ? min(ranges[2 * key + 1], start + seg_len) : ranges[2 * key + 1];
     if (NP > 1) {  // this wave's part of the list (whole chunks)
@@ -268,9 +273,11 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
             }
             const float4 *pz = reinterpret_cast<const float4 *>(ccs + (size_t)gid * 8);
             const float4 z0 = pz[0], z1 = pz[1];  // cc[0..2], cs[0] | cs[1..2]
-            sh0[wofs + lane] = make_float4(q0.x, q0.y, q0.z, q0.w);                       // u, v, ca, cbc
-            sh1[wofs + lane] = make_float4(q1.x, q1.y, __uint_as_float(bx0 | ((bx1 - bx0) << 16)),
-                                    __uint_as_float(by0 | ((by1 - by0) << 16)));   // cd, op, bbx', bby'
+            // conic pre-multiplied by K = -log2(e) / 2: G = exp2(K m) without a multiply per pixel (the backward's
+            // dL/dconic = -1/2 dG/dm' ... is formed from the unscaled moments, below)
+            sh0[wofs + lane] = make_float4(q0.x, q0.y, q0.z * NEG_HALF_LOG2E, q0.w * NEG_HALF_LOG2E);  // u, v, K ca, K cbc
+            sh1[wofs + lane] = make_float4(q1.x * NEG_HALF_LOG2E, q1.y, __uint_as_float(bx0 | ((bx1 - bx0) << 16)),
+                                    __uint_as_float(by0 | ((by1 - by0) << 16)));   // K cd, op, bbx', bby'
             sh2[wofs + lane] = z0;
             sh3[wofs + lane] = make_float4(z1.x, z1.y, q2.y, 0.0f);  // .z = depth (WAVE)
         }
@@ -284,14 +291,16 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
             float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_dep = 0;
             float v_cc[3] = {0, 0, 0}, v_cs[3] = {0, 0, 0};
             const float dz = q3.z;
+            // the lane's two column / row offsets once per entry (no int -> float conversion in the list loop)
+            const float dxs[2] = {fx0 - q0.x, fx0 + 8.0f - q0.x}, dys[2] = {fy0 - q0.y, fy0 + 8.0f - q0.y};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!((msk >> s) & 1u)) continue;
                 const uint32_t px = X0 + 8u * (s & 1) + lx, py = Y0 + 8u * (s >> 1) + ly;
                 const bool in = (px - (bbx & 0xFFFFu)) < (bbx >> 16) && (py - (bby & 0xFFFFu)) < (bby >> 16);
-                const float dx = (float)px - q0.x, dy = (float)py - q0.y;
-                const float m = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
-                const float G = in ? __builtin_amdgcn_exp2f(m * NEG_HALF_LOG2E) : 0.0f;
+                const float dx = dxs[s & 1], dy = dys[s >> 1];
+                const float m = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;  // K m
+                const float G = in ? __builtin_amdgcn_exp2f(m) : 0.0f;
                 const float a = G * op;  // amplitude, DR:1270-1271 (no clamp on this path)
                 if (!BWD) {
 #pragma unroll
@@ -308,8 +317,11 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
                     v_op += da * G;
                     const float dm = -0.5f * (da * op) * G;
                     v_ca += dm * dx * dx; v_cbc += dm * dx * dy; v_cd += dm * dy * dy;
-                    v_u -= dm * (2.0f * ca * dx + cbc * dy);
-                    v_v -= dm * (cbc * dx + 2.0f * cd * dy);
+                    // dL/d(u, v) = -dm (2 ca dx + cbc dy, cbc dx + 2 cd dy) with the UNSCALED conic = (K-scaled) / K:
+                    // dmk = dm / K = (da op G) ln 2 ... folded into one constant
+                    const float dmk = (da * op) * G * 0.69314718055994530942f;  // -0.5 / K = ln 2
+                    v_u -= dmk * (2.0f * ca * dx + cbc * dy);
+                    v_v -= dmk * (cbc * dx + 2.0f * cd * dy);
                 }
             }
             if (BWD) {
