@@ -62,7 +62,7 @@ typedef struct FgsDims {
     int32_t fwd_variant;    /* forward work split: 0 | 1, 2, 4 = depth-split forward with that many list parts
                                (waves) per tile | -1, -2, -4 = row-split forward with that many waves per tile.
                                Phase path: |fwd_variant| = waves per tile.                                      */
-    int32_t bin_mode;       /* tile binning: 0 | 1 = direct counting sort | 2 = emit + stable radix sort        */
+    int32_t bin_mode;       /* tile binning: 0 | 1 = direct (column / row rank masks) | 2 = emit + stable radix sort */
     int32_t reserved;       /* must be 0                                                                        */
 } FgsDims;
 
