@@ -17,6 +17,11 @@ LIB = os.path.join(OUT_DIR, "libfgs_hip.so")
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc"]
+# -fno-slp-vectorize on the compositing / splat translation units: packed fp32 instructions (v_pk_fma_f32 ...) issue at
+# two plain instructions' cost on gfx950 and forming their register pairs costs v_movs on top:
+# -9 % on the whole config-5 step when fgs_asm.hip got the flag.  (Not on fgs_project.hip: its row sums / double-precision
+# adjoint are 10 % FASTER with the vectoriser on.)
+NO_SLP = ["-fno-slp-vectorize"]
 # per-file extra flags.  fgs_project.hip carries the "canonical fp32" contract: no FMA
 # contraction, IEEE divide/sqrt, so integer decisions match the CPU oracle bit for bit.
 SOURCES = {
@@ -24,8 +29,8 @@ SOURCES = {
     "fgs_project.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "fgs_sort.hip": [],
     "fgs_bin.hip": [],
-    "fgs_composite.hip": ["-ffast-math", "-fno-finite-math-only", "-fno-slp-vectorize"],
-    "fgs_asm.hip": [],
+    "fgs_composite.hip": ["-ffast-math", "-fno-finite-math-only"] + NO_SLP,
+    "fgs_asm.hip": NO_SLP,  # no fast-math here: the transfer function needs the accurate sincosf
     "fgs_gather.hip": [],
     "fgs_fft.hip": [],
     "fgs_spectral.hip": [],
