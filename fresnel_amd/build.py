@@ -68,7 +68,9 @@ def build(force=False, verbose=False, defines=(), suffix=""):
             continue
         obj = os.path.join(OBJ_DIR, name.replace(".hip", ".o"))
         if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_time:
-            cmd = [hipcc] + COMMON + extra + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
+            # experiment builds: FGS_BUILD_EXTRA_<FILE STEM> = extra compiler flags for one file (e.g. scheduler options)
+            more = os.environ.get("FGS_BUILD_EXTRA_" + name.split(".")[0].upper(), "").split()
+            cmd = [hipcc] + COMMON + extra + more + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
