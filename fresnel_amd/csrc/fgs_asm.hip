@@ -135,14 +135,14 @@ __device__ __forceinline__ float plane_depth(int k, int P, float near_, float fa
 // fftfreq(n - k) = -fftfreq(k) exactly, and H depends on fx^2, fy^2 only: one thread evaluates the quadrant entry
 // (ky <= H/2, kx <= W/2) -- the accurate sincosf is what this kernel costs -- and stores it at its up to four mirror
 // positions, bit-identical to evaluating every entry (58 -> 20 us for 3 x 16 planes of 512^2).
-__global__ __launch_bounds__(256) void k_asm_transfer(int W, int H, int P, float near_, float far_, float focal,
-                                                      float inv_ndx, float inv_ndy,
-                                                      const float *__restrict__ wavelengths,
-                                                      float2 *__restrict__ htab) {
+__device__ __forceinline__ void asm_transfer_block(uint32_t blk, int W, int H, int P, float near_, float far_, float focal,
+                                                   float inv_ndx, float inv_ndy,
+                                                   const float *__restrict__ wavelengths,
+                                                   float2 *__restrict__ htab) {
     const size_t HW = (size_t)W * H;
     const int QW = W / 2 + 1, QH = H / 2 + 1;
     const size_t QHW = (size_t)QW * QH;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = (size_t)blk * 256 + threadIdx.x;
     if (i >= 3 * (size_t)P * QHW) return;
     const int kx = (int)(i % QW), ky = (int)((i / QW) % QH);
     const int p = (int)((i / QHW) % P), c = (int)(i / (QHW * P));
@@ -167,9 +167,10 @@ __global__ __launch_bounds__(256) void k_asm_transfer(int W, int H, int P, float
 }
 
 // ccs[g] = (c_r cos phi_r, c_g cos phi_g, c_b cos phi_b, c_r sin phi_r | c_g sin phi_g, c_b sin phi_b, 0, 0)  DR:1274-1283
-__global__ __launch_bounds__(256) void k_asm_phasors(uint32_t total, int phase_channels, const float *__restrict__ color,
-                                                     const float *__restrict__ phase, float *__restrict__ ccs) {
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void asm_phasors_block(uint32_t blk, uint32_t total, int phase_channels,
+                                                  const float *__restrict__ color, const float *__restrict__ phase,
+                                                  float *__restrict__ ccs) {
+    const uint32_t g = blk * 256 + threadIdx.x;
     if (g >= total) return;
     float cc[3], cs[3];
 #pragma unroll
@@ -183,6 +184,33 @@ __global__ __launch_bounds__(256) void k_asm_phasors(uint32_t total, int phase_c
     float4 *o = reinterpret_cast<float4 *>(ccs + (size_t)g * 8);
     o[0] = make_float4(cc[0], cc[1], cc[2], cs[0]);
     o[1] = make_float4(cs[1], cs[2], 0.0f, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_asm_phasors(uint32_t total, int phase_channels, const float *__restrict__ color,
+                                                     const float *__restrict__ phase, float *__restrict__ ccs) {
+    asm_phasors_block(blockIdx.x, total, phase_channels, color, phase, ccs);
+}
+
+// Everything of an ASM forward that depends on the inputs alone, in ONE launch (a one-image step is 45 launches of a few
+// microseconds each): blocks [0, nb_ph) the phasors, [nb_ph, nb_ph + nb_tr) the transfer functions, the last block the
+// twiddles of the column-fused transforms (N = 0: none).
+__global__ __launch_bounds__(256) void k_asm_prep(uint32_t nb_ph, uint32_t nb_tr, uint32_t total, int phase_channels,
+                                                  const float *__restrict__ color, const float *__restrict__ phase,
+                                                  float *__restrict__ ccs, int W, int H, int P, float near_, float far_,
+                                                  float focal, float inv_ndx, float inv_ndy,
+                                                  const float *__restrict__ wavelengths, float2 *__restrict__ htab, int N,
+                                                  float2 *__restrict__ tw) {
+    if (blockIdx.x < nb_ph) {
+        asm_phasors_block(blockIdx.x, total, phase_channels, color, phase, ccs);
+    } else if (blockIdx.x < nb_ph + nb_tr) {
+        asm_transfer_block(blockIdx.x - nb_ph, W, H, P, near_, far_, focal, inv_ndx, inv_ndy, wavelengths, htab);
+    } else {
+        for (int n = threadIdx.x; n < N / 2; n += 256) {
+            float sn, cs;
+            sincospif(-2.0f * (float)n / (float)N, &sn, &cs);
+            tw[n] = make_float2(cs, sn);
+        }
+    }
 }
 
 // One wave per (image, plane, tile); lane = one pixel of each of the four 8x8 sub-tiles.
@@ -434,15 +462,7 @@ __device__ __forceinline__ float image_max(const float *__restrict__ pmax, int b
 //             in bit-reversed row order, radix-4 decimation-in-time inverse FFT (natural order out), store; then rocFFT
 //             1-D inverse rows.
 // Both directions: one read and one write of the plane data in the column pass instead of two reads and one write plus
-// the accumulate kernel's pass.  Unnormalised, like hipFFT.  Twiddles w_N^n = exp(-2 pi i n / N) from a global table.
-__global__ __launch_bounds__(256) void k_fft_twiddles(int N, float2 *__restrict__ tw) {
-    for (int n = threadIdx.x; n < N / 2; n += 256) {
-        float sn, cs;
-        sincospif(-2.0f * (float)n / (float)N, &sn, &cs);
-        tw[n] = make_float2(cs, sn);
-    }
-}
-
+// the accumulate kernel's pass.  Unnormalised, like hipFFT.  Twiddles w_N^n = exp(-2 pi i n / N) from a global table (k_asm_prep).
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a conj(b)
@@ -1053,7 +1073,6 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
         return rc;
     fgs_stage_end(ST_PROJECT, st);
     if ((rc = fgs_launch_binning(p.base, sv, sc, st))) return rc;
-    fgs_stage_begin(ST_SPLAT_FWD, st);
     float2 *field = reinterpret_cast<float2 *>(sv + p.v_field);
     float2 *htab = reinterpret_cast<float2 *>(sv + p.v_htab);
     float2 *total = reinterpret_cast<float2 *>(sv + p.v_total);
@@ -1061,8 +1080,17 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     const uint32_t grid = (uint32_t)B * P * p.base.tiles;
     float *ccs = reinterpret_cast<float *>(sv + p.v_ccs);
     const uint32_t ngauss = (uint32_t)B * (uint32_t)a.num_gaussians;
-    hipLaunchKernelGGL(k_asm_phasors, dim3((ngauss + 255) / 256), dim3(256), 0, st, ngauss, a.phase_channels, color, phase, ccs);
-    FGS_LAUNCH_CHECK("k_asm_phasors");
+    const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
+    const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
+    {
+        const size_t nh = 3 * (size_t)P * (size_t)(W / 2 + 1) * (size_t)(H / 2 + 1);  // one quadrant, mirrored
+        const uint32_t nb_ph = (ngauss + 255) / 256, nb_tr = (uint32_t)((nh + 255) / 256);
+        hipLaunchKernelGGL(k_asm_prep, dim3(nb_ph + nb_tr + 1), dim3(256), 0, st, nb_ph, nb_tr, ngauss, a.phase_channels,
+                           color, phase, ccs, W, H, P, a.depth_near, a.depth_far, a.focal_depth, inv_ndx, inv_ndy,
+                           wavelengths, htab, p.col_logn ? H : 0, reinterpret_cast<float2 *>(sv + p.v_tw));
+        FGS_LAUNCH_CHECK("k_asm_prep");
+    }
+    fgs_stage_begin(ST_SPLAT_FWD, st);
 #define FGS_SPLAT_FWD(WV, NPV, DW)                                                                                     \
     hipLaunchKernelGGL((k_asm_splat<false, WV, NPV>), dim3(grid), dim3(64 * NPV), 0, st, (uint32_t)p.base.tiles,       \
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,                              \
@@ -1077,20 +1105,12 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     FGS_LAUNCH_CHECK("k_asm_splat");
     fgs_stage_end(ST_SPLAT_FWD, st);
     fgs_stage_begin(ST_FIELD_FWD, st);
-    const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
-    const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
-    const size_t nh = 3 * (size_t)P * (size_t)(W / 2 + 1) * (size_t)(H / 2 + 1);  // one quadrant, mirrored
-    hipLaunchKernelGGL(k_asm_transfer, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st, W, H, P, a.depth_near,
-                       a.depth_far, a.focal_depth, inv_ndx, inv_ndy, wavelengths, htab);
-    FGS_LAUNCH_CHECK("k_asm_transfer");
     if (p.col_logn) {
         // rows by rocFFT, columns + transfer function + plane sum in one pass of our own (k_colfft_fwd)
         if ((rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
         float2 *tw = reinterpret_cast<float2 *>(sv + p.v_tw);
         float2 *accp = reinterpret_cast<float2 *>(sc + p.c_accp);
         const int PG = p.col_pg;
-        hipLaunchKernelGGL(k_fft_twiddles, dim3(1), dim3(256), 0, st, H, tw);
-        FGS_LAUNCH_CHECK("k_fft_twiddles");
 #define FGS_COLFFT_FWD(LG, TCV)                                                                                       \
     hipLaunchKernelGGL((k_colfft_fwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B * PG),                    \
                        dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, PG, field, htab, tw, PG > 1 ? accp : total)
