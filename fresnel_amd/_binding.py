@@ -57,7 +57,7 @@ class FgsAsmDims(ctypes.Structure):
                 ("num_planes", ctypes.c_int32), ("depth_near", ctypes.c_float),
                 ("depth_far", ctypes.c_float), ("focal_depth", ctypes.c_float),
                 ("pixel_pitch", ctypes.c_float), ("phase_channels", ctypes.c_int32),
-                ("num_cameras", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("num_cameras", ctypes.c_int32), ("bin_mode", ctypes.c_int32)]
 
 
 class FgsWaveDims(ctypes.Structure):

@@ -140,9 +140,9 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
 #define FGS_SEG64_MAX_GAUSSIANS 200000  /* B * N up to which the shorter segments pay; re-measured at the end of round 2: config 2 bwd 0.264 (64) vs 0.281 ms (128), config 3 at 4 images 0.684 vs 0.690, at 8 images 1.30 vs 1.29, decoder-like 3.52 vs 3.37 */
 #endif
     L.seg_len = d->seg_len ? d->seg_len : ((B * N <= FGS_SEG64_MAX_GAUSSIANS && !row_split) ? 64 : FGS_SEG);
-    p->direct_binning = layers == 1 && p->tiles <= FGS_BIN_MAX_TILES && tx + ty <= FGS_MASK_MAX_LINES && d->bin_mode != 2;
+    p->direct_binning = p->tiles <= FGS_BIN_MAX_TILES && tx + ty <= FGS_MASK_MAX_LINES && d->bin_mode != 2;
     if (d->bin_mode == 1 && !p->direct_binning) {
-        fgs_set_error("bin_mode=1 (direct binning) needs a single layer, <= %d tiles and <= %d tile columns + rows per image",
+        fgs_set_error("bin_mode=1 (direct binning) needs <= %d tiles and <= %d tile columns + rows per image",
                       FGS_BIN_MAX_TILES, FGS_MASK_MAX_LINES);
         return FGS_EINVAL;
     }
@@ -182,6 +182,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     p->s_bsum = o; o = align256(o + nblk * 4);
     // gradient rows: one per duplicate; four (one per sub-tile wave) on the phase path
     p->s_grows = o; o = align256(o + dcap * FGS_GROW_FLOATS * 4 * (d->use_phase ? 4 : 1));
+    p->s_plane = o; o = align256(o + B * ((size_t)layers + 1) * 4);
     p->s_rsum = o; o = align256(o + B * N * 12 * 4);
     p->s_total = o;
     return FGS_OK;

@@ -67,6 +67,7 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     d.max_radius = a->max_radius;
     for (int i = 0; i < 3; ++i) d.background[i] = a->background[i];
     d.use_phase = 0; d.phase_amplitude = 0.0f; d.num_cameras = a->num_cameras;
+    d.bin_mode = a->bin_mode;
     p->a = *a;
     const int rc = fgs_make_plan(&d, &p->base, a->num_planes, false);
     if (rc) return rc;

@@ -161,14 +161,40 @@ constexpr uint32_t TO_TILES = 1024;     // tiles per block of the tile-table ker
 __device__ __forceinline__ uint32_t length_bucket(uint32_t len);
 constexpr uint32_t MB_MAX_LINES = FGS_MASK_MAX_LINES;  // tile columns + rows the build kernel keeps in LDS
 
+// plane id of every depth rank (layered lists): keys of the stable pass that groups `order` by plane
+__global__ __launch_bounds__(256) void k_plane_keys(uint32_t total, uint32_t N, const uint32_t *__restrict__ sorted_idx,
+                                                    const uint32_t *__restrict__ layer, uint32_t *__restrict__ keys) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < total) keys[i] = layer[(i / N) * N + sorted_idx[i]];
+}
+
 __global__ __launch_bounds__(256) void k_mask_build(uint32_t N, uint32_t tiles_x, uint32_t tiles_y, uint32_t bpi,
                                                     uint32_t w64p, const uint32_t *__restrict__ order,
                                                     const uint32_t *__restrict__ tile_count,
                                                     const float *__restrict__ rec,
                                                     unsigned long long *__restrict__ masks,
-                                                    uint32_t *__restrict__ bsum) {
+                                                    uint32_t *__restrict__ bsum, uint32_t nrb, uint32_t layers,
+                                                    const uint32_t *__restrict__ plane_keys,
+                                                    uint32_t *__restrict__ plane_start) {
     __shared__ unsigned long long sm[MB_MAX_LINES][4];
     __shared__ uint32_t wtot[4];
+    if (blockIdx.x >= nrb) {
+        // layered lists (ASM depth planes): `order` is grouped by plane (stable pass over the plane ids after the depth
+        // sort); plane_start[b][p] = first rank of plane p = lower bound of p in the image's sorted plane keys
+        const uint32_t i = (blockIdx.x - nrb) * 256 + threadIdx.x, per = layers + 1;
+        const uint32_t B = nrb / bpi;
+        if (i < B * per) {
+            const uint32_t b = i / per, pl = i - b * per;
+            const uint32_t *k = plane_keys + (size_t)b * N;
+            uint32_t lo = 0, hi = N;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (k[mid] < pl) lo = mid + 1; else hi = mid;
+            }
+            plane_start[i] = lo;
+        }
+        return;
+    }
     const uint32_t b = blockIdx.x / bpi, blk = blockIdx.x - b * bpi;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t r = blk * MB_RANKS + threadIdx.x;
@@ -221,8 +247,35 @@ __device__ __forceinline__ void mask_words(const unsigned long long *__restrict_
     }
 }
 
+// a list's depth-rank range [r_lo, r_hi): the whole image, or the ranks of the list's layer (depth plane)
+struct RankRange { uint32_t b, t, r_lo, r_hi; };
+__device__ __forceinline__ RankRange rank_range(uint32_t list, uint32_t N, uint32_t tiles, uint32_t layers,
+                                                const uint32_t *__restrict__ plane_start) {
+    RankRange r;
+    const uint32_t bl = list / tiles;  // b * layers + layer
+    r.t = list - bl * tiles;
+    r.b = bl / layers;
+    r.r_lo = 0; r.r_hi = N;
+    if (layers > 1) {
+        const uint32_t pl = bl - r.b * layers;
+        r.r_lo = plane_start[r.b * (layers + 1) + pl];
+        r.r_hi = plane_start[r.b * (layers + 1) + pl + 1];
+    }
+    return r;
+}
+// the word w of a (column & row) mask restricted to the ranks [r_lo, r_hi)
+__device__ __forceinline__ unsigned long long clip_word(unsigned long long m, uint32_t w, uint32_t r_lo, uint32_t r_hi) {
+    const uint32_t lo = w * 64u, hi = lo + 64u;
+    if (hi <= r_lo || lo >= r_hi) return 0ull;
+    if (r_lo > lo) m &= ~0ull << (r_lo - lo);
+    if (r_hi < hi) m &= ~0ull >> (hi - r_hi);
+    return m;
+}
+
 template <int WPL>
-__global__ __launch_bounds__(256) void k_mask_count(uint32_t B, uint32_t tiles, uint32_t tiles_x, uint32_t lines,
+__global__ __launch_bounds__(256) void k_mask_count(uint32_t B, uint32_t N, uint32_t layers,
+                                                    const uint32_t *__restrict__ plane_start, uint32_t tiles,
+                                                    uint32_t tiles_x, uint32_t lines,
                                                     uint32_t w64p, uint32_t nrb,
                                                     const unsigned long long *__restrict__ masks,
                                                     uint32_t *__restrict__ lens, uint32_t *__restrict__ bsum,
@@ -248,16 +301,18 @@ __global__ __launch_bounds__(256) void k_mask_count(uint32_t B, uint32_t tiles, 
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (tile >= B * tiles) return;
-    const uint32_t b = tile / tiles, t = tile - b * tiles, y = t / tiles_x, x = t - y * tiles_x;
+    if (tile >= B * layers * tiles) return;
+    const RankRange rr = rank_range(tile, N, tiles, layers, plane_start);
+    const uint32_t b = rr.b, y = rr.t / tiles_x, x = rr.t - y * tiles_x;
     const unsigned long long *col = masks + ((size_t)b * lines + x) * w64p;
     const unsigned long long *row = masks + ((size_t)b * lines + tiles_x + y) * w64p;
     uint32_t c = 0;
-    for (uint32_t w0 = lane * WPL; w0 < w64p; w0 += 64u * WPL) {
+    const uint32_t w_end = min(w64p, (rr.r_hi + 63u) / 64u);
+    for (uint32_t w0 = (rr.r_lo / 64u) / (64u * WPL) * (64u * WPL) + lane * WPL; w0 < w_end; w0 += 64u * WPL) {
         unsigned long long m[WPL];
         mask_words<WPL>(col, row, w0, m);
 #pragma unroll
-        for (int k = 0; k < WPL; ++k) c += (uint32_t)__popcll(m[k]);
+        for (int k = 0; k < WPL; ++k) c += (uint32_t)__popcll(clip_word(m[k], w0 + k, rr.r_lo, rr.r_hi));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
@@ -272,7 +327,9 @@ constexpr uint32_t ME_CAP = 2048;       // list entries a wave parks in LDS per 
 // faster at config 3 -- 43.7 us -- and slower on long lists, 150 vs 110 us on the decoder-like scene: the per-lane
 // 4-byte stores it needs cost more than the gather it removes.)
 template <int WPL>
-__global__ __launch_bounds__(256) void k_mask_emit(uint32_t B, uint32_t N, uint32_t tiles, uint32_t tiles_x,
+__global__ __launch_bounds__(256) void k_mask_emit(uint32_t B, uint32_t N, uint32_t layers,
+                                                   const uint32_t *__restrict__ plane_start, uint32_t tiles,
+                                                   uint32_t tiles_x,
                                                    uint32_t lines, uint32_t w64p, uint32_t nrb, uint32_t bpi,
                                                    uint32_t dcap, const unsigned long long *__restrict__ masks,
                                                    const uint32_t *__restrict__ order,
@@ -296,19 +353,25 @@ __global__ __launch_bounds__(256) void k_mask_emit(uint32_t B, uint32_t N, uint3
     const uint32_t ntb = gridDim.x - nrb;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile = fgs_xcd_remap(blockIdx.x - nrb, ntb) * 4u + wave;
-    if (tile >= B * tiles) return;
-    const uint32_t b = tile / tiles, t = tile - b * tiles, y = t / tiles_x, x = t - y * tiles_x;
+    if (tile >= B * layers * tiles) return;
+    const RankRange rr = rank_range(tile, N, tiles, layers, plane_start);
+    const uint32_t b = rr.b, y = rr.t / tiles_x, x = rr.t - y * tiles_x;
     const unsigned long long *col = masks + ((size_t)b * lines + x) * w64p;
     const unsigned long long *row = masks + ((size_t)b * lines + tiles_x + y) * w64p;
     const uint32_t *ord = order + (size_t)b * N;
     uint32_t *pk = park[wave];
     uint32_t base = ranges[2 * tile];  // next list slot
-    for (uint32_t c0 = 0; c0 < w64p; c0 += 64u * WPL) {
+    const uint32_t w_end = min(w64p, (rr.r_hi + 63u) / 64u);
+    for (uint32_t c0 = (rr.r_lo / 64u) / (64u * WPL) * (64u * WPL); c0 < w_end; c0 += 64u * WPL) {
         const uint32_t w0 = c0 + lane * WPL;
         unsigned long long m[WPL];
 #pragma unroll
         for (int k = 0; k < WPL; ++k) m[k] = 0ull;
-        if (w0 < w64p) mask_words<WPL>(col, row, w0, m);
+        if (w0 < w_end) {
+            mask_words<WPL>(col, row, w0, m);
+#pragma unroll
+            for (int k = 0; k < WPL; ++k) m[k] = clip_word(m[k], w0 + k, rr.r_lo, rr.r_hi);
+        }
         uint32_t cl = 0;
 #pragma unroll
         for (int k = 0; k < WPL; ++k) cl += (uint32_t)__popcll(m[k]);
@@ -571,9 +634,25 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     // keys straight from the projection's depth_key (read-only), payload = index inside the image, generated by the
     // first pass; per-pass prefix formed inside the downsweep: 8 launches (was 13)
     uint32_t *ks, *vs;
-    int rc = fgs_launch_radix_sort(keys0, vals0, keys1, vals1, order, &ks, &vs, N, nullptr, N, N, B, 32, hist, st,
-                                   depth_key, N);
+    const bool layered_direct = p.direct_binning && p.layers > 1;
+    int rc = fgs_launch_radix_sort(keys0, vals0, keys1, vals1, layered_direct ? nullptr : order, &ks, &vs, N, nullptr, N, N,
+                                   B, 32, hist, st, depth_key, N);
     if (rc) return rc;
+    uint32_t *plane_keys = nullptr;  // sorted plane ids per image (layered direct binning)
+    if (layered_direct) {
+        // group the depth order by layer (depth plane) with ONE more stable pass over the plane ids: `order` then lists
+        // plane 0's Gaussians in depth order, then plane 1's, ... and a (plane, tile) list is a rank RANGE of the masks
+        uint32_t *kfree = ks == keys0 ? keys1 : keys0, *vfree = vs == vals0 ? vals1 : vals0;
+        hipLaunchKernelGGL(k_plane_keys, dim3(nblk), dim3(256), 0, st, total, N, vs,
+                           reinterpret_cast<const uint32_t *>(saved + p.s_layer), kfree);
+        FGS_LAUNCH_CHECK("k_plane_keys");
+        uint32_t pbits = 0;
+        while ((1u << pbits) < (uint32_t)p.layers) ++pbits;
+        uint32_t *ks2, *vs2;
+        if ((rc = fgs_launch_radix_sort(kfree, vs, ks, vfree, order, &ks2, &vs2, N, nullptr, N, N, B, pbits, hist, st)))
+            return rc;
+        plane_keys = ks2;
+    }
     fgs_stage_end(ST_DEPTH_SORT, st);
     const uint32_t ntiles_all = B * (uint32_t)p.layers * (uint32_t)p.tiles;
     uint32_t *tile_order = reinterpret_cast<uint32_t *>(saved + p.L.tile_order);
@@ -583,18 +662,23 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         // mask binning (see k_mask_build): 5 launches, none of them serial over Gaussians
         const uint32_t bpi = (N + MB_RANKS - 1) / MB_RANKS, nrb = B * bpi;
         const uint32_t tiles_x = (uint32_t)p.L.tiles_x, tiles_y = (uint32_t)p.L.tiles_y, lines = tiles_x + tiles_y;
-        const uint32_t w64p = fgs_mask_words(N);
-        unsigned long long *masks = reinterpret_cast<unsigned long long *>(keys0);  // [B][lines][w64p]
-        uint32_t *lens = keys1;                                                     // [B * tiles]
+        const uint32_t w64p = fgs_mask_words(N), layers = (uint32_t)p.layers;
+        // masks [B][lines][w64p] and list lengths [B * layers * tiles] in the two sort buffers the (plane) keys are NOT in
+        unsigned long long *masks = reinterpret_cast<unsigned long long *>(plane_keys == keys0 ? keys1 : keys0);
+        uint32_t *lens = vals0;
+        uint32_t *plane_start = reinterpret_cast<uint32_t *>(scratch + p.s_plane);  // [B][layers + 1]
         uint32_t *dup_off = reinterpret_cast<uint32_t *>(saved + p.L.dup_off);
         const uint32_t ntb = (ntiles_all + 3) / 4;  // four tiles (waves) per block
-        const int wpl = w64p <= 64 ? 1 : (w64p <= 128 ? 2 : (w64p <= 256 ? 4 : 8));
+        // rank words a list spans: all of them, or its plane's share
+        const uint32_t wspan = layers > 1 ? (w64p + layers - 1) / layers + 2 : w64p;
+        const int wpl = wspan <= 64 ? 1 : (wspan <= 128 ? 2 : (wspan <= 256 ? 4 : 8));
+        const uint32_t npb = layers > 1 ? (B * (layers + 1) + 255) / 256 : 0u;  // blocks that find the plane ranges
         fgs_stage_begin(ST_DUP_EMIT, st);
-        hipLaunchKernelGGL(k_mask_build, dim3(nrb), dim3(256), 0, st, N, tiles_x, tiles_y, bpi, w64p, order,
-                           tile_count, rec, masks, bsum);
+        hipLaunchKernelGGL(k_mask_build, dim3(nrb + npb), dim3(256), 0, st, N, tiles_x, tiles_y, bpi, w64p, order,
+                           tile_count, rec, masks, bsum, nrb, layers, plane_keys, plane_start);
         FGS_LAUNCH_CHECK("k_mask_build");
-#define FGS_MASK_COUNT(W) hipLaunchKernelGGL(k_mask_count<W>, dim3(ntb + 1), dim3(256), 0, st, B, (uint32_t)p.tiles, \
-                                             tiles_x, lines, w64p, nrb, masks, lens, bsum, counters, dcap)
+#define FGS_MASK_COUNT(W) hipLaunchKernelGGL(k_mask_count<W>, dim3(ntb + 1), dim3(256), 0, st, B, N, layers, plane_start, \
+                                             (uint32_t)p.tiles, tiles_x, lines, w64p, nrb, masks, lens, bsum, counters, dcap)
         if (wpl == 1) FGS_MASK_COUNT(1); else if (wpl == 2) FGS_MASK_COUNT(2); else if (wpl == 4) FGS_MASK_COUNT(4); else FGS_MASK_COUNT(8);
 #undef FGS_MASK_COUNT
         FGS_LAUNCH_CHECK("k_mask_count");
@@ -605,9 +689,9 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
             return rc;
         fgs_stage_end(ST_TILE_RANGES, st);
         fgs_stage_begin(ST_TILE_SORT, st);
-#define FGS_MASK_EMIT(W) hipLaunchKernelGGL(k_mask_emit<W>, dim3(nrb + ntb), dim3(256), 0, st, B, N, (uint32_t)p.tiles, \
-                                            tiles_x, lines, w64p, nrb, bpi, dcap, masks, order, tile_count, ranges, bsum, \
-                                            dup_ids, dup_off)
+#define FGS_MASK_EMIT(W) hipLaunchKernelGGL(k_mask_emit<W>, dim3(nrb + ntb), dim3(256), 0, st, B, N, layers, plane_start, \
+                                            (uint32_t)p.tiles, tiles_x, lines, w64p, nrb, bpi, dcap, masks, order,         \
+                                            tile_count, ranges, bsum, dup_ids, dup_off)
         if (wpl == 1) FGS_MASK_EMIT(1); else if (wpl == 2) FGS_MASK_EMIT(2); else if (wpl == 4) FGS_MASK_EMIT(4); else FGS_MASK_EMIT(8);
 #undef FGS_MASK_EMIT
         FGS_LAUNCH_CHECK("k_mask_emit");

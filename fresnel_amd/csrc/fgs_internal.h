@@ -36,6 +36,7 @@ struct FgsPlan {
     size_t s_hist;            // uint32 radix histograms
     size_t s_bsum;            // uint32 block sums for the duplicate-offset scan
     size_t s_grows;           // float [Dcap][12]: per-duplicate gradient rows (composite bwd -> reduce)
+    size_t s_plane;           // uint32 [B][layers + 1]: first depth rank of every layer (layered direct binning)
     size_t s_rsum;            // float [B*N][12]: per-Gaussian totals of the blend path's rows (k_row_sum -> k_project_bwd)
 };
 

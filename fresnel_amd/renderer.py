@@ -332,6 +332,7 @@ class AsmRenderer(torch.autograd.Function):
         d.focal_depth, d.pixel_pitch = float(cfg["focal_depth"]), float(cfg["pixel_pitch"])
         d.phase_channels = 3 if ph.dim() == 3 else 1
         d.num_cameras = cam_tensor.shape[0]
+        d.bin_mode = int(cfg.get("bin_mode", 0))  # FgsAsmDims.bin_mode: list-building override for A/B runs and tests
         sb, cb = ctypes.c_size_t(0), ctypes.c_size_t(0)
         with torch.cuda.device(dev):
             B.check(lib.fgs_asm_workspace_bytes(ctypes.byref(d), ctypes.byref(sb), ctypes.byref(cb)),
@@ -495,7 +496,8 @@ class ASMWaveFieldRenderer(nn.Module):
         cfg = dict(width=self.width, height=self.height, max_radius=self.max_radius,
                    background=[float(b) for b in self.background.tolist()],
                    num_depth_planes=self.num_depth_planes, depth_range=self.depth_range,
-                   focal_depth=self.focal_depth, pixel_pitch=self.pixel_pitch)
+                   focal_depth=self.focal_depth, pixel_pitch=self.pixel_pitch,
+                   bin_mode=int(getattr(self, "bin_mode", 0)))  # tests set ren.bin_mode = 2 for the radix path
         cam_tensor = pack_cameras(camera, positions.device)
         img = AsmRenderer.apply(positions, scales, rotations, colors, opacities, phases, wavelengths_rgb,
                                 cam_tensor, cfg)

@@ -160,7 +160,9 @@ typedef struct FgsAsmDims {
     float pixel_pitch;       /* DR:1091 */
     int32_t phase_channels;  /* 1: phases (B,N); 3: phases (B,N,3) */
     int32_t num_cameras;     /* 1 or B */
-    int32_t reserved;
+    int32_t bin_mode;        /* list building, as FgsDims.bin_mode: 0 = automatic | 1 = direct (rank masks; the depth order is
+                                grouped by plane and a (plane, tile) list is a rank range of the masks) | 2 = emit + stable
+                                radix sort over (image, plane, tile) keys.  Same lists either way (tests)                 */
 } FgsAsmDims;
 
 int fgs_asm_workspace_bytes(const FgsAsmDims *dims, size_t *saved_bytes, size_t *scratch_bytes);
