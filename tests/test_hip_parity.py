@@ -335,6 +335,35 @@ def test_mask_binning_dense_tiles_flush_in_windows():
     assert np.array_equal(outs[0]["dup_off"], outs[1]["dup_off"])
 
 
+def test_count_pairs_equals_the_bbox_areas():
+    """fgs_count_pairs (the benchmark's unit of work, SURVEY 8d: composited Gaussian-pixels = sum of the visible
+    Gaussians' integer bbox areas) against numpy on the saved records and against the oracle's P."""
+    import ctypes
+    from fresnel_amd import _binding as B, renderer as R
+    from fresnel_amd.renderer import Camera
+    from oracle import fgs_oracle as orc
+    dev = _cuda()
+    N, W, H = 5000, 200, 136
+    a0, a1 = synth_aniso(N, 91, smax=0.2), synth_aniso(N, 92, smax=0.05)
+    ts = [torch.from_numpy(np.stack([x, y])).to(dev) for x, y in zip(a0, a1)]
+    cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    cfg = R._Cfg(W, H, (0, 0, 0), 64, False, 0.25)
+    _, _, saved, dims, _ = R.forward_raw(*ts, None, R.pack_cameras(cam, dev), cfg)
+    pairs = torch.zeros(1, dtype=torch.int64, device=dev)
+    B.check(B.load().fgs_count_pairs(ctypes.byref(dims), ctypes.c_void_p(saved.data_ptr()), ctypes.c_void_p(pairs.data_ptr()),
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "fgs_count_pairs")
+    st = R.inspect_saved(saved, dims)
+    rec = st["rec"].cpu().numpy()
+    cnt = st["tile_count"].cpu().numpy()
+    bbx = np.ascontiguousarray(rec[..., 10]).view(np.uint32).astype(np.int64)
+    bby = np.ascontiguousarray(rec[..., 11]).view(np.uint32).astype(np.int64)
+    area = ((bbx >> 16) - (bbx & 0xFFFF)) * ((bby >> 16) - (bby & 0xFFFF))
+    expect = int(area[cnt != 0].sum())
+    assert int(pairs.item()) == expect and expect > 100000
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    assert expect == sum(int(orc.render(*a, ocam, keep_pairs=False).P) for a in (a0, a1))
+
+
 def test_wide_frame_direct_binning_division_is_exact():
     """A frame of 80 tile columns with Gaussians whose bbox spans > 64 of them (radius cap 700): the tile-row
     division of the direct binning's scatter must be exact for any width (the rounded-up reciprocal alone
