@@ -32,7 +32,7 @@ SOURCES = {
     "fgs_composite.hip": ["-ffast-math", "-fno-finite-math-only"] + NO_SLP,
     "fgs_asm.hip": NO_SLP,  # no fast-math here: the transfer function needs the accurate sincosf
     "fgs_gather.hip": [],
-    "fgs_fft.hip": [],
+    "fgs_fft.hip": NO_SLP,
     "fgs_spectral.hip": [],
 }
 LINK_LIBS = ["-lhipfft"]

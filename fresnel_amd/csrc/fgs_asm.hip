@@ -20,6 +20,7 @@
 #include <hipfft/hipfft.h>
 #include "fgs_internal.h"
 #include "fgs_wave.h"
+#include "fgs_colfft.h"
 
 namespace {
 
@@ -99,7 +100,7 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
         int r2 = p->col_logn ? fgs_fft_rows_work_bytes(a->width, (int)(B * P * 3) * a->height, &p->work_big)
                              : fgs_fft_work_bytes(a->height, a->width, (int)(B * P * 3), &p->work_big);
         if (r2) return r2;
-        r2 = fgs_fft_work_bytes(a->height, a->width, (int)(B * 3), &p->work_small);
+        r2 = fgs_fft2_work_bytes(a->height, a->width, (int)(B * 3), &p->work_small);
         if (r2) return r2;
     }
     o = p->base.s_total;
@@ -464,69 +465,6 @@ __device__ __forceinline__ float image_max(const float *__restrict__ pmax, int b
 //             1-D inverse rows.
 // Both directions: one read and one write of the plane data in the column pass instead of two reads and one write plus
 // the accumulate kernel's pass.  Unnormalised, like hipFFT.  Twiddles w_N^n = exp(-2 pi i n / N) from a global table (k_asm_prep).
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a conj(b)
-
-// In-LDS FFT of the TC columns of x[N][TC], N = 2^LOGN, all NT threads of the block; tw = w_N^n, n < N/2, in LDS.
-// INV = false: forward (e^-), decimation in frequency, natural order in, bit-reversed order out.  INV = true: inverse
-// (e^+), decimation in time, bit-reversed order in, natural order out.  Two radix-2 stages per pass over the data
-// (block sizes M and M/2), one more radix-2 pass when LOGN is odd.  (Consecutive lanes = the TC columns of a row, then
-// the next butterfly: a 32-lane group reads two whole rows, conflict-free except in the last pass.)
-template <int LOGN, int TC, int NT, bool INV>
-__device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *tw) {
-    constexpr int N = 1 << LOGN;
-    auto pair_pass = [&]() {  // block size 2: x[2k] = a + b, x[2k+1] = a - b
-#pragma unroll 1
-        for (int idx = threadIdx.x; idx < (N / 2) * TC; idx += NT) {
-            const int col = idx % TC, k = idx / TC;
-            const float2 a = x[2 * k][col], b = x[2 * k + 1][col];
-            x[2 * k][col] = cadd(a, b); x[2 * k + 1][col] = csub(a, b);
-        }
-        __syncthreads();
-    };
-    auto quad_pass = [&](int M) {  // block sizes M and M / 2 on the points i, i + M/4, i + M/2, i + 3M/4
-        const int Q = M / 4, step = N / M;
-#pragma unroll 1
-        for (int idx = threadIdx.x; idx < (N / 4) * TC; idx += NT) {
-            const int col = idx % TC, q = idx / TC;
-            const int i = q % Q, p0 = (q / Q) * M + i, p1 = p0 + Q, p2 = p0 + 2 * Q, p3 = p0 + 3 * Q;
-            const float2 w1 = tw[i * step], w2 = tw[2 * i * step];  // w_M^i, w_M^(2i) = w_(M/2)^i
-            const float2 a0 = x[p0][col], a1 = x[p1][col], a2 = x[p2][col], a3 = x[p3][col];
-            if (!INV) {
-                const float2 s02 = cadd(a0, a2), s13 = cadd(a1, a3), d02 = csub(a0, a2), d13 = csub(a1, a3);
-                const float2 u2 = cmul(d02, w1), u3 = cmul(make_float2(d13.y, -d13.x), w1);  // w_M^(i + M/4) = -i w_M^i
-                x[p0][col] = cadd(s02, s13);
-                x[p1][col] = cmul(csub(s02, s13), w2);
-                x[p2][col] = cadd(u2, u3);
-                x[p3][col] = cmul(csub(u2, u3), w2);
-            } else {
-                const float2 t1 = cmulc(a1, w2), t3 = cmulc(a3, w2);
-                const float2 r0 = cadd(a0, t1), r1 = csub(a0, t1), r2 = cadd(a2, t3), r3 = csub(a2, t3);
-                const float2 v2 = cmulc(r2, w1), v3t = cmulc(r3, w1);
-                const float2 v3 = make_float2(-v3t.y, v3t.x);  // conj(-i w_M^i) = +i conj(w_M^i)
-                x[p0][col] = cadd(r0, v2);
-                x[p2][col] = csub(r0, v2);
-                x[p1][col] = cadd(r1, v3);
-                x[p3][col] = csub(r1, v3);
-            }
-        }
-        __syncthreads();
-    };
-    if (!INV) {
-#pragma unroll
-        for (int lg = LOGN; lg >= 2; lg -= 2) quad_pass(1 << lg);
-        if (LOGN & 1) pair_pass();
-    } else {
-        if (LOGN & 1) pair_pass();
-#pragma unroll
-        for (int lg = (LOGN & 1) ? 3 : 2; lg <= LOGN; lg += 2) quad_pass(1 << lg);
-    }
-}
-
-template <int LOGN>
-__device__ __forceinline__ int bitrev(int r) { return (int)(__brev((unsigned)r) >> (32 - LOGN)); }
-
 // Eight tile elements per thread: NT = N * TC / 8 threads per block (1024 for a 512 x 16 tile).  (The first version ran
 // 256 threads with 32 elements each: 270 / 458 VGPRs, one wave per SIMD, 1.9 / 1.3 ms at 8 images.)
 constexpr int COLFFT_PER = 8;
@@ -1135,7 +1073,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
                            total);
         FGS_LAUNCH_CHECK("k_asm_accumulate");
     }
-    if ((rc = fgs_fft_exec(H, W, B * 3, total, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
+    if ((rc = fgs_fft2_exec(H, W, B * 3, total, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_hw = 1.0f / (float)HW;
     float *pmax = reinterpret_cast<float *>(sc + p.c_part);
     hipLaunchKernelGGL(k_asm_max, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, inv_hw, total, pmax);
@@ -1180,7 +1118,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
                        a.background[2], total, scal, psum, g_rgb, gtot);
     FGS_LAUNCH_CHECK("k_asm_output_bwd2");
     // adjoint of the unnormalised inverse FFT is the unnormalised forward FFT
-    if ((rc = fgs_fft_exec(H, W, B * 3, gtot, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
+    if ((rc = fgs_fft2_exec(H, W, B * 3, gtot, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
     unsigned nwl = (unsigned)(((size_t)B * HW + 255) / 256);

@@ -1,0 +1,69 @@
+// In-LDS radix-4 FFT down the columns of a tile, shared by the column-fused transforms of the angular-spectrum renderer
+// (fgs_asm.hip) and the plain column pass of fgs_fft2_exec (fgs_fft.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+__device__ __forceinline__ float2 fgs_cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a conj(b)
+
+// In-LDS FFT of the TC columns of x[N][TC], N = 2^LOGN, all NT threads of the block; tw = w_N^n, n < N/2, in LDS.
+// INV = false: forward (e^-), decimation in frequency, natural order in, bit-reversed order out.  INV = true: inverse
+// (e^+), decimation in time, bit-reversed order in, natural order out.  Two radix-2 stages per pass over the data
+// (block sizes M and M/2), one more radix-2 pass when LOGN is odd.  (Consecutive lanes = the TC columns of a row, then
+// the next butterfly: a 32-lane group reads two whole rows, conflict-free except in the last pass.)
+template <int LOGN, int TC, int NT, bool INV>
+__device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *tw) {
+    constexpr int N = 1 << LOGN;
+    auto pair_pass = [&]() {  // block size 2: x[2k] = a + b, x[2k+1] = a - b
+#pragma unroll 1
+        for (int idx = threadIdx.x; idx < (N / 2) * TC; idx += NT) {
+            const int col = idx % TC, k = idx / TC;
+            const float2 a = x[2 * k][col], b = x[2 * k + 1][col];
+            x[2 * k][col] = cadd(a, b); x[2 * k + 1][col] = csub(a, b);
+        }
+        __syncthreads();
+    };
+    auto quad_pass = [&](int M) {  // block sizes M and M / 2 on the points i, i + M/4, i + M/2, i + 3M/4
+        const int Q = M / 4, step = N / M;
+#pragma unroll 1
+        for (int idx = threadIdx.x; idx < (N / 4) * TC; idx += NT) {
+            const int col = idx % TC, q = idx / TC;
+            const int i = q % Q, p0 = (q / Q) * M + i, p1 = p0 + Q, p2 = p0 + 2 * Q, p3 = p0 + 3 * Q;
+            const float2 w1 = tw[i * step], w2 = tw[2 * i * step];  // w_M^i, w_M^(2i) = w_(M/2)^i
+            const float2 a0 = x[p0][col], a1 = x[p1][col], a2 = x[p2][col], a3 = x[p3][col];
+            if (!INV) {
+                const float2 s02 = cadd(a0, a2), s13 = cadd(a1, a3), d02 = csub(a0, a2), d13 = csub(a1, a3);
+                const float2 u2 = fgs_cmul(d02, w1), u3 = fgs_cmul(make_float2(d13.y, -d13.x), w1);  // w_M^(i + M/4) = -i w_M^i
+                x[p0][col] = cadd(s02, s13);
+                x[p1][col] = fgs_cmul(csub(s02, s13), w2);
+                x[p2][col] = cadd(u2, u3);
+                x[p3][col] = fgs_cmul(csub(u2, u3), w2);
+            } else {
+                const float2 t1 = cmulc(a1, w2), t3 = cmulc(a3, w2);
+                const float2 r0 = cadd(a0, t1), r1 = csub(a0, t1), r2 = cadd(a2, t3), r3 = csub(a2, t3);
+                const float2 v2 = cmulc(r2, w1), v3t = cmulc(r3, w1);
+                const float2 v3 = make_float2(-v3t.y, v3t.x);  // conj(-i w_M^i) = +i conj(w_M^i)
+                x[p0][col] = cadd(r0, v2);
+                x[p2][col] = csub(r0, v2);
+                x[p1][col] = cadd(r1, v3);
+                x[p3][col] = csub(r1, v3);
+            }
+        }
+        __syncthreads();
+    };
+    if (!INV) {
+#pragma unroll
+        for (int lg = LOGN; lg >= 2; lg -= 2) quad_pass(1 << lg);
+        if (LOGN & 1) pair_pass();
+    } else {
+        if (LOGN & 1) pair_pass();
+#pragma unroll
+        for (int lg = (LOGN & 1) ? 3 : 2; lg <= LOGN; lg += 2) quad_pass(1 << lg);
+    }
+}
+
+template <int LOGN>
+__device__ __forceinline__ int bitrev(int r) { return (int)(__brev((unsigned)r) >> (32 - LOGN)); }
+

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <tuple>
 #include "fgs_internal.h"
+#include "fgs_colfft.h"
 
 namespace {
 
@@ -82,3 +83,80 @@ int fgs_fft_rows_exec(int W, int rows, float2 *data, int dir, void *work, hipStr
     return fgs_fft_exec(0, W, rows, data, dir, work, st);
 }
 int fgs_fft_rows_work_bytes(int W, int rows, size_t *bytes) { return fgs_fft_work_bytes(0, W, rows, bytes); }
+
+// ---- 2-D transforms with our own column pass ---------------------------------------------------------------------
+// rocFFT's 2-D C2C plans run a row kernel at ~5.4 TB/s and a column kernel at ~2 TB/s (config 5's 805 MB: 0.30 + 0.80 ms).
+// For heights 64 ... 1024 that are powers of two fgs_fft2_exec uses rocFFT for the rows only and k_colfft_plain for the
+// columns: per (field, tile of TC columns) the H x TC tile goes through LDS (128-byte row segments), radix-4 FFT down the
+// columns (fgs_colfft.h), one read and one write of the data.  Other heights: rocFFT's 2-D plan.  Unnormalised both ways.
+namespace {
+
+template <int LOGN, int TC, bool INV>
+__global__ __launch_bounds__((1 << LOGN) * TC / 8) void k_colfft_plain(int W, float2 *__restrict__ data) {
+    constexpr int N = 1 << LOGN, PER = 8, NT = N * TC / PER;
+    __shared__ float2 x[N][TC];
+    __shared__ float2 tw[N / 2];
+    for (int n = threadIdx.x; n < N / 2; n += NT) {
+        float sn, cs;
+        sincospif(-2.0f * (float)n / (float)N, &sn, &cs);
+        tw[n] = make_float2(cs, sn);
+    }
+    const int c0 = blockIdx.x * TC, col = threadIdx.x % TC, r0 = threadIdx.x / TC;
+    const bool live = c0 + col < W;
+    float2 *f = data + (size_t)blockIdx.y * N * W + c0 + col;
+    // forward: natural rows in, LDS row r ends up holding frequency bitrev(r); inverse: frequency k goes to LDS row
+    // bitrev(k), natural rows out
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int r = r0 + e * (NT / TC);
+        x[r][col] = live ? f[(size_t)(INV ? bitrev<LOGN>(r) : r) * W] : make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+    lds_fft_columns<LOGN, TC, NT, INV>(x, tw);
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int r = r0 + e * (NT / TC);
+            f[(size_t)(INV ? r : bitrev<LOGN>(r)) * W] = x[r][col];
+        }
+    }
+}
+
+int colfft_logn(int H) {
+    for (int lg = 6; lg <= 10; ++lg)
+        if (H == (1 << lg)) return lg;
+    return 0;
+}
+
+template <bool INV>
+int launch_colfft_plain(int lg, int W, int batch, float2 *data, hipStream_t st) {
+#define FGS_CP(LG, TCV)                                                                                              \
+    hipLaunchKernelGGL((k_colfft_plain<LG, TCV, INV>), dim3((unsigned)((W + TCV - 1) / TCV), (unsigned)batch),         \
+                       dim3((1 << LG) * TCV / 8), 0, st, W, data)
+    switch (lg) {
+        case 6: FGS_CP(6, 16); break;
+        case 7: FGS_CP(7, 16); break;
+        case 8: FGS_CP(8, 16); break;
+        case 9: FGS_CP(9, 16); break;
+        default: FGS_CP(10, 8); break;
+    }
+#undef FGS_CP
+    FGS_LAUNCH_CHECK("k_colfft_plain");
+    return FGS_OK;
+}
+
+}  // namespace
+
+int fgs_fft2_work_bytes(int H, int W, int batch, size_t *bytes) {
+    if (colfft_logn(H)) return fgs_fft_rows_work_bytes(W, batch * H, bytes);
+    return fgs_fft_work_bytes(H, W, batch, bytes);
+}
+
+int fgs_fft2_exec(int H, int W, int batch, float2 *data, int dir, void *work, hipStream_t st) {
+    const int lg = colfft_logn(H);
+    if (!lg) return fgs_fft_exec(H, W, batch, data, dir, work, st);
+    int rc = fgs_fft_rows_exec(W, batch * H, data, dir, work, st);
+    if (rc) return rc;
+    return dir == HIPFFT_FORWARD ? launch_colfft_plain<false>(lg, W, batch, data, st)
+                                 : launch_colfft_plain<true>(lg, W, batch, data, st);
+}

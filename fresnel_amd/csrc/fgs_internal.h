@@ -103,6 +103,9 @@ int fgs_fft_work_bytes(int H, int W, int batch, size_t *bytes);
 int fgs_fft_exec(int H, int W, int batch, float2 *data, int dir, void *work, hipStream_t st);
 int fgs_fft_rows_exec(int W, int rows, float2 *data, int dir, void *work, hipStream_t st);  // 1-D, along rows of length W
 int fgs_fft_rows_work_bytes(int W, int rows, size_t *bytes);
+// 2-D transform, rocFFT rows + our own column pass for power-of-two heights 64 ... 1024 (else rocFFT's 2-D plan)
+int fgs_fft2_work_bytes(int H, int W, int batch, size_t *bytes);
+int fgs_fft2_exec(int H, int W, int batch, float2 *data, int dir, void *work, hipStream_t st);
 int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, float *out_rgb,
                              float *out_depth, hipStream_t st);
 int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *saved, char *scratch,

@@ -137,7 +137,7 @@ int make_spec_plan(const FgsSpectralDims *d, SpecPlan *p) {
     p->v_spec = 0;
     p->v_total = align256(2 * p->n * sizeof(float2));
     size_t work = 0;
-    const int rc = fgs_fft_work_bytes(d->height, d->width, 2 * d->images * d->channels, &work);
+    const int rc = fgs_fft2_work_bytes(d->height, d->width, 2 * d->images * d->channels, &work);
     if (rc) return rc;
     p->c_part = 0;
     p->c_work = align256(2 * MAX_PART * sizeof(double));
@@ -285,7 +285,7 @@ extern "C" {
 int fgs_asm_propagate_workspace_bytes(int32_t height, int32_t width, int32_t channels, size_t *scratch_bytes) {
     if (height < 1 || width < 1 || channels < 1) { fgs_set_error("fgs_asm_propagate: invalid dims"); return FGS_EINVAL; }
     size_t work = 0;
-    const int rc = fgs_fft_work_bytes(height, width, channels, &work);
+    const int rc = fgs_fft2_work_bytes(height, width, channels, &work);
     if (rc) return rc;
     if (scratch_bytes) *scratch_bytes = align256((size_t)(1 + channels) * MAX_PART * sizeof(double)) + align256(work + 256);
     return FGS_OK;
@@ -307,13 +307,13 @@ int fgs_asm_propagate_forward(int32_t height, int32_t width, int32_t channels, f
     hipError_t e = hipMemcpyAsync(spectrum, field, n * sizeof(float2), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { fgs_set_error("propagate copy: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     float2 *spec = reinterpret_cast<float2 *>(spectrum), *o = reinterpret_cast<float2 *>(out);
-    if ((rc = fgs_fft_exec(height, width, channels, spec, HIPFFT_FORWARD, work, st))) return rc;
+    if ((rc = fgs_fft2_exec(height, width, channels, spec, HIPFFT_FORWARD, work, st))) return rc;
     const float inv_ndx = (float)(1.0 / ((double)width * (double)pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)height * (double)pixel_pitch));
     hipLaunchKernelGGL(k_prop_apply, dim3((unsigned)((n + RT - 1) / RT)), dim3(RT), 0, st, width, height, channels, inv_ndx,
                        inv_ndy, band_limit, z, wavelengths, spec, o);
     FGS_LAUNCH_CHECK("k_prop_apply");
-    return fgs_fft_exec(height, width, channels, o, HIPFFT_BACKWARD, work, st);
+    return fgs_fft2_exec(height, width, channels, o, HIPFFT_BACKWARD, work, st);
 }
 
 int fgs_asm_propagate_backward(int32_t height, int32_t width, int32_t channels, float pixel_pitch, int32_t band_limit,
@@ -334,7 +334,7 @@ int fgs_asm_propagate_backward(int32_t height, int32_t width, int32_t channels, 
     if (e != hipSuccess) { fgs_set_error("propagate copy: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     float2 *g = reinterpret_cast<float2 *>(g_field);
     // adjoint of the normalised inverse transform: forward transform / (HW) (the scale is applied in the kernel)
-    if ((rc = fgs_fft_exec(height, width, channels, g, HIPFFT_FORWARD, work, st))) return rc;
+    if ((rc = fgs_fft2_exec(height, width, channels, g, HIPFFT_FORWARD, work, st))) return rc;
     unsigned gx = part_blocks(HW);
     if ((size_t)gx * channels > MAX_PART) gx = MAX_PART / channels ? MAX_PART / channels : 1;
     const float inv_ndx = (float)(1.0 / ((double)width * (double)pixel_pitch));
@@ -343,7 +343,7 @@ int fgs_asm_propagate_backward(int32_t height, int32_t width, int32_t channels, 
                        band_limit, z, wavelengths, reinterpret_cast<const float2 *>(spectrum), g, part);
     FGS_LAUNCH_CHECK("k_prop_apply_bwd");
     // adjoint of the forward transform: the unnormalised inverse
-    if ((rc = fgs_fft_exec(height, width, channels, g, HIPFFT_BACKWARD, work, st))) return rc;
+    if ((rc = fgs_fft2_exec(height, width, channels, g, HIPFFT_BACKWARD, work, st))) return rc;
     const unsigned stride = gx * channels;
     hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(RT), 0, st, part, stride, stride, 1u, 1.0, g_z);
     FGS_LAUNCH_CHECK("k_final_sums");
@@ -382,7 +382,7 @@ int fgs_spectral_loss_forward(const FgsSpectralDims *dims, const float *rendered
     hipLaunchKernelGGL(k_spec_pack, dim3((unsigned)((p.n + RT - 1) / RT)), dim3(RT), 0, st, p.d.mode, C, HW, p.n,
                        p.d.focal_depth, rendered, target, depth, wavelength, spec);
     FGS_LAUNCH_CHECK("k_spec_pack");
-    if ((rc = fgs_fft_exec(H, W, 2 * B * C, spec, HIPFFT_FORWARD, work, st))) return rc;
+    if ((rc = fgs_fft2_exec(H, W, 2 * B * C, spec, HIPFFT_FORWARD, work, st))) return rc;
     const unsigned nb = part_blocks(p.n);
     hipLaunchKernelGGL(k_spec_reduce, dim3(nb), dim3(RT), 0, st, p.d.mode, W, H, p.n, p.d.cutoff, p.d.high_weight, spec, part);
     FGS_LAUNCH_CHECK("k_spec_reduce");
@@ -413,7 +413,7 @@ int fgs_spectral_loss_backward(const FgsSpectralDims *dims, const float *rendere
                        p.d.high_weight, g_loss, spec);
     FGS_LAUNCH_CHECK("k_spec_grad");
     // adjoint of the unnormalised forward transform: the unnormalised inverse
-    if ((rc = fgs_fft_exec(H, W, 2 * B * C, spec, HIPFFT_BACKWARD, work, st))) return rc;
+    if ((rc = fgs_fft2_exec(H, W, 2 * B * C, spec, HIPFFT_BACKWARD, work, st))) return rc;
     const unsigned nb = part_blocks((size_t)B * HW);
     hipLaunchKernelGGL(k_spec_unpack, dim3(nb), dim3(RT), 0, st, p.d.mode, B, C, HW, p.d.focal_depth, rendered, target,
                        depth, wavelength, spec, g_rendered, g_target, g_depth, part);
