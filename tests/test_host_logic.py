@@ -87,3 +87,61 @@ def test_compute_losses_adds_the_spectral_terms_with_the_reference_weights(monke
             0.1 * FrequencyDomainLoss()(r, t))
     assert abs(float(total) - float(want)) <= 1e-5 * abs(float(want))
     assert {"wave_eq", "phase_retrieval", "frequency"} <= set(d)
+
+
+def test_column_fft_pass_structure_numpy_model():
+    """The in-LDS column FFT of fgs_colfft.h (two fused radix-2 stages per pass over the points i, i + M/4, i + M/2,
+    i + 3M/4; decimation in frequency forward -> bit-reversed order out, decimation in time inverse <- bit-reversed
+    order in; one extra radix-2 pass for odd log2 N), restated index for index in numpy and checked against numpy.fft.
+    The kernels themselves are checked on the GPU (tests/test_hip_asm.py, tests/test_losses.py); this pins the scheme."""
+    def bitrev(r, logn):
+        return int(format(r, "0%db" % logn)[::-1], 2)
+
+    def fft_cols(x, logn, inv):
+        N = 1 << logn
+        x = x.astype(np.complex128).copy()
+        tw = np.exp(-2j * np.pi * np.arange(N // 2) / N)
+
+        def pair():
+            for k in range(N // 2):
+                a, b = x[2 * k], x[2 * k + 1]
+                x[2 * k], x[2 * k + 1] = a + b, a - b
+
+        def quad(M):
+            Q, step = M // 4, N // M
+            for q in range(N // 4):
+                i = q % Q
+                p0 = (q // Q) * M + i
+                p1, p2, p3 = p0 + Q, p0 + 2 * Q, p0 + 3 * Q
+                w1, w2 = tw[i * step], tw[2 * i * step]
+                a0, a1, a2, a3 = x[p0], x[p1], x[p2], x[p3]
+                if not inv:
+                    s02, s13, d02, d13 = a0 + a2, a1 + a3, a0 - a2, a1 - a3
+                    u2, u3 = d02 * w1, (d13 * -1j) * w1
+                    x[p0], x[p1], x[p2], x[p3] = s02 + s13, (s02 - s13) * w2, u2 + u3, (u2 - u3) * w2
+                else:
+                    t1, t3 = a1 * np.conj(w2), a3 * np.conj(w2)
+                    r0, r1, r2, r3 = a0 + t1, a0 - t1, a2 + t3, a2 - t3
+                    v2, v3 = r2 * np.conj(w1), (r3 * np.conj(w1)) * 1j
+                    x[p0], x[p2], x[p1], x[p3] = r0 + v2, r0 - v2, r1 + v3, r1 - v3
+
+        if not inv:
+            for lg in range(logn, 1, -2):
+                quad(1 << lg)
+            if logn & 1:
+                pair()
+        else:
+            if logn & 1:
+                pair()
+            for lg in range(3 if logn & 1 else 2, logn + 1, 2):
+                quad(1 << lg)
+        return x
+
+    rs = np.random.RandomState(0)
+    for logn in (6, 7, 9, 10):
+        N = 1 << logn
+        br = np.array([bitrev(r, logn) for r in range(N)])
+        v = rs.randn(N) + 1j * rs.randn(N)
+        assert np.abs(fft_cols(v, logn, False) - np.fft.fft(v)[br]).max() < 1e-10 * N
+        g = rs.randn(N) + 1j * rs.randn(N)
+        assert np.abs(fft_cols(g[br], logn, True) - np.fft.ifft(g) * N).max() < 1e-10 * N
