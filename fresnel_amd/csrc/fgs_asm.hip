@@ -2,18 +2,19 @@
 // (DR:1150-1344) and AngularSpectrumPropagator (DR:929-1065) and their autograd.
 //
 // Pipeline (forward), all on the caller's stream:
-//   k_project (shared; also assigns the nearest depth plane)  -> binning keyed by (image, plane,
-//   tile) -> k_asm_splat (one wave per (image, plane, tile): complex amplitudes a c e^{i phi},
-//   order-independent sum, DR:1233-1283) -> batched 2-D C2C forward FFT of all B*P*3 plane
-//   fields (hipFFT on rocFFT) -> k_asm_transfer + k_asm_accumulate: acc_c = sum_p F_pc H_pc with
-//   H = exp(i 2 pi z_p sqrt(max(l_c^-2 - fx^2 - fy^2, 0))) (DR:989-999) -> ONE inverse FFT per
-//   (image, channel) instead of one per plane (linearity of the propagation, 3 instead of 48) ->
-//   k_asm_max / k_asm_output: sqrt(|U|^2 + 1e-8), per-image max-normalisation, background
-//   composition and clamps (DR:1315-1332).
-// Backward retraces this with the adjoint transforms (3 forward + B*P*3 inverse FFTs).
+//   k_project (shared; also assigns the nearest depth plane) -> lists per (image, plane, tile) (layered mask binning,
+//   fgs_bin.hip) -> k_asm_prep (phasors c e^{i phi} per Gaussian, transfer functions H = exp(i 2 pi z_p sqrt(max(l_c^-2 -
+//   fx^2 - fy^2, 0))) (DR:989-999), FFT twiddles: one launch) -> k_asm_splat (one wave per list: complex amplitudes
+//   a c e^{i phi}, order-independent sum, DR:1233-1283) -> 2-D forward transform of all B*P*3 plane fields: rocFFT 1-D rows
+//   + k_colfft_fwd, our own column FFT fused with acc_c = sum_p F_pc H_pc (heights 2^6 ... 2^10; otherwise rocFFT's 2-D plan
+//   + k_asm_accumulate) -> ONE inverse transform per (image, channel) instead of one per plane (linearity of the
+//   propagation, 3 instead of 48) -> k_asm_max / k_asm_output: sqrt(|U|^2 + 1e-8), per-image max-normalisation (two-level
+//   reduction, no atomics), background composition and clamps (DR:1315-1332).
+// Backward retraces this with the adjoint transforms (k_colfft_bwd: gAcc conj(H) + the dL/dlambda terms + inverse column
+// FFT, then rocFFT inverse rows).
 //
-// Bounds: the splat is VALU-bound like the compositor; FFTs and the elementwise spectral kernels
-// are HBM-bound (8 B per complex sample per pass).
+// Bounds: the splat is VALU-bound on long lists and HBM-bound on config 5's short ones; the transforms are HBM-bound (8 B
+// per complex sample per pass, two passes per 2-D transform).
 //
 // Compiled WITHOUT fast-math: the transfer-function phase reaches ~200 rad, so sin/cos need the
 // accurate range reduction of sincosf.

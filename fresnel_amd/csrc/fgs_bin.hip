@@ -1,4 +1,4 @@
-// Stage 2: depth order + per-tile duplication + tile sort + tile ranges.
+// Stage 2: depth order + per-tile lists (mask binning; emit + tile sort as the fallback) + tile tables.
 // New design (the reference renderer has no tiles: it walks each depth-sorted Gaussian's
 // integer bbox, DR:582-600).  A tile's list = the Gaussians whose reference bbox intersects
 // the tile, in the reference's depth order, so compositing a tile list reproduces DR:582-667

@@ -1,5 +1,6 @@
 // hipFFT (rocFFT) plan cache shared by the angular-spectrum renderer, the standalone propagator and the spectral
-// losses: batched 2-D C2C transforms, in place, caller-provided work areas.
+// losses: batched C2C transforms (2-D, and 1-D rows), in place, caller-provided work areas; and fgs_fft2_exec, the 2-D
+// transform with our own column pass (end of file).
 #include <hipfft/hipfft.h>
 #include <map>
 #include <memory>
