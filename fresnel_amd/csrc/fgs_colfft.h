@@ -53,14 +53,86 @@ __device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *t
         }
         __syncthreads();
     };
+    // THREE radix-2 stages per pass (block sizes M, M/2, M/4) on the eight points i + k M/8: with NT = N TC / 8 threads
+    // every thread does exactly one 8-point butterfly per pass, and a 512-point column needs three passes (and barriers)
+    // instead of five.  w_M^(i + k M/8) = w_M^i w_8^k, w_(M/2)^(i + k' M/8) = w_M^(2i) w_4^k', w_(M/4)^i = w_M^(4i).
+    auto oct_pass = [&](int M) {
+        const int E = M / 8, step = N / M;
+        constexpr float S = 0.70710678118654752440f;
+#pragma unroll 1
+        for (int idx = threadIdx.x; idx < (N / 8) * TC; idx += NT) {
+            const int col = idx % TC, q = idx / TC;
+            const int i = q % E, b0 = (q / E) * M + i;
+            const float2 t1 = tw[i * step], t2 = tw[2 * i * step], t4 = tw[4 * i * step];
+            float2 a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = x[b0 + k * E][col];
+            if (!INV) {
+                float2 s[4], d[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s[k] = cadd(a[k], a[k + 4]); d[k] = csub(a[k], a[k + 4]); }
+                d[1] = make_float2(S * (d[1].x + d[1].y), S * (d[1].y - d[1].x));   // w_8
+                d[2] = make_float2(d[2].y, -d[2].x);                                 // w_8^2 = -i
+                d[3] = make_float2(S * (d[3].y - d[3].x), -S * (d[3].x + d[3].y));  // w_8^3
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = fgs_cmul(d[k], t1);
+                float2 b[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float2 *v = h ? d : s;
+                    const float2 e13 = csub(v[1], v[3]);
+                    b[4 * h + 0] = cadd(v[0], v[2]);
+                    b[4 * h + 1] = cadd(v[1], v[3]);
+                    b[4 * h + 2] = fgs_cmul(csub(v[0], v[2]), t2);
+                    b[4 * h + 3] = fgs_cmul(make_float2(e13.y, -e13.x), t2);        // w_4 = -i
+                }
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    x[b0 + (2 * qd) * E][col] = cadd(b[2 * qd], b[2 * qd + 1]);
+                    x[b0 + (2 * qd + 1) * E][col] = fgs_cmul(csub(b[2 * qd], b[2 * qd + 1]), t4);
+                }
+            } else {
+                float2 b[8];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float2 v = cmulc(a[2 * qd + 1], t4);
+                    b[2 * qd] = cadd(a[2 * qd], v);
+                    b[2 * qd + 1] = csub(a[2 * qd], v);
+                }
+                float2 s[4], d[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float2 *o = h ? d : s;
+                    const float2 v2 = cmulc(b[4 * h + 2], t2), v3t = cmulc(b[4 * h + 3], t2);
+                    const float2 v3 = make_float2(-v3t.y, v3t.x);                    // conj(w_4) = +i
+                    o[0] = cadd(b[4 * h + 0], v2); o[2] = csub(b[4 * h + 0], v2);
+                    o[1] = cadd(b[4 * h + 1], v3); o[3] = csub(b[4 * h + 1], v3);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = cmulc(d[k], t1);
+                d[1] = make_float2(S * (d[1].x - d[1].y), S * (d[1].x + d[1].y));   // conj(w_8)
+                d[2] = make_float2(-d[2].y, d[2].x);                                 // +i
+                d[3] = make_float2(-S * (d[3].x + d[3].y), S * (d[3].x - d[3].y));  // conj(w_8^3)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    x[b0 + k * E][col] = cadd(s[k], d[k]);
+                    x[b0 + (k + 4) * E][col] = csub(s[k], d[k]);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    constexpr int NOCT = LOGN / 3, REM = LOGN - 3 * NOCT;  // radix-8 passes from the top, then one radix-4 / radix-2 pass
     if (!INV) {
 #pragma unroll
-        for (int lg = LOGN; lg >= 2; lg -= 2) quad_pass(1 << lg);
-        if (LOGN & 1) pair_pass();
+        for (int o = 0; o < NOCT; ++o) oct_pass(1 << (LOGN - 3 * o));
+        if (REM == 2) quad_pass(4);
+        if (REM == 1) pair_pass();
     } else {
-        if (LOGN & 1) pair_pass();
+        if (REM == 2) quad_pass(4);
+        if (REM == 1) pair_pass();
 #pragma unroll
-        for (int lg = (LOGN & 1) ? 3 : 2; lg <= LOGN; lg += 2) quad_pass(1 << lg);
+        for (int o = NOCT - 1; o >= 0; --o) oct_pass(1 << (LOGN - 3 * o));
     }
 }
 
