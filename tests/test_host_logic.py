@@ -90,10 +90,14 @@ def test_compute_losses_adds_the_spectral_terms_with_the_reference_weights(monke
 
 
 def test_column_fft_pass_structure_numpy_model():
-    """The in-LDS column FFT of fgs_colfft.h (two fused radix-2 stages per pass over the points i, i + M/4, i + M/2,
-    i + 3M/4; decimation in frequency forward -> bit-reversed order out, decimation in time inverse <- bit-reversed
-    order in; one extra radix-2 pass for odd log2 N), restated index for index in numpy and checked against numpy.fft.
-    The kernels themselves are checked on the GPU (tests/test_hip_asm.py, tests/test_losses.py); this pins the scheme."""
+    """The in-LDS column FFT of fgs_colfft.h restated index for index in numpy and checked against numpy.fft: radix-8
+    passes (three radix-2 stages on the points i + k M/8, twiddles w_M^i w_8^k / w_M^2i w_4^k' / w_M^4i), then one radix-4
+    or radix-2 pass for the remaining stages; decimation in frequency forward -> bit-reversed order out, decimation in
+    time inverse <- bit-reversed order in.  The kernels themselves are checked on the GPU (tests/test_hip_asm.py,
+    tests/test_losses.py); this pins the scheme."""
+    S = np.sqrt(0.5)
+    W8 = [1, S * (1 - 1j), -1j, S * (-1 - 1j)]
+
     def bitrev(r, logn):
         return int(format(r, "0%db" % logn)[::-1], 2)
 
@@ -125,20 +129,53 @@ def test_column_fft_pass_structure_numpy_model():
                     v2, v3 = r2 * np.conj(w1), (r3 * np.conj(w1)) * 1j
                     x[p0], x[p2], x[p1], x[p3] = r0 + v2, r0 - v2, r1 + v3, r1 - v3
 
-        if not inv:
-            for lg in range(logn, 1, -2):
-                quad(1 << lg)
-            if logn & 1:
-                pair()
-        else:
-            if logn & 1:
-                pair()
-            for lg in range(3 if logn & 1 else 2, logn + 1, 2):
-                quad(1 << lg)
+        def octp(M):
+            E, step = M // 8, N // M
+            for q in range(N // 8):
+                i = q % E
+                p = [(q // E) * M + i + k * E for k in range(8)]
+                t1, t2, t4 = tw[i * step], tw[2 * i * step], tw[4 * i * step]
+                a = [x[pp] for pp in p]
+                if not inv:
+                    s = [a[k] + a[k + 4] for k in range(4)]
+                    d = [(a[k] - a[k + 4]) * W8[k] * t1 for k in range(4)]
+                    b = []
+                    for h in (s, d):
+                        b += [h[0] + h[2], h[1] + h[3], (h[0] - h[2]) * t2, (h[1] - h[3]) * (-1j) * t2]
+                    out = []
+                    for qd in range(4):
+                        out += [b[2 * qd] + b[2 * qd + 1], (b[2 * qd] - b[2 * qd + 1]) * t4]
+                else:
+                    c1, c2, c4 = np.conj(t1), np.conj(t2), np.conj(t4)
+                    b = []
+                    for qd in range(4):
+                        v = a[2 * qd + 1] * c4
+                        b += [a[2 * qd] + v, a[2 * qd] - v]
+                    sd = []
+                    for h in (b[0:4], b[4:8]):
+                        v2, v3 = h[2] * c2, h[3] * c2 * 1j
+                        sd.append([h[0] + v2, h[1] + v3, h[0] - v2, h[1] - v3])
+                    out = [0] * 8
+                    for k in range(4):
+                        v = sd[1][k] * np.conj(W8[k]) * c1
+                        out[k], out[k + 4] = sd[0][k] + v, sd[0][k] - v
+                for k in range(8):
+                    x[p[k]] = out[k]
+
+        seq, lg = [], logn
+        while lg >= 3:
+            seq.append(("o", lg))
+            lg -= 3
+        if lg == 2:
+            seq.append(("q", 2))
+        if lg == 1:
+            seq.append(("p", 1))
+        for kind, l in (seq[::-1] if inv else seq):
+            octp(1 << l) if kind == "o" else (quad(1 << l) if kind == "q" else pair())
         return x
 
     rs = np.random.RandomState(0)
-    for logn in (6, 7, 9, 10):
+    for logn in (6, 7, 8, 9, 10):
         N = 1 << logn
         br = np.array([bitrev(r, logn) for r in range(N)])
         v = rs.randn(N) + 1j * rs.randn(N)
