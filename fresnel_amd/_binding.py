@@ -35,7 +35,7 @@ class FgsDims(ctypes.Structure):
                 ("use_phase", ctypes.c_int32), ("phase_amplitude", ctypes.c_float),
                 ("num_cameras", ctypes.c_int32), ("saturation_skip", ctypes.c_int32),
                 ("seg_len", ctypes.c_int32), ("fwd_variant", ctypes.c_int32), ("bin_mode", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("tile_w", ctypes.c_int32)]
 
 
 class FgsSavedLayout(ctypes.Structure):
@@ -47,7 +47,7 @@ class FgsSavedLayout(ctypes.Structure):
                 ("dup_capacity", ctypes.c_size_t),
                 ("tiles_x", ctypes.c_int32), ("tiles_y", ctypes.c_int32),
                 ("seg_off", ctypes.c_size_t), ("seg_tile", ctypes.c_size_t), ("seg_ckpt", ctypes.c_size_t),
-                ("seg_capacity", ctypes.c_size_t), ("seg_len", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("seg_capacity", ctypes.c_size_t), ("seg_len", ctypes.c_int32), ("tile_w", ctypes.c_int32)]
 
 
 class FgsAsmDims(ctypes.Structure):
@@ -158,7 +158,7 @@ def make_dims(batch, num_gaussians, width, height, max_radius=64.0, background=(
     d.num_cameras = int(num_cameras)
     d.saturation_skip = 1 if saturation_skip else 0
     for k, v in (tuning or {}).items():
-        if k not in ("seg_len", "fwd_variant", "bin_mode"):
+        if k not in ("seg_len", "fwd_variant", "bin_mode", "tile_w"):
             raise FgsError(f"unknown tuning field {k!r}")
         setattr(d, k, int(v))
     return d

@@ -67,9 +67,9 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     }
     const int fv = d->fwd_variant, afv = fv < 0 ? -fv : fv;
     if ((d->seg_len != 0 && d->seg_len != 64 && d->seg_len != FGS_SEG) || (afv != 0 && afv != 1 && afv != 2 && afv != 4) ||
-        d->bin_mode < 0 || d->bin_mode > 2 || d->reserved != 0) {
-        fgs_set_error("invalid tuning: seg_len=%d fwd_variant=%d bin_mode=%d reserved=%d", d->seg_len, d->fwd_variant,
-                      d->bin_mode, d->reserved);
+        d->bin_mode < 0 || d->bin_mode > 2 || (d->tile_w != 0 && d->tile_w != 16 && d->tile_w != 32)) {
+        fgs_set_error("invalid tuning: seg_len=%d fwd_variant=%d bin_mode=%d tile_w=%d", d->seg_len, d->fwd_variant,
+                      d->bin_mode, d->tile_w);
         return FGS_EINVAL;
     }
     const size_t B = d->batch, N = d->num_gaussians;
@@ -77,10 +77,21 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     memset(p, 0, sizeof(*p));
     p->d = *d;
     p->layers = layers;
-    const int tx = (d->width + FGS_TILE - 1) / FGS_TILE, ty = (d->height + FGS_TILE - 1) / FGS_TILE;
+    // Tile width.  32 x 16 tiles (eight 8 x 8 sub-tiles per lane) on the blend path with the depth-split forward: a Gaussian
+    // touches ~0.6x as many tiles, so everything paid per (tile, Gaussian) duplicate -- LDS record reads, row / column
+    // terms, the ten-sum reduction and its gradient row, the row-sum traffic, the lists -- is paid 0.6x as often.  The phase
+    // path (one wave per sub-tile), the row-split forward (saturation_skip / fwd_variant < 0) and the splat renderers
+    // (layers > 1 or no segment checkpoints) keep 16 x 16.
+    const bool wide_ok = !d->use_phase && !d->saturation_skip && d->fwd_variant >= 0 && layers == 1 && segment_ckpt;
+    if (d->tile_w == 32 && !wide_ok) {
+        fgs_set_error("tile_w=32 needs the blend path with the depth-split forward");
+        return FGS_EINVAL;
+    }
+    p->tile_w = d->tile_w ? d->tile_w : (wide_ok ? 32 : 16);
+    const int tx = (d->width + p->tile_w - 1) / p->tile_w, ty = (d->height + FGS_TILE - 1) / FGS_TILE;
     p->tiles = tx * ty;
-    // bbox width <= floor(2r)+2 pixels -> spans at most floor((2r+1)/16)+2 tile columns
-    int span = (int)((2.0 * (double)d->max_radius + 1.0) / FGS_TILE) + 2;
+    // bbox width <= floor(2r)+2 pixels -> spans at most floor((2r+1)/tile)+2 tile columns
+    int span = (int)((2.0 * (double)d->max_radius + 1.0) / p->tile_w) + 2;
     if (span > tx) span = tx;
     int spany = (int)((2.0 * (double)d->max_radius + 1.0) / FGS_TILE) + 2;
     if (spany > ty) spany = ty;
@@ -146,7 +157,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
                       FGS_BIN_MAX_TILES, FGS_MASK_MAX_LINES);
         return FGS_EINVAL;
     }
-    L.reserved = 0;
+    L.tile_w = p->tile_w;
     const size_t ucap = dcap / L.seg_len + B * layers * p->tiles;
     L.seg_off = o; L.seg_tile = o; L.seg_ckpt = o; L.seg_capacity = 0;
     if (!d->use_phase) {
@@ -154,7 +165,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
         L.seg_off = o; o = align256(o + (B * layers * p->tiles + 1) * 4);
         L.seg_tile = o; o = align256(o + ucap * 4);
         L.seg_ckpt = o;
-        if (segment_ckpt && layers == 1) o = align256(o + ucap * 5 * 256 * 4);
+        if (segment_ckpt && layers == 1) o = align256(o + ucap * 5 * 64 * (size_t)(p->tile_w / 4) * 4);  // 5 x sub-tiles x 64 floats per slot
     }
     L.total_bytes = o;
     L.dup_capacity = dcap;

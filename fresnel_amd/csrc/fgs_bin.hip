@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
                                                   const float *__restrict__ rec,
                                                   const uint32_t *__restrict__ bsum,
                                                   const uint32_t *__restrict__ layer, uint32_t layers,
-                                                  uint32_t *__restrict__ dup_off,
+                                                  uint32_t tile_w, uint32_t *__restrict__ dup_off,
                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t gid, tot;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
     if (c != 0) {
         const uint32_t bbx = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBX]);
         const uint32_t bby = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBY]);
-        tx0 = (bbx & 0xFFFFu) / FGS_TILE;
+        tx0 = (bbx & 0xFFFFu) / tile_w;
         ty0 = (bby & 0xFFFFu) / FGS_TILE;
-        w = ((bbx >> 16) - 1) / FGS_TILE - tx0 + 1;
+        w = ((bbx >> 16) - 1) / tile_w - tx0 + 1;
         kbase = ((gid / N) * layers + (layer ? layer[gid] : 0u)) * tiles;
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -123,14 +123,14 @@ __global__ __launch_bounds__(256) void k_dup_emit(uint32_t total, uint32_t N, ui
 }
 
 struct TileRect { uint32_t tx0, ty0, w, cnt; };
-__device__ __forceinline__ TileRect tile_rect(const float *__restrict__ rec, uint32_t gid, uint32_t cnt) {
+__device__ __forceinline__ TileRect tile_rect(const float *__restrict__ rec, uint32_t gid, uint32_t cnt, uint32_t tile_w) {
     TileRect r = {0, 0, 1, cnt};
     if (cnt) {
         const uint32_t bbx = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBX]);
         const uint32_t bby = __float_as_uint(rec[(size_t)gid * FGS_REC_FLOATS + R_BBY]);
-        r.tx0 = (bbx & 0xFFFFu) / FGS_TILE;
+        r.tx0 = (bbx & 0xFFFFu) / tile_w;
         r.ty0 = (bby & 0xFFFFu) / FGS_TILE;
-        r.w = ((bbx >> 16) - 1) / FGS_TILE - r.tx0 + 1;
+        r.w = ((bbx >> 16) - 1) / tile_w - r.tx0 + 1;
     }
     return r;
 }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_mask_build(uint32_t N, uint32_t tiles_x
                                                     unsigned long long *__restrict__ masks,
                                                     uint32_t *__restrict__ bsum, uint32_t nrb, uint32_t layers,
                                                     const uint32_t *__restrict__ plane_keys,
-                                                    uint32_t *__restrict__ plane_start) {
+                                                    uint32_t *__restrict__ plane_start, uint32_t tile_w) {
     __shared__ unsigned long long sm[MB_MAX_LINES][4];
     __shared__ uint32_t wtot[4];
     if (blockIdx.x >= nrb) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_mask_build(uint32_t N, uint32_t tiles_x
     uint32_t cnt = 0, tx0 = 0xFFFFu, tx1 = 0, ty0 = 0xFFFFu, ty1 = 0;
     if (r < N) {
         const uint32_t gid = b * N + order[b * N + r];
-        const TileRect q = tile_rect(rec, gid, tile_count[gid]);
+        const TileRect q = tile_rect(rec, gid, tile_count[gid], tile_w);
         cnt = q.cnt;
         if (cnt) { tx0 = q.tx0; tx1 = q.tx0 + q.w - 1u; ty0 = q.ty0; ty1 = q.ty0 + cnt / q.w - 1u; }
     }
@@ -684,7 +684,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         const uint32_t npb = layers > 1 ? (B * (layers + 1) + 255) / 256 : 0u;  // blocks that find the plane ranges
         fgs_stage_begin(ST_DUP_EMIT, st);
         hipLaunchKernelGGL(k_mask_build, dim3(nrb + npb), dim3(256), 0, st, N, tiles_x, tiles_y, bpi, w64p, order,
-                           tile_count, rec, masks, bsum, nrb, layers, plane_keys, plane_start);
+                           tile_count, rec, masks, bsum, nrb, layers, plane_keys, plane_start, (uint32_t)p.tile_w);
         FGS_LAUNCH_CHECK("k_mask_build");
 #define FGS_MASK_COUNT(W) hipLaunchKernelGGL(k_mask_count<W>, dim3(ntb + 1), dim3(256), 0, st, B, N, layers, plane_start, \
                                              (uint32_t)p.tiles, tiles_x, lines, w64p, nrb, masks, lens, bsum, counters, dcap)
@@ -717,7 +717,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     hipLaunchKernelGGL(k_dup_emit, dim3(nblk), dim3(256), 0, st, total, N, (uint32_t)p.tiles,
                        (uint32_t)p.L.tiles_x, dcap, order, tile_count, rec, bsum,
                        p.layers > 1 ? reinterpret_cast<const uint32_t *>(saved + p.s_layer) : nullptr,
-                       (uint32_t)p.layers, reinterpret_cast<uint32_t *>(saved + p.L.dup_off), keys0, vals0);
+                       (uint32_t)p.layers, (uint32_t)p.tile_w, reinterpret_cast<uint32_t *>(saved + p.L.dup_off), keys0, vals0);
     FGS_LAUNCH_CHECK("k_dup_emit");
     fgs_stage_end(ST_DUP_EMIT, st);
     fgs_stage_begin(ST_TILE_SORT, st);

@@ -58,14 +58,14 @@ struct TileCtx {
 };
 
 __device__ __forceinline__ TileCtx tile_ctx_of(uint32_t tile, uint32_t tiles, uint32_t tiles_x,
-                                               const uint32_t *__restrict__ ranges) {
+                                               const uint32_t *__restrict__ ranges, uint32_t tile_w = FGS_TILE) {
     TileCtx c;
     c.tile = tile;
     c.b = c.tile / tiles;
     const uint32_t t = c.tile - c.b * tiles;
     c.ty = t / tiles_x;
     c.tx = t - c.ty * tiles_x;
-    c.X0 = c.tx * FGS_TILE;
+    c.X0 = c.tx * tile_w;
     c.Y0 = c.ty * FGS_TILE;
     c.start = ranges[2 * c.tile];
     c.end = ranges[2 * c.tile + 1];
@@ -74,8 +74,8 @@ __device__ __forceinline__ TileCtx tile_ctx_of(uint32_t tile, uint32_t tiles, ui
 
 __device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x,
                                             const uint32_t *__restrict__ tile_order,
-                                            const uint32_t *__restrict__ ranges) {
-    return tile_ctx_of(tile_order ? tile_order[blockIdx.x] : blockIdx.x, tiles, tiles_x, ranges);
+                                            const uint32_t *__restrict__ ranges, uint32_t tile_w = FGS_TILE) {
+    return tile_ctx_of(tile_order ? tile_order[blockIdx.x] : blockIdx.x, tiles, tiles_x, ranges, tile_w);
 }
 
 
@@ -303,22 +303,29 @@ struct BlendState { float Cr, Cg, Cb, T, D; };
 __device__ __forceinline__ BlendState compose(const BlendState &a, const BlendState &b) {
     return {a.Cr + a.T * b.Cr, a.Cg + a.T * b.Cg, a.Cb + a.T * b.Cb, a.T * b.T, a.D + a.T * b.D};
 }
-__device__ __forceinline__ void ckpt_store(float *ck, const BlendState &v) {  // [5][4][64] slot, this lane's cell
-    ck[0] = v.Cr; ck[256] = v.Cg; ck[2 * 256] = v.Cb; ck[3 * 256] = 1.0f - v.T; ck[4 * 256] = v.D;
+// [5][NS][64] slot (NS = 4 sub-tiles of a 16 x 16 tile, 8 of a 32 x 16 tile), this lane's cell; PL = NS * 64
+template <int PL = 256>
+__device__ __forceinline__ void ckpt_store(float *ck, const BlendState &v) {
+    ck[0] = v.Cr; ck[PL] = v.Cg; ck[2 * PL] = v.Cb; ck[3 * PL] = 1.0f - v.T; ck[4 * PL] = v.D;
 }
+template <int PL = 256>
 __device__ __forceinline__ BlendState ckpt_load(const float *ck) {
-    return {ck[0], ck[256], ck[2 * 256], 1.0f - ck[3 * 256], ck[4 * 256]};
+    return {ck[0], ck[PL], ck[2 * PL], 1.0f - ck[3 * PL], ck[4 * PL]};
 }
 
-template <int NP>
-__global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blend_fwd_parts(  // 64 VGPRs: -2.6 %
+// NSX = sub-tile columns of the tile: 2 (16 x 16 tiles) or 4 (32 x 16 tiles, FgsSavedLayout.tile_w = 32: eight sub-tiles
+// per lane; 80 VGPRs = 6 waves per SIMD instead of 8, but every list entry's staging, LDS reads and row terms are
+// amortised over up to eight sub-tile passes and there are ~0.6x as many entries).
+template <int NP, int NSX>
+__global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 8 : 5, NSX == 2 ? 8 : 5))) void k_blend_fwd_parts(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, float *__restrict__ pix_state,
     float *__restrict__ out_rgb, float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off,
     float *__restrict__ seg_ckpt, uint32_t seg_len) {
+    constexpr int NS = 2 * NSX, PL = NS * 64, SLOT = 5 * PL;  // sub-tiles per tile, floats per checkpoint plane / slot
     __shared__ float4 sh0[NP][64], sh1[NP][64], sh2[NP][64];
-    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
+    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges, 8u * NSX);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lx = lane & 7u, ly = lane >> 3;
@@ -328,28 +335,28 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const bool active = first_seg < nseg;
     const uint32_t pstart = c.start + first_seg * seg_len;
     const uint32_t pend = active ? min(c.end, pstart + spp * seg_len) : pstart;
-    float *slot0 = seg_ckpt + (size_t)seg_off[c.tile] * (5 * 256) + lane;  // + s * 64 per sub-tile
-    float T[4], Cr[4], Cg[4], Cb[4], Dm[4];
+    float *slot0 = seg_ckpt + (size_t)seg_off[c.tile] * SLOT + lane;  // + s * 64 per sub-tile
+    float T[NS], Cr[NS], Cg[NS], Cb[NS], Dm[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; }
-    const uint32_t shx = lx, shy = 16u + ly;
-    float fx0 = (float)(c.X0 + lx), fx1 = (float)(c.X0 + lx + 8u), fy0 = (float)(c.Y0 + ly);
-    asm("" : "+v"(fx0), "+v"(fx1), "+v"(fy0));
+    for (int s = 0; s < NS; ++s) { T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; }
+    const uint32_t shx = lx, shy = 16u + ly;  // this lane's column bit in cbits / row bit in flags
+    float fx0 = (float)(c.X0 + lx), fy0 = (float)(c.Y0 + ly);
+    asm("" : "+v"(fx0), "+v"(fy0));
     for (uint32_t base = pstart; base < pend; base += 64) {
         const uint32_t n = min(64u, pend - base);
         if (base != pstart && ((base - c.start) % seg_len) == 0) {  // LOCAL state in front of this segment
-            float *ck = slot0 + (size_t)((base - c.start) / seg_len) * (5 * 256);
+            float *ck = slot0 + (size_t)((base - c.start) / seg_len) * SLOT;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) ckpt_store(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
+            for (int s = 0; s < NS; ++s) ckpt_store<PL>(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
         }
         if (lane < n) {
             const uint32_t gid = dup_ids[base + lane];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
             float4 q0 = r[0], q1 = r[1], q2 = r[2];
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
-            uint32_t flags, bits;
-            stage_decode(c.X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, bits);
-            q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
+            uint32_t flags, cbits;
+            stage_decode_w<NSX>(c.X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, cbits);
+            q2.z = __uint_as_float(cbits); q2.w = __uint_as_float(flags);
             // alpha = min(G op, 0.99) = 0.99 clamp01(G op / 0.99): the list loop forms a' = clamp01(G op') with the
             // FREE clamp modifier of v_mul instead of a v_min (4.3 issue cycles on gfx950), the 0.99 rides on the
             // colours / depth (w c = (a' T)(0.99 c)) and on the transmittance update (T -= 0.99 a' T, one v_fmac with a
@@ -361,37 +368,37 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
         __builtin_amdgcn_wave_barrier();  // wave-private LDS: one wave's LDS instructions execute in order
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[wave][j], q1 = sh1[wave][j], q2 = sh2[wave][j];
-            const uint32_t fl = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));  // stage_decode flags
-            const uint32_t msk = fl & 15u;
+            const uint32_t fl = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));  // stage_decode_w flags
+            const uint32_t msk = fl & ((1u << NS) - 1u);
             if (!msk) continue;
             // (Skipping the lane masks for entries whose bbox covers the tile, or the min for opacities <= 0.98, behind
             // wave-uniform branches -- what pays in the backward -- made this loop 10 % SLOWER: 0.68 -> 0.75 ms at config 3;
             // its passes are too short to amortise a branch.)
-            constexpr bool inside = false;
-            const uint32_t bits = __float_as_uint(q2.z);
-            // the lane's two column masks once per entry (3.3 sub-tile passes per entry on average: -2.8 %)
-            const uint32_t mxc[2] = {(uint32_t)__builtin_amdgcn_sbfe((int)bits, shx, 1), (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u, 1)};
-            // ... and its two column offsets (3.3 passes per entry: one subtraction per pass would be more)
-            float dxc[2] = {fx0 - q0.x, fx1 - q0.x};
+            const uint32_t cbits = __float_as_uint(q2.z), rbits = __float_as_uint(q2.w);
+            // the lane's column masks and column offsets once per entry (3.3 sub-tile passes per entry on 16 x 16 tiles)
+            uint32_t mxc[NSX];
+            float dxc[NSX];
+#pragma unroll
+            for (int col = 0; col < NSX; ++col) {
+                mxc[col] = (uint32_t)__builtin_amdgcn_sbfe((int)cbits, shx + 8u * col, 1);
+                dxc[col] = fx0 + 8.0f * col - q0.x;
+            }
             asm("" : "+v"(dxc[0]), "+v"(dxc[1]));
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
-                if (!((msk >> (2 * row)) & 3u)) continue;
+                if (!((msk >> (NSX * row)) & ((1u << NSX) - 1u))) continue;
                 const float dy = row ? fy0 + 8.0f - q0.y : fy0 - q0.y;
                 const float bdy = q0.w * dy, cyy = (q1.x * dy) * dy;
-                uint32_t my = ~0u;
-                if (!inside) my = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u * row, 1);
+                const uint32_t my = (uint32_t)__builtin_amdgcn_sbfe((int)rbits, shy + 8u * row, 1);
 #pragma unroll
-                for (int col = 0; col < 2; ++col) {
-                    const int s = 2 * row + col;
+                for (int col = 0; col < NSX; ++col) {
+                    const int s = NSX * row + col;
                     if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
                     const float dx = dxc[col];
                     const float t = q0.z * dx + bdy;
                     float G = __builtin_amdgcn_exp2f(t * dx + cyy);
-                    if (!inside) {
-                        const uint32_t mk = my & mxc[col];
-                        G = __uint_as_float(__float_as_uint(G) & mk);
-                    }
+                    const uint32_t mk = my & mxc[col];
+                    G = __uint_as_float(__float_as_uint(G) & mk);
                     float a1;  // alpha / 0.99, opacity >= 0 here
                     asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(a1) : "v"(G), "v"(q1.y));
                     const float w = a1 * T[s];  // (alpha T) / 0.99
@@ -406,27 +413,27 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint32_t last = nseg ? (nseg - 1) / spp : 0u;
     if (NP > 1 && nseg > spp) {  // more than one part
         if (active && wave != 0) {
-            float *ck = (wave == last) ? slot0 : slot0 + (size_t)((wave + 1) * spp) * (5 * 256);
+            float *ck = (wave == last) ? slot0 : slot0 + (size_t)((wave + 1) * spp) * SLOT;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) ckpt_store(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
+            for (int s = 0; s < NS; ++s) ckpt_store<PL>(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
         }
         __threadfence_block();
         __syncthreads();
         if (wave != 0) return;
         // wave 0: its own result is the absolute state in front of part 1
         {
-            float *ck = slot0 + (size_t)spp * (5 * 256);
+            float *ck = slot0 + (size_t)spp * SLOT;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) ckpt_store(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
+            for (int s = 0; s < NS; ++s) ckpt_store<PL>(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
         }
         for (uint32_t pp = 1; pp <= last; ++pp) {
-            const float *src = (pp == last) ? slot0 : slot0 + (size_t)((pp + 1) * spp) * (5 * 256);
-            float *dst = slot0 + (size_t)((pp + 1) * spp) * (5 * 256);
+            const float *src = (pp == last) ? slot0 : slot0 + (size_t)((pp + 1) * spp) * SLOT;
+            float *dst = slot0 + (size_t)((pp + 1) * spp) * SLOT;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const BlendState acc = compose(BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]}, ckpt_load(src + s * 64));
+            for (int s = 0; s < NS; ++s) {
+                const BlendState acc = compose(BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]}, ckpt_load<PL>(src + s * 64));
                 Cr[s] = acc.Cr; Cg[s] = acc.Cg; Cb[s] = acc.Cb; T[s] = acc.T; Dm[s] = acc.D;
-                if (pp != last) ckpt_store(dst + s * 64, acc);
+                if (pp != last) ckpt_store<PL>(dst + s * 64, acc);
             }
         }
     } else if (wave != 0) {
@@ -434,8 +441,8 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     const size_t HW = (size_t)W * H;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t px = c.X0 + 8u * (s % NSX) + lx, py = c.Y0 + 8u * (s / NSX) + ly;
         if (px < W && py < H) {
             const size_t o = (size_t)py * W + px;
             float *ps = pix_state + (size_t)c.b * 6 * HW + o;
@@ -468,7 +475,10 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(8, 8)))
 // per-pixel checkpoint in front of its segment, so units are independent and of bounded length.
 // Six waves per SIMD (80 VGPRs): the loop is bound by VALU issue with dependent chains in every pass (exp -> alpha -> w
 // -> S -> rcp -> dalpha), and the sixth wave buys 4 % (1.37 -> 1.31 ms at config 3); a seventh needs spills and loses 35 %.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_composite_bwd(
+// NSX = sub-tile columns of the tile: 2 (16 x 16 tiles) or 4 (32 x 16 tiles: eight sub-tiles per lane, ~0.6x as many list
+// entries, reductions and gradient rows; 5 waves per SIMD instead of 6 -- the loop is issue-bound, not latency-bound).
+template <int NSX>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6 : 5, NSX == 2 ? 6 : 5))) void k_composite_bwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, uint32_t dcap,
     const uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg_off,
     const uint32_t *__restrict__ seg_tile, const float *__restrict__ seg_ckpt, const uint32_t *__restrict__ ranges,
@@ -480,6 +490,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     __shared__ __attribute__((aligned(16))) float red[10 * FGS_RED_PITCH];  // per-lane partial sums of one list entry
     // work unit = (tile, depth segment): blockIdx.x indexes the unit list built by k_tile_order; the grid is
     // sized from the capacity, surplus blocks leave at once
+    constexpr int NS = 2 * NSX, PL = NS * 64, SLOT = 5 * PL;  // sub-tiles per tile, floats per checkpoint plane / slot
     const uint32_t num_units = counters[2];
     if (blockIdx.x >= num_units) return;
     // units are listed tile by tile: an XCD gets a contiguous run of them, so neighbouring tiles -- which share
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     const uint32_t fwd_parts = (int32_t)counters[5] > 1 ? counters[5] : 0u;
     const uint32_t unit_tile = seg_tile[unit];
     const uint32_t seg = unit - seg_off[unit_tile];
-    TileCtx c = tile_ctx_of(unit_tile, tiles, tiles_x, ranges);
+    TileCtx c = tile_ctx_of(unit_tile, tiles, tiles_x, ranges, 8u * NSX);
     uint32_t rebase_seg = seg;  // first segment of this segment's list part if its checkpoint is part-local
     if (fwd_parts > 1) {
         const uint32_t nseg = (c.end - c.start + seg_len - 1) / seg_len;
@@ -506,13 +517,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     if (t_eps > 0.0f) {
         // FgsDims.saturation_skip: the forward stopped walking this tile's list after `live` segments (count
         // parked in the checkpoint slot of segment 0); the entries of a dead segment get all-zero gradient rows
-        const uint32_t live = reinterpret_cast<const uint32_t *>(seg_ckpt + (size_t)seg_off[unit_tile] * (5 * 256))[0];
+        const uint32_t live = reinterpret_cast<const uint32_t *>(seg_ckpt + (size_t)seg_off[unit_tile] * SLOT)[0];
         if (seg >= live) {
             for (uint32_t i = c.start + lane; i < c.end; i += 64) {
                 const uint32_t gid = dup_ids[i];
                 const float4 q2 = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS)[2];
                 const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
-                const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
+                const uint32_t tx0 = (bbx & 0xFFFFu) / (8u * NSX), tx1 = ((bbx >> 16) - 1) / (8u * NSX);
                 const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE;
                 const uint32_t e = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
                 if (e < dcap) {
@@ -525,10 +536,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     }
     // T: running transmittance (w = alpha T, T -= w: one instruction less per pixel than T = 1 - A, A += w)
     // S: T_fin (gI.bg) + sum over not-yet-visited w q
-    float gr[4], gg[4], gb[4], gd[4], S[4], T[4];
+    float gr[NS], gg[NS], gb[NS], gd[NS], S[NS], T[NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const uint32_t px = c.X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t px = c.X0 + 8u * (s % NSX) + lx, py = c.Y0 + 8u * (s / NSX) + ly;
         gr[s] = gg[s] = gb[s] = gd[s] = S[s] = 0.0f;
         T[s] = 1.0f;
         if (px < W && py < H) {
@@ -550,21 +561,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             // belongs to the list entries before it.  After a depth-split forward (k_blend_fwd_parts, fwd_parts
             // waves per tile) the checkpoint of a segment inside part p > 0 is local to that part and is re-based
             // with the absolute state kept in the slot of the part's first segment.
-            BlendState st = ckpt_load(seg_ckpt + (size_t)unit * (5 * 256) + s * 64 + lane);
+            BlendState st = ckpt_load<PL>(seg_ckpt + (size_t)unit * SLOT + s * 64 + lane);
             if (rebase_seg != seg) {
                 const size_t slot = (size_t)unit - seg + rebase_seg;
-                st = compose(ckpt_load(seg_ckpt + slot * (5 * 256) + s * 64 + lane), st);
+                st = compose(ckpt_load<PL>(seg_ckpt + slot * SLOT + s * 64 + lane), st);
             }
             T[s] = st.T;
             S[s] -= gr[s] * st.Cr + gg[s] * st.Cg + gb[s] * st.Cb + gd[s] * st.D;
         }
     }
-    const uint32_t shx = lx, shy = 16u + ly;  // this lane's column / row bit in the staged pixel bits
-    uint32_t alive = 0x3Fu;  // sub-tiles still composited (bits 0-3) | the two flag bits
+    const uint32_t shx = lx, shy = 16u + ly;  // this lane's column bit in the staged column bits / row bit in the flags
+    uint32_t alive = (1u << NS) - 1u;  // sub-tiles still composited (FgsDims.saturation_skip; 16 x 16 tiles only)
     if (t_eps > 0.0f) {
-        alive = 0x30u;
+        alive = 0u;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < NS; ++s)
             if (__ballot(T[s] >= t_eps) != 0ull) alive |= 1u << s;  // T = 1 - A of the checkpoint, as in the forward
     }
     float fx0 = (float)(c.X0 + lx), fy0 = (float)(c.Y0 + ly);
@@ -577,15 +588,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             float4 q2 = r[2];
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
             const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu;
-            const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
+            const uint32_t tx0 = bx0 / (8u * NSX), tx1 = (bx1 - 1) / (8u * NSX), ty0 = by0 / FGS_TILE;
             she[lane] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
             float4 q0 = r[0], q1 = r[1];
             // m = a dx^2 + (b+c) dx dy + d dy^2 >= 0 everywhere (so G <= 1): positive definite, with a margin
             // that covers the fp32 rounding of m
             const bool conic_ok = q0.z > 0.0f && q1.x > 0.0f && 3.996f * q0.z * q1.x > q0.w * q0.w;
-            uint32_t flags, bits;
-            stage_decode(c.X0, c.Y0, bbx, bby, q1.y, flags, bits, conic_ok);
-            q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
+            uint32_t flags, cbits;
+            stage_decode_w<NSX>(c.X0, c.Y0, bbx, bby, q1.y, flags, cbits, conic_ok);
+            q2.z = __uint_as_float(cbits); q2.w = __uint_as_float(flags);
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;  // conic in exp2 units
             // alpha = 0.99 a', a' = clamp01(G op / 0.99) (free clamp modifier instead of a v_min, as in the forward); the
             // list loop works with w' = a' T = w / 0.99 and colours c' = 0.99 c, so that w q = w' q'; its sums come out
@@ -597,11 +608,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         __syncthreads();
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-            const uint32_t msk = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w)) & alive;  // stage_decode flags
-            const uint32_t bits = __float_as_uint(q2.z);                                // stage_decode pixel bits
+            const uint32_t fl = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));  // stage_decode_w flags
+            const uint32_t msk = fl & alive;
+            const uint32_t cbits = __float_as_uint(q2.z), rbits = __float_as_uint(q2.w);  // column bits; row bits at 16+
             const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;  // conic pre-multiplied by K = -log2(e)/2
             // terms shared by the sub-tiles of a column / row, formed once per list entry
-            const float dxa = fx0 - q0.x, dya = fy0 - q0.y, dxb = dxa + 8.0f, dyb = dya + 8.0f;
+            const float dxa = fx0 - q0.x, dya = fy0 - q0.y, dyb = dya + 8.0f;
             float bdya = cbc * dya, bdyb = cbc * dyb, cyya = (cd * dya) * dya, cyyb = (cd * dyb) * dyb;
             asm("" : "+v"(bdya), "+v"(bdyb), "+v"(cyya), "+v"(cyyb));  // keep the row terms: do not recompute them per sub-tile
             // bbox membership: the lane's column / row bits of the staged pixel bits become all-ones / zero masks
@@ -616,20 +628,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 // ops: `clamp` (flag bit 4 clear: opacity > 0.98 or a doubtful conic): the clamp-gradient select.
                 // (Four specialised instantiations of this loop body made the compiler carry T and S through eight
                 // v_mov per list entry and were 5 % slower.)
-                uint32_t cflag = msk & 16u;  // clear: `clamp`.  Kept as a scalar and tested where it is used: as a bool the
+                uint32_t cflag = fl & 256u;  // clear: `clamp`.  Kept as a scalar and tested where it is used: as a bool the
                 asm("" : "+s"(cflag));       // compiler materialised it through a v_cndmask / v_cmp pair per list entry
                 // the lane masks of every entry, also of those whose bbox covers the tile (all bits set): skipping the four
                 // v_bfe behind a branch needed four v_mov of the default and was 0.9 % slower
-                const uint32_t mx0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx, 1), mx1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shx + 8u, 1);
-                const uint32_t my0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy, 1), my1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits, shy + 8u, 1);
+                uint32_t mxs[NSX];
+                float dxs[NSX];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                for (int col = 0; col < NSX; ++col) {
+                    mxs[col] = (uint32_t)__builtin_amdgcn_sbfe((int)cbits, shx + 8u * col, 1);
+                    dxs[col] = dxa + 8.0f * col;
+                }
+                const uint32_t my0 = (uint32_t)__builtin_amdgcn_sbfe((int)rbits, shy, 1), my1 = (uint32_t)__builtin_amdgcn_sbfe((int)rbits, shy + 8u, 1);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
                     if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
                     // G is zeroed outside the bbox: alpha, w and every gradient term below then vanish by themselves
-                    const uint32_t mk = ((s & 1) ? mx1 : mx0) & ((s >> 1) ? my1 : my0);
-                    const float dx = (s & 1) ? dxb : dxa, dy = (s >> 1) ? dyb : dya;
-                    const float t = ca * dx + ((s >> 1) ? bdyb : bdya);
-                    const float Gu = __builtin_amdgcn_exp2f(t * dx + ((s >> 1) ? cyyb : cyya));
+                    const int col = s % NSX, row = s / NSX;
+                    const uint32_t mk = mxs[col] & (row ? my1 : my0);
+                    const float dx = dxs[col], dy = row ? dyb : dya;
+                    const float t = ca * dx + (row ? bdyb : bdya);
+                    const float Gu = __builtin_amdgcn_exp2f(t * dx + (row ? cyyb : cyya));
                     const float G = __uint_as_float(__float_as_uint(Gu) & mk);
                     float a1;  // alpha / 0.99
                     asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(a1) : "v"(G), "v"(op));
@@ -877,12 +896,16 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     const float t_eps = (p.d.saturation_skip && !p.d.use_phase) ? FGS_SATURATION_EPS : 0.0f;
     const int fw = p.fwd_waves;
     if (const int np = p.fwd_parts) {
-#define FGS_PARTS_LAUNCH(NP)                                                                                  \
-    hipLaunchKernelGGL((k_blend_fwd_parts<NP>), dim3(grid), dim3(64 * NP), 0, st, (uint32_t)p.tiles,          \
+#define FGS_PARTS_LAUNCH(NP, NSXV)                                                                            \
+    hipLaunchKernelGGL((k_blend_fwd_parts<NP, NSXV>), dim3(grid), dim3(64 * NP), 0, st, (uint32_t)p.tiles,    \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
                        p.d.background[1], p.d.background[2], tile_order, ranges, dup_ids, rec, pix, out_rgb,  \
                        out_depth, seg_off, seg_ckpt, (uint32_t)p.L.seg_len)
-        if (np == 1) FGS_PARTS_LAUNCH(1); else if (np == 2) FGS_PARTS_LAUNCH(2); else FGS_PARTS_LAUNCH(4);
+        if (p.tile_w == 32) {
+            if (np == 1) FGS_PARTS_LAUNCH(1, 4); else if (np == 2) FGS_PARTS_LAUNCH(2, 4); else FGS_PARTS_LAUNCH(4, 4);
+        } else {
+            if (np == 1) FGS_PARTS_LAUNCH(1, 2); else if (np == 2) FGS_PARTS_LAUNCH(2, 2); else FGS_PARTS_LAUNCH(4, 2);
+        }
 #undef FGS_PARTS_LAUNCH
         FGS_LAUNCH_CHECK("k_blend_fwd_parts");
         return FGS_OK;
@@ -925,20 +948,23 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
         return FGS_OK;
     }
     const uint32_t ugrid = (uint32_t)p.L.seg_capacity;  // surplus blocks exit at once (measured: free)
-    hipLaunchKernelGGL(k_composite_bwd, dim3(ugrid), dim3(64), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x,
-                       (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0], p.d.background[1],
-                       p.d.background[2], (uint32_t)p.L.dup_capacity,
-                       reinterpret_cast<const uint32_t *>(saved + p.L.counters),
-                       reinterpret_cast<const uint32_t *>(saved + p.L.seg_off),
-                       reinterpret_cast<const uint32_t *>(saved + p.L.seg_tile),
-                       reinterpret_cast<const float *>(saved + p.L.seg_ckpt),
-                       reinterpret_cast<const uint32_t *>(saved + p.L.ranges),
-                       reinterpret_cast<const uint32_t *>(saved + p.L.dup_ids),
-                       reinterpret_cast<const float *>(saved + p.L.rec),
-                       reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
-                       reinterpret_cast<const float *>(saved + p.L.pix_state), g_rgb, g_depth,
-                       reinterpret_cast<float *>(scratch + p.s_grows),
-                       p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f);
+#define FGS_BWD_LAUNCH(NSXV)                                                                                  \
+    hipLaunchKernelGGL(k_composite_bwd<NSXV>, dim3(ugrid), dim3(64), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x, \
+                       (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0], p.d.background[1], \
+                       p.d.background[2], (uint32_t)p.L.dup_capacity, \
+                       reinterpret_cast<const uint32_t *>(saved + p.L.counters), \
+                       reinterpret_cast<const uint32_t *>(saved + p.L.seg_off), \
+                       reinterpret_cast<const uint32_t *>(saved + p.L.seg_tile), \
+                       reinterpret_cast<const float *>(saved + p.L.seg_ckpt), \
+                       reinterpret_cast<const uint32_t *>(saved + p.L.ranges), \
+                       reinterpret_cast<const uint32_t *>(saved + p.L.dup_ids), \
+                       reinterpret_cast<const float *>(saved + p.L.rec), \
+                       reinterpret_cast<const uint32_t *>(saved + p.L.dup_off), \
+                       reinterpret_cast<const float *>(saved + p.L.pix_state), g_rgb, g_depth, \
+                       reinterpret_cast<float *>(scratch + p.s_grows), \
+                       p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f)
+    if (p.tile_w == 32) FGS_BWD_LAUNCH(4); else FGS_BWD_LAUNCH(2);
+#undef FGS_BWD_LAUNCH
     FGS_LAUNCH_CHECK("k_composite_bwd");
     return FGS_OK;
 }

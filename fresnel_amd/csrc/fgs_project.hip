@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_project(
     const float *__restrict__ cams, const float *__restrict__ pos, const float *__restrict__ scale,
     const float *__restrict__ quat, const float *__restrict__ color, const float *__restrict__ opacity,
     float *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ tile_count,
-    uint32_t *__restrict__ layer, int32_t num_planes, float plane_near, float plane_far) {
+    uint32_t *__restrict__ layer, int32_t num_planes, float plane_near, float plane_far, int32_t tile_w) {
     const int32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int32_t b = idx / N;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_project(
     }
     uint32_t ntiles = 0;
     if (vis && x0 < x1 && y0 < y1)
-        ntiles = (uint32_t)(((x1 - 1) / FGS_TILE - x0 / FGS_TILE + 1) * ((y1 - 1) / FGS_TILE - y0 / FGS_TILE + 1));
+        ntiles = (uint32_t)(((x1 - 1) / tile_w - x0 / tile_w + 1) * ((y1 - 1) / FGS_TILE - y0 / FGS_TILE + 1));
     // inverse of cov + 1e-4 I, DR:578-579 (closed form)
     const float ar = o.a + 1e-4f, dr = o.d + 1e-4f;
     const float detr = ar * dr - o.b * o.c;
@@ -493,7 +493,7 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
                        reinterpret_cast<uint32_t *>(saved + p.L.depth_key),
                        reinterpret_cast<uint32_t *>(saved + p.L.tile_count),
                        num_planes > 1 ? reinterpret_cast<uint32_t *>(saved + p.s_layer) : nullptr, num_planes,  // one plane: layer 0
-                       plane_near, plane_far);
+                       plane_near, plane_far, p.tile_w);
     FGS_LAUNCH_CHECK("k_project");
     return FGS_OK;
 }

@@ -33,6 +33,31 @@ __device__ __forceinline__ void stage_decode(uint32_t X0, uint32_t Y0, uint32_t 
     bits = xm | (ym << 16);
 }
 
+// The same for a tile of NSX x 2 sub-tiles (16 or 32 pixels wide), depth-split forward and blend backward:
+//   flags  bits 0 .. 2 NSX - 1: sub-tile s = row * NSX + col touched (none when the opacity is negative);
+//          bit 8: the alpha clamp cannot bind (opacity <= 0.98 and `conic_ok`); bits 16-31: pixel row Y0 + i in [y0, y1);
+//   cbits  bit i (i < 8 NSX): pixel column X0 + i lies in [x0, x1).
+template <int NSX>
+__device__ __forceinline__ void stage_decode_w(uint32_t X0, uint32_t Y0, uint32_t bbx, uint32_t bby, float op,
+                                               uint32_t &flags, uint32_t &cbits, bool conic_ok = true) {
+    constexpr int TW = 8 * NSX;
+    const int x0 = (int)(bbx & 0xFFFFu), x1 = (int)(bbx >> 16), y0 = (int)(bby & 0xFFFFu), y1 = (int)(bby >> 16);
+    const int lx0 = max(x0 - (int)X0, 0), lx1 = min(x1 - (int)X0, TW);
+    const int ly0 = max(y0 - (int)Y0, 0), ly1 = min(y1 - (int)Y0, 16);
+    cbits = lx1 > lx0 ? (uint32_t)(((1ull << (lx1 - lx0)) - 1ull) << lx0) : 0u;
+    const uint32_t ym = ly1 > ly0 ? ((1u << (ly1 - ly0)) - 1u) << ly0 : 0u;
+    uint32_t touched = 0;
+    if (op >= 0.0f) {
+#pragma unroll
+        for (int c = 0; c < NSX; ++c) {
+            const uint32_t cm = (cbits >> (8 * c)) & 0xFFu;
+            if (cm && (ym & 0xFFu)) touched |= 1u << c;
+            if (cm && (ym >> 8)) touched |= 1u << (NSX + c);
+        }
+    }
+    flags = touched | ((op <= 0.98f && conic_ok) ? 256u : 0u) | (ym << 16);
+}
+
 // (x < lim) ? v : 0.  The compare and the select are kept ADJACENT in one asm block: a v_cndmask reading VCC
 // straight after the v_cmp that wrote it issues in ~2.6 cycles on gfx950, any other VCC-reading v_cndmask in
 // 14-23 (scratch/ubench/valu3.hip, valu4.hip).

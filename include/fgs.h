@@ -31,7 +31,7 @@ extern "C" {
 #define FGS_ELAUNCH (-2)   /* HIP launch error */
 #define FGS_EUNSUPPORTED (-3)
 
-#define FGS_TILE 16        /* tile edge in pixels */
+#define FGS_TILE 16        /* tile height in pixels, and the width unless FgsSavedLayout.tile_w says 32 */
 #define FGS_SEG 128        /* largest depth segment: list entries per backward work unit; a call uses
                               FgsSavedLayout.seg_len (64 for small problems, else FGS_SEG)            */
 #define FGS_TUNE_AUTO 0    /* FgsDims.seg_len / fwd_variant / bin_mode: let the library choose        */
@@ -63,7 +63,8 @@ typedef struct FgsDims {
                                (waves) per tile | -1, -2, -4 = row-split forward with that many waves per tile.
                                Phase path: |fwd_variant| = waves per tile.                                      */
     int32_t bin_mode;       /* tile binning: 0 | 1 = direct (column / row rank masks) | 2 = emit + stable radix sort */
-    int32_t reserved;       /* must be 0                                                                        */
+    int32_t tile_w;         /* tile width in pixels: 0 | 16 | 32 (tiles are always 16 rows high).  0 = automatic:
+                               32 on the blend path with the depth-split forward, 16 elsewhere                  */
 } FgsDims;
 
 /* Camera record on the DEVICE: FGS_CAMERA_FLOATS floats per camera (Camera, DR:27-52):
@@ -103,7 +104,8 @@ typedef struct FgsSavedLayout {
     size_t seg_capacity; /* Ucap = Dcap / seg_len + B*T                                             */
     int32_t seg_len;     /* list entries per depth segment for these dims: 64 when B*N <= 200 000 (more,
                             shorter work units for launches that would not fill the chip), else 128   */
-    int32_t reserved;
+    int32_t tile_w;      /* tile width in pixels (16 | 32; tiles_x counts tiles of this width); a tile has
+                            tile_w / 8 x 2 sub-tiles of 8 x 8 pixels, and seg_ckpt slots hold 5 x that many x 64 floats */
 } FgsSavedLayout;
 
 /* Sizes of the two caller-provided device buffers.  `saved` must stay untouched between

@@ -91,10 +91,13 @@ def count_pairs(vis_sorted, bbox):
                                         _p(np.ascontiguousarray(bbox, np.int32))))
 
 
-def tile_lists(vis_sorted, bbox, W, H, ts=16):
+def tile_lists(vis_sorted, bbox, W, H, ts=16, tile_w=None):
+    """Per-tile lists in depth order; tiles are ts x ts, or tile_w x ts when tile_w is given."""
     vs = np.ascontiguousarray(vis_sorted, np.int32)
     bb = np.ascontiguousarray(bbox, np.int32)
-    T = ((W + ts - 1) // ts) * ((H + ts - 1) // ts)
+    tw = ts if tile_w is None else int(tile_w)
+    T = ((W + tw - 1) // tw) * ((H + ts - 1) // ts)
+    ts = tw | (ts << 16)
     ranges = np.zeros(T + 1, np.int64)
     D = lib().fgs_or_tile_lists(ctypes.c_int32(len(vs)), _p(vs), _p(bb), ctypes.c_int32(W),
                                 ctypes.c_int32(H), ctypes.c_int32(ts), _p(ranges), None)

@@ -131,15 +131,17 @@ def test_saturation_skip_vs_oracle(shape):
 
 
 def test_large_frame_radix_binning_path_vs_oracle():
-    """A frame of more than 4096 tiles per image (1200 x 1100 = 75 x 69 = 5175 tiles): the direct counting sort does
-    not apply and the lists come from the emit + stable radix sort path (also what the layered ASM keys use); image,
-    depth, gradients and integer stages against the oracle."""
+    """The emit + stable radix sort list builder (frames of more than 4096 tiles per image, e.g. 2400 x 1100 = 75 x 69
+    tiles of 32 x 16, where the direct binning cannot be forced; here selected with bin_mode = 2 on a 1200 x 1100 frame, once
+    with 16 x 16 and once with 32 x 16 tiles): image, depth, gradients and integer stages against the oracle."""
     from oracle import fgs_oracle as orc
     from fresnel_amd import _binding as B
     from fresnel_amd.renderer import Camera
     W, H, N = 1200, 1100, 3000
-    with pytest.raises(B.FgsError):  # direct binning cannot be forced on such a frame
-        B.workspace_bytes(B.make_dims(1, N, W, H, tuning=dict(bin_mode=1)))
+    with pytest.raises(B.FgsError):  # direct binning cannot be forced on a frame of more than 4096 tiles
+        B.workspace_bytes(B.make_dims(1, N, 2 * W, H, tuning=dict(bin_mode=1)))
+    with pytest.raises(B.FgsError):
+        B.workspace_bytes(B.make_dims(1, N, W, H, tuning=dict(bin_mode=1, tile_w=16)))
     rs = np.random.RandomState(3)
     from helpers import synth_aniso
     arrs = list(synth_aniso(N, 5, smax=0.08))
@@ -150,12 +152,15 @@ def test_large_frame_radix_binning_path_vs_oracle():
     gI = rs.standard_normal((3, H, W)).astype(np.float32)
     gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
     go = orc.render_backward(r, gI, gD)
-    st = _hip_stages([a[None] for a in arrs], cam, W, H, bg)
-    _check_integer_stages(st, 0, r, W, H)
-    out = _hip_render(arrs, cam, W, H, bg, grads=(gI, gD))
-    assert rel_to_max(out["image"], r.image) <= TOL and rel_to_max(out["depth"], r.depth) <= TOL
-    for k in KEYS:
-        assert rel_to_max(out["grad_" + k], go[k]) <= TOL, k
+    for tile_w in (16, 32):
+        tuning = dict(bin_mode=2, tile_w=tile_w)
+        st = _hip_stages([a[None] for a in arrs], cam, W, H, bg, tuning=tuning)
+        assert int(st["layout"].tile_w) == tile_w
+        _check_integer_stages(st, 0, r, W, H)
+        out = _hip_render(arrs, cam, W, H, bg, grads=(gI, gD), tuning=tuning)
+        assert rel_to_max(out["image"], r.image) <= TOL and rel_to_max(out["depth"], r.depth) <= TOL
+        for k in KEYS:
+            assert rel_to_max(out["grad_" + k], go[k]) <= TOL, k
 
 
 def test_more_than_65536_gaussians_per_image_vs_oracle():

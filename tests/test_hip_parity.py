@@ -96,7 +96,7 @@ def _check_integer_stages(st, b, r, W, H):
     assert np.array_equal(np.ascontiguousarray(rec[vis_h, 0:2]).view(np.uint32), np.ascontiguousarray(r.proj["mean2d"][vis_h]).view(np.uint32))
     assert np.array_equal(np.ascontiguousarray(rec[vis_h, 9]).view(np.uint32), np.ascontiguousarray(r.proj["depth"][vis_h]).view(np.uint32))
     # per-tile lists
-    ranges_o, ids_o = orc.tile_lists(r.vis_sorted, r.proj["bbox"], W, H, 16)
+    ranges_o, ids_o = orc.tile_lists(r.vis_sorted, r.proj["bbox"], W, H, 16, tile_w=int(st["layout"].tile_w))
     T = len(ranges_o) - 1
     rg = st["ranges"][b]
     dup = st["dup_ids"]
