@@ -313,41 +313,49 @@ __device__ __forceinline__ BlendState ckpt_load(const float *ck) {
     return {ck[0], ck[PL], ck[2 * PL], 1.0f - ck[3 * PL], ck[4 * PL]};
 }
 
-// NSX = sub-tile columns of the tile: 2 (16 x 16 tiles) or 4 (32 x 16 tiles, FgsSavedLayout.tile_w = 32: eight sub-tiles
-// per lane; 80 VGPRs = 6 waves per SIMD instead of 8, but every list entry's staging, LDS reads and row terms are
-// amortised over up to eight sub-tile passes and there are ~0.6x as many entries).
-template <int NP, int NSX>
-__global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 8 : 5, NSX == 2 ? 8 : 5))) void k_blend_fwd_parts(
+// WIDE = 1: 32 x 16 tiles (FgsSavedLayout.tile_w = 32; the backward then has eight sub-tiles per lane and ~0.6x as many
+// list entries, reductions and gradient rows).  The forward keeps its 16 x 16 register budget -- holding eight sub-tiles per
+// lane here cost 99 VGPRs, 4-5 waves per SIMD and +5 ... 35 % -- by giving every list part TWO waves, one per 16 x 16 half
+// of the tile: a wave stages the part's records with the flags of ITS half and skips the entries that do not touch it, so
+// its work is that of the 16 x 16 tile's list plus one LDS read and a branch per skipped entry.
+template <int NP, int WIDE>
+__global__ __launch_bounds__(64 * NP * (1 + WIDE)) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blend_fwd_parts(  // 64 VGPRs: -2.6 %
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, float *__restrict__ pix_state,
     float *__restrict__ out_rgb, float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off,
     float *__restrict__ seg_ckpt, uint32_t seg_len) {
-    constexpr int NS = 2 * NSX, PL = NS * 64, SLOT = 5 * PL;  // sub-tiles per tile, floats per checkpoint plane / slot
-    __shared__ float4 sh0[NP][64], sh1[NP][64], sh2[NP][64];
-    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges, 8u * NSX);
+    constexpr int NW = NP * (1 + WIDE);                   // waves per block
+    constexpr int TSX = WIDE ? 4 : 2;                     // sub-tile columns of the whole tile
+    constexpr int PL = 2 * TSX * 64, SLOT = 5 * PL;       // floats per checkpoint plane / slot: [5][2 TSX][64]
+    __shared__ float4 sh0[NW][64], sh1[NW][64], sh2[NW][64];
+    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges, 8u * TSX);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t part = WIDE ? wave >> 1 : wave, half = WIDE ? wave & 1u : 0u;
+    const uint32_t X0 = c.X0 + 16u * half;                // this wave's 16 x 16 half of the tile
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t nseg = (c.end - c.start + seg_len - 1) / seg_len;
     const uint32_t spp = (nseg + NP - 1) / NP;  // segments per part
-    const uint32_t first_seg = wave * spp;
+    const uint32_t first_seg = part * spp;
     const bool active = first_seg < nseg;
     const uint32_t pstart = c.start + first_seg * seg_len;
     const uint32_t pend = active ? min(c.end, pstart + spp * seg_len) : pstart;
-    float *slot0 = seg_ckpt + (size_t)seg_off[c.tile] * SLOT + lane;  // + s * 64 per sub-tile
-    float T[NS], Cr[NS], Cg[NS], Cb[NS], Dm[NS];
+    // this lane's cells of a checkpoint slot: sub-tile (row, 2 half + col) of the tile's 2 x TSX grid
+    float *slot0 = seg_ckpt + (size_t)seg_off[c.tile] * SLOT + 2u * half * 64u + lane;
+    auto cell = [](int s) { return ((s >> 1) * TSX + (s & 1)) * 64; };
+    float T[4], Cr[4], Cg[4], Cb[4], Dm[4];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; }
+    for (int s = 0; s < 4; ++s) { T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; }
     const uint32_t shx = lx, shy = 16u + ly;  // this lane's column bit in cbits / row bit in flags
-    float fx0 = (float)(c.X0 + lx), fy0 = (float)(c.Y0 + ly);
-    asm("" : "+v"(fx0), "+v"(fy0));
+    float fx0 = (float)(X0 + lx), fx1 = (float)(X0 + lx + 8u), fy0 = (float)(c.Y0 + ly);
+    asm("" : "+v"(fx0), "+v"(fx1), "+v"(fy0));
     for (uint32_t base = pstart; base < pend; base += 64) {
         const uint32_t n = min(64u, pend - base);
         if (base != pstart && ((base - c.start) % seg_len) == 0) {  // LOCAL state in front of this segment
             float *ck = slot0 + (size_t)((base - c.start) / seg_len) * SLOT;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) ckpt_store<PL>(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
+            for (int s = 0; s < 4; ++s) ckpt_store<PL>(ck + cell(s), BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
         }
         if (lane < n) {
             const uint32_t gid = dup_ids[base + lane];
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(NSX == 
             float4 q0 = r[0], q1 = r[1], q2 = r[2];
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
             uint32_t flags, cbits;
-            stage_decode_w<NSX>(c.X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, cbits);
+            stage_decode_w<2>(X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, cbits);
             q2.z = __uint_as_float(cbits); q2.w = __uint_as_float(flags);
             // alpha = min(G op, 0.99) = 0.99 clamp01(G op / 0.99): the list loop forms a' = clamp01(G op') with the
             // FREE clamp modifier of v_mul instead of a v_min (4.3 issue cycles on gfx950), the 0.99 rides on the
@@ -367,32 +375,28 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(NSX == 
         }
         __builtin_amdgcn_wave_barrier();  // wave-private LDS: one wave's LDS instructions execute in order
         for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t fl = __builtin_amdgcn_readfirstlane(__float_as_uint(sh2[wave][j].w));  // stage_decode_w flags
+            const uint32_t msk = fl & 15u;
+            if (!msk) continue;  // (WIDE: also the entries that touch only the other half of the tile)
             const float4 q0 = sh0[wave][j], q1 = sh1[wave][j], q2 = sh2[wave][j];
-            const uint32_t fl = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));  // stage_decode_w flags
-            const uint32_t msk = fl & ((1u << NS) - 1u);
-            if (!msk) continue;
             // (Skipping the lane masks for entries whose bbox covers the tile, or the min for opacities <= 0.98, behind
             // wave-uniform branches -- what pays in the backward -- made this loop 10 % SLOWER: 0.68 -> 0.75 ms at config 3;
             // its passes are too short to amortise a branch.)
             const uint32_t cbits = __float_as_uint(q2.z), rbits = __float_as_uint(q2.w);
-            // the lane's column masks and column offsets once per entry (3.3 sub-tile passes per entry on 16 x 16 tiles)
-            uint32_t mxc[NSX];
-            float dxc[NSX];
-#pragma unroll
-            for (int col = 0; col < NSX; ++col) {
-                mxc[col] = (uint32_t)__builtin_amdgcn_sbfe((int)cbits, shx + 8u * col, 1);
-                dxc[col] = fx0 + 8.0f * col - q0.x;
-            }
+            // the lane's two column masks once per entry (3.3 sub-tile passes per entry on average: -2.8 %)
+            const uint32_t mxc[2] = {(uint32_t)__builtin_amdgcn_sbfe((int)cbits, shx, 1), (uint32_t)__builtin_amdgcn_sbfe((int)cbits, shx + 8u, 1)};
+            // ... and its two column offsets (3.3 passes per entry: one subtraction per pass would be more)
+            float dxc[2] = {fx0 - q0.x, fx1 - q0.x};
             asm("" : "+v"(dxc[0]), "+v"(dxc[1]));
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
-                if (!((msk >> (NSX * row)) & ((1u << NSX) - 1u))) continue;
+                if (!((msk >> (2 * row)) & 3u)) continue;
                 const float dy = row ? fy0 + 8.0f - q0.y : fy0 - q0.y;
                 const float bdy = q0.w * dy, cyy = (q1.x * dy) * dy;
                 const uint32_t my = (uint32_t)__builtin_amdgcn_sbfe((int)rbits, shy + 8u * row, 1);
 #pragma unroll
-                for (int col = 0; col < NSX; ++col) {
-                    const int s = NSX * row + col;
+                for (int col = 0; col < 2; ++col) {
+                    const int s = 2 * row + col;
                     if (!((msk >> s) & 1u)) continue;  // scalar branch: sub-tile not touched
                     const float dx = dxc[col];
                     const float t = q0.z * dx + bdy;
@@ -409,40 +413,40 @@ __global__ __launch_bounds__(64 * NP) __attribute__((amdgpu_waves_per_eu(NSX == 
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // ---- hand the part results over and compose them (wave 0) ----
+    // ---- hand the part results over and compose them (the part-0 wave of each half) ----
     const uint32_t last = nseg ? (nseg - 1) / spp : 0u;
     if (NP > 1 && nseg > spp) {  // more than one part
-        if (active && wave != 0) {
-            float *ck = (wave == last) ? slot0 : slot0 + (size_t)((wave + 1) * spp) * SLOT;
+        if (active && part != 0) {
+            float *ck = (part == last) ? slot0 : slot0 + (size_t)((part + 1) * spp) * SLOT;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) ckpt_store<PL>(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
+            for (int s = 0; s < 4; ++s) ckpt_store<PL>(ck + cell(s), BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
         }
         __threadfence_block();
         __syncthreads();
-        if (wave != 0) return;
-        // wave 0: its own result is the absolute state in front of part 1
+        if (part != 0) return;
+        // part 0: its own result is the absolute state in front of part 1
         {
             float *ck = slot0 + (size_t)spp * SLOT;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) ckpt_store<PL>(ck + s * 64, BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
+            for (int s = 0; s < 4; ++s) ckpt_store<PL>(ck + cell(s), BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
         }
         for (uint32_t pp = 1; pp <= last; ++pp) {
             const float *src = (pp == last) ? slot0 : slot0 + (size_t)((pp + 1) * spp) * SLOT;
             float *dst = slot0 + (size_t)((pp + 1) * spp) * SLOT;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const BlendState acc = compose(BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]}, ckpt_load<PL>(src + s * 64));
+            for (int s = 0; s < 4; ++s) {
+                const BlendState acc = compose(BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]}, ckpt_load<PL>(src + cell(s)));
                 Cr[s] = acc.Cr; Cg[s] = acc.Cg; Cb[s] = acc.Cb; T[s] = acc.T; Dm[s] = acc.D;
-                if (pp != last) ckpt_store<PL>(dst + s * 64, acc);
+                if (pp != last) ckpt_store<PL>(dst + cell(s), acc);
             }
         }
-    } else if (wave != 0) {
+    } else if (part != 0) {
         return;
     }
     const size_t HW = (size_t)W * H;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const uint32_t px = c.X0 + 8u * (s % NSX) + lx, py = c.Y0 + 8u * (s / NSX) + ly;
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t px = X0 + 8u * (s & 1) + lx, py = c.Y0 + 8u * (s >> 1) + ly;
         if (px < W && py < H) {
             const size_t o = (size_t)py * W + px;
             float *ps = pix_state + (size_t)c.b * 6 * HW + o;
@@ -896,15 +900,15 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     const float t_eps = (p.d.saturation_skip && !p.d.use_phase) ? FGS_SATURATION_EPS : 0.0f;
     const int fw = p.fwd_waves;
     if (const int np = p.fwd_parts) {
-#define FGS_PARTS_LAUNCH(NP, NSXV)                                                                            \
-    hipLaunchKernelGGL((k_blend_fwd_parts<NP, NSXV>), dim3(grid), dim3(64 * NP), 0, st, (uint32_t)p.tiles,    \
+#define FGS_PARTS_LAUNCH(NP, WD)                                                                              \
+    hipLaunchKernelGGL((k_blend_fwd_parts<NP, WD>), dim3(grid), dim3(64 * NP * (1 + WD)), 0, st, (uint32_t)p.tiles, \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
                        p.d.background[1], p.d.background[2], tile_order, ranges, dup_ids, rec, pix, out_rgb,  \
                        out_depth, seg_off, seg_ckpt, (uint32_t)p.L.seg_len)
         if (p.tile_w == 32) {
-            if (np == 1) FGS_PARTS_LAUNCH(1, 4); else if (np == 2) FGS_PARTS_LAUNCH(2, 4); else FGS_PARTS_LAUNCH(4, 4);
+            if (np == 1) FGS_PARTS_LAUNCH(1, 1); else if (np == 2) FGS_PARTS_LAUNCH(2, 1); else FGS_PARTS_LAUNCH(4, 1);
         } else {
-            if (np == 1) FGS_PARTS_LAUNCH(1, 2); else if (np == 2) FGS_PARTS_LAUNCH(2, 2); else FGS_PARTS_LAUNCH(4, 2);
+            if (np == 1) FGS_PARTS_LAUNCH(1, 0); else if (np == 2) FGS_PARTS_LAUNCH(2, 0); else FGS_PARTS_LAUNCH(4, 0);
         }
 #undef FGS_PARTS_LAUNCH
         FGS_LAUNCH_CHECK("k_blend_fwd_parts");

@@ -22,6 +22,7 @@ for it in range(40):
     go = orc.render_backward(r, gI, gD)
     ts = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in arrs]
     ren = TileBasedRenderer(W, H, background=bg, max_radius=maxr)
+    ren.tuning = dict(tile_w=int(rs.choice([16, 32])))
     img, dep = ren(*ts, cam, return_depth=True)
     ((img * torch.from_numpy(gI).to(dev)).sum() + (dep * torch.from_numpy(gD).to(dev)).sum()).backward()
     errs = dict(image=rel_to_max(img.detach().cpu().numpy(), r.image), depth=rel_to_max(dep.detach().cpu().numpy(), r.depth))

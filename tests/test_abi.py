@@ -49,16 +49,18 @@ def test_workspace_and_layout():
     assert L.total_bytes == saved and saved > 0 and scratch > 0
     offs = [L.rec, L.depth_key, L.tile_count, L.order, L.counters, L.ranges, L.dup_ids, L.pix_state]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
-    # the blend path's default: 32 x 16 tiles (4 x 5 here; a 64-px radius spans <= 6 tile columns and <= 10 tile rows)
-    La = B.saved_layout(B.make_dims(2, 1000, 100, 72))
+    # 32 x 16 tiles on request (4 x 5 here; a 64-px radius spans <= 6 tile columns and <= 10 tile rows) ...
+    La = B.saved_layout(B.make_dims(2, 1000, 100, 72, tuning=dict(tile_w=32)))
     assert La.tile_w == 32 and La.tiles_x == 4 and La.tiles_y == 5 and La.dup_capacity == 2 * 1000 * 4 * 5
+    assert B.saved_layout(B.make_dims(2, 1000, 100, 72)).tile_w == 16
+    # ... and by default on the blend path from 512-pixel-wide frames on
     d2 = B.make_dims(8, 32768, 512, 512)
     L2 = B.saved_layout(d2)
-    assert L2.dup_capacity == 8 * 32768 * 60 and L2.tiles_x == 16 and L2.tiles_y == 32
+    assert L2.tile_w == 32 and L2.dup_capacity == 8 * 32768 * 60 and L2.tiles_x == 16 and L2.tiles_y == 32
     assert B.saved_layout(B.make_dims(8, 32768, 512, 512, tuning=dict(tile_w=16))).dup_capacity == 8 * 32768 * 100
     # the phase path, the row-split forward and saturation_skip keep 16 x 16 tiles and refuse 32
-    assert B.saved_layout(B.make_dims(2, 1000, 100, 72, use_phase=True)).tile_w == 16
-    assert B.saved_layout(B.make_dims(2, 1000, 100, 72, saturation_skip=True)).tile_w == 16
+    assert B.saved_layout(B.make_dims(2, 1000, 512, 512, use_phase=True)).tile_w == 16
+    assert B.saved_layout(B.make_dims(2, 1000, 512, 512, saturation_skip=True)).tile_w == 16
     with pytest.raises(B.FgsError):
         B.workspace_bytes(B.make_dims(2, 1000, 100, 72, use_phase=True, tuning=dict(tile_w=32)))
     with pytest.raises(B.FgsError):
@@ -119,7 +121,7 @@ def test_tuning_fields_are_validated_and_change_only_the_split():
         B.workspace_bytes(B.make_dims(1, 100, 8192, 16, tuning=dict(bin_mode=1, tile_w=16)))
     B.workspace_bytes(B.make_dims(1, 100, 8192, 16, tuning=dict(tile_w=16)))
     B.workspace_bytes(B.make_dims(1, 100, 8176, 16, tuning=dict(bin_mode=1, tile_w=16)))
-    B.workspace_bytes(B.make_dims(1, 100, 8192, 16, tuning=dict(bin_mode=1)))  # 256 + 1 lines of 32 x 16 tiles
+    B.workspace_bytes(B.make_dims(1, 100, 8192, 16, tuning=dict(bin_mode=1)))  # 256 + 1 lines of 32 x 16 tiles (automatic)
 
 
 def test_new_entries_validate_arguments_without_a_gpu(lib):

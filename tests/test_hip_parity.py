@@ -108,24 +108,28 @@ def _check_integer_stages(st, b, r, W, H):
             assert np.array_equal(dup[s:e] - b * N, exp), f"tile {t}: list differs"
 
 
+@pytest.mark.parametrize("tile_w", [16, 32])
 @pytest.mark.parametrize("case", [c for c in TBR_CASES if not c.startswith("G6")])
-def test_golden_forward_backward(case):
+def test_golden_forward_backward(case, tile_w):
     g = load_golden(case)
     W, H = [int(v) for v in g["size"]]
     arrs = [g[k] for k in ["positions", "scales", "rotations", "colors", "opacities"]]
-    out = _hip_render(arrs, _camera_from_golden(g), W, H, g["background"], grads=(g["gI"], g["gD"]))
+    out = _hip_render(arrs, _camera_from_golden(g), W, H, g["background"], grads=(g["gI"], g["gD"]),
+                      tuning=dict(tile_w=tile_w))
     assert np.abs(out["image"] - g["image"]).max() <= TOL * max(1.0, float(np.abs(g["image"]).max()))
     assert rel_to_max(out["depth"], g["depth"]) <= TOL
     for k in ["positions", "scales", "rotations", "colors", "opacities"]:
         assert rel_to_max(out["grad_" + k], g["grad_" + k]) <= TOL, k
 
 
+@pytest.mark.parametrize("tile_w", [16, 32])
 @pytest.mark.parametrize("case", [c for c in TBR_CASES if not c.startswith("G6")])
-def test_golden_integer_stages(case):
+def test_golden_integer_stages(case, tile_w):
     g = load_golden(case)
     W, H = [int(v) for v in g["size"]]
     arrs = [g[k] for k in ["positions", "scales", "rotations", "colors", "opacities"]]
-    st = _hip_stages([a[None] for a in arrs], _camera_from_golden(g), W, H, g["background"])
+    st = _hip_stages([a[None] for a in arrs], _camera_from_golden(g), W, H, g["background"], tuning=dict(tile_w=tile_w))
+    assert int(st["layout"].tile_w) == tile_w
     r = _oracle(arrs, oracle_camera(g), g["background"])
     _check_integer_stages(st, 0, r, W, H)
     # and against the reference's own integer stages stored in the fixture
@@ -362,6 +366,40 @@ def test_count_pairs_equals_the_bbox_areas():
     assert int(pairs.item()) == expect and expect > 100000
     ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
     assert expect == sum(int(orc.render(*a, ocam, keep_pairs=False).P) for a in (a0, a1))
+
+
+@pytest.mark.parametrize("W,H,N,smax,fwd,seg", [(72, 40, 900, 0.15, 4, 64), (200, 136, 4000, 0.2, 2, 128), (48, 32, 1500, 0.5, 1, 64),
+                                                (33, 17, 300, 0.3, 4, 128)])
+def test_wide_tiles_vs_oracle(W, H, N, smax, fwd, seg):
+    """32 x 16 tiles (FgsDims.tile_w = 32: eight sub-tiles per lane in the backward, two waves per list part -- one per
+    16 x 16 half -- in the forward, [5][8][64] checkpoint slots) on frames that are not whole numbers of tiles, with every
+    forward split and both segment lengths, two images per call, some opacities above the clamp and below zero: integer
+    stages bit-exact, image / depth / all gradients against the oracle, and bitwise the same lists' CONTENT as 16 x 16
+    tiles would give after merging (checked through the oracle's rectangular tile lists)."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    a0 = list(synth_aniso(N, 500 + N, smax=smax, opacity_max=1.1))
+    a1 = list(synth_aniso(N, 900 + N, smax=smax / 3))
+    a0[4][::7] = -0.2
+    a0[4][3::11] = 0.995
+    cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    bg = (0.3, 0.1, 0.2)
+    tuning = dict(tile_w=32, fwd_variant=fwd, seg_len=seg)
+    batch = [np.stack([x, y]) for x, y in zip(a0, a1)]
+    st = _hip_stages(batch, cam, W, H, bg, tuning=tuning)
+    assert int(st["layout"].tile_w) == 32 and int(st["layout"].tiles_x) == (W + 31) // 32
+    rs = np.random.RandomState(N)
+    gI = rs.standard_normal((2, 3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((2, H, W)) * 0.1).astype(np.float32)
+    out = _hip_render(batch, cam, W, H, bg, grads=(gI, gD), tuning=tuning)
+    for b, arrs in enumerate((a0, a1)):
+        r = _oracle(arrs, ocam, bg)
+        _check_integer_stages(st, b, r, W, H)
+        go = orc.render_backward(r, gI[b], gD[b])
+        assert rel_to_max(out["image"][b], r.image) <= TOL and rel_to_max(out["depth"][b], r.depth) <= TOL
+        for k in ["positions", "scales", "rotations", "colors", "opacities"]:
+            assert rel_to_max(out["grad_" + k][b], go[k]) <= TOL, (b, k)
 
 
 def test_wide_frame_direct_binning_division_is_exact():
