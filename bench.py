@@ -255,7 +255,9 @@ def main():
 
     # unit of work: composited Gaussian-pixels of this rank's batch (device-side count over the reference bboxes,
     # which are the same for every renderer: DR:594-597 / DR:1240-1247)
-    cfg0 = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, False, 0.25)
+    # (the blend path picks its own tile width; the phase and splat renderers of configs 4 / 5 run 16 x 16 tiles)
+    cfg0 = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, False, 0.25,
+                  tuning=dict(tile_w=16) if args.workload in ("config4", "config5") or args.saturation_skip else None)
     _, _, saved, dims, _ = R.forward_raw(*[t.detach() for t in leaves], None, R.pack_cameras(cam, device), cfg0)
     pairs_dev = torch.zeros(1, dtype=torch.int64, device=device)
     B.check(B.load().fgs_count_pairs(ctypes.byref(dims), ctypes.c_void_p(saved.data_ptr()),
@@ -264,6 +266,7 @@ def main():
     st = R.inspect_saved(saved, dims)
     D_local = int(st["counters"][0].item())
     U_local = int(st["counters"][2].item())  # backward work units = depth segments
+    tile_w = int(st["layout"].tile_w)  # 16, or 32 on the blend path from 512-pixel-wide frames on
     pairs_local = int(pairs_dev.item())
     del saved, st
 
@@ -303,15 +306,16 @@ def main():
     if rank == 0:
         # ---- roofline (rank 0's launches, hipEvent-timed in the library on the stream the kernels run on) ----
         HW = S * S
-        tiles = per_gpu * ((S + 15) // 16) ** 2
-        extra_units = max(U_local - tiles, 0)  # checkpoints: 5 floats x 256 pixels per depth segment after a tile's first
+        tiles = per_gpu * ((S + tile_w - 1) // tile_w) * ((S + 15) // 16)
+        extra_units = max(U_local - tiles, 0)  # checkpoints: 5 floats per tile pixel per depth segment after a tile's first
+        ckpt_bytes = 5 * 4 * 16 * tile_w
         row_bytes = 4 * 48 if args.workload == "config4" else 40
         alg_bytes = {  # ALGORITHMIC HBM bytes per launch of each stage, B images per launch
             "project": per_gpu * N * (56 + 48 + 8),
             "depth_sort": per_gpu * N * 8 * (1 + 2 * 4),
             "list_building": per_gpu * N * 8 + 4 * D_local,  # dup_emit + tile_ranges + tile_sort stages together
-            "composite_fwd": per_gpu * (40 * HW) + 52 * D_local + 5120 * extra_units,
-            "composite_bwd": per_gpu * (36 * HW) + (52 + row_bytes) * D_local + 5120 * extra_units,
+            "composite_fwd": per_gpu * (40 * HW) + 52 * D_local + ckpt_bytes * extra_units,
+            "composite_bwd": per_gpu * (36 * HW) + (52 + row_bytes) * D_local + ckpt_bytes * extra_units,
             "project_bwd": row_bytes * D_local + per_gpu * N * 2 * 56,
             "field_fwd": ASM_BYTES_PER_IMAGE * per_gpu, "field_bwd": ASM_BYTES_PER_IMAGE * per_gpu,
         }
@@ -383,7 +387,7 @@ def main():
                                    + (", + all-reduce of the 2.7 MB decoder-grad bucket (" + args.backend + ")" if world > 1 else ""),
                        "gaussians": N, "resolution": S, "images_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "distribution": args.distribution, "pairs_per_step": int(pairs_all),
-                       "tile_duplicates_rank0": D_local, "depth_segments_rank0": U_local,
+                       "tile_w": tile_w, "tile_duplicates_rank0": D_local, "depth_segments_rank0": U_local,
                        "saturation_skip": bool(args.saturation_skip), "parallelism": f"image-wise dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
