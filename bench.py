@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--saturation-skip", action="store_true",
                     help="NOT the default and not the headline: FgsDims.saturation_skip=1 (stop compositing sub-tiles whose "
                          "accumulated alpha reached 1.0f); value still counts the reference's pairs, see DESIGN.md")
+    ap.add_argument("--tuning", default="",
+                    help="experiments only, e.g. seg_len=64,tile_w=16: FgsDims work-split overrides (results are the same; "
+                         "the default leaves every choice to the library)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a 1-GPU box")
     args = ap.parse_args()
@@ -224,6 +227,8 @@ def main():
     else:
         ren = R.TileBasedRenderer(S, S, use_phase_blending=args.workload == "config4", phase_amplitude=0.25,
                                   saturation_skip=args.saturation_skip).to(device)
+        if args.tuning:
+            ren.tuning = {k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))}
     g = torch.Generator().manual_seed(4242 + rank)
     gI = torch.randn(per_gpu, 3, S, S, generator=g).to(device)
     gD = (torch.randn(per_gpu, S, S, generator=g) * 0.1).to(device)
@@ -257,7 +262,8 @@ def main():
     # which are the same for every renderer: DR:594-597 / DR:1240-1247)
     # (the blend path picks its own tile width; the phase and splat renderers of configs 4 / 5 run 16 x 16 tiles)
     cfg0 = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, False, 0.25,
-                  tuning=dict(tile_w=16) if args.workload in ("config4", "config5") or args.saturation_skip else None)
+                  tuning=dict(tile_w=16) if args.workload in ("config4", "config5") or args.saturation_skip else
+                  ({k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))} if args.tuning else None))
     _, _, saved, dims, _ = R.forward_raw(*[t.detach() for t in leaves], None, R.pack_cameras(cam, device), cfg0)
     pairs_dev = torch.zeros(1, dtype=torch.int64, device=device)
     B.check(B.load().fgs_count_pairs(ctypes.byref(dims), ctypes.c_void_p(saved.data_ptr()),

@@ -66,7 +66,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
         return FGS_EINVAL;
     }
     const int fv = d->fwd_variant, afv = fv < 0 ? -fv : fv;
-    if ((d->seg_len != 0 && d->seg_len != 64 && d->seg_len != FGS_SEG) || (afv != 0 && afv != 1 && afv != 2 && afv != 4) ||
+    if (d->seg_len < 0 || d->seg_len > 512 || d->seg_len % 64 != 0 || (afv != 0 && afv != 1 && afv != 2 && afv != 4) ||
         d->bin_mode < 0 || d->bin_mode > 2 || (d->tile_w != 0 && d->tile_w != 16 && d->tile_w != 32)) {
         fgs_set_error("invalid tuning: seg_len=%d fwd_variant=%d bin_mode=%d tile_w=%d", d->seg_len, d->fwd_variant,
                       d->bin_mode, d->tile_w);
@@ -146,8 +146,8 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     // not fill the chip a few times over (config 2: -5 %, config 5: -3 %), costs 1 % at config 3's size.  The
     // row-split forward stages up to 128 records per chunk and needs 128.
     const bool row_split = !d->use_phase && p->fwd_parts == 0;
-    if (row_split && d->seg_len == 64) {
-        fgs_set_error("seg_len=64 is not available with the row-split forward (saturation_skip / fwd_variant < 0)");
+    if (row_split && d->seg_len != 0 && d->seg_len != FGS_SEG) {
+        fgs_set_error("seg_len=%d is not available with the row-split forward (saturation_skip / fwd_variant < 0)", d->seg_len);
         return FGS_EINVAL;
     }
 #ifndef FGS_SEG64_MAX_GAUSSIANS

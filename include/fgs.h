@@ -58,7 +58,7 @@ typedef struct FgsDims {
      * integer stages bit for bit -- tests/test_hip_parity.py).  The library reads NO environment variables: a
      * forward and its backward agree because both derive the plan from the same FgsDims, and the forward also
      * records (seg_len, fwd_variant) in saved.counters[4..5], which the backward kernels read. */
-    int32_t seg_len;        /* list entries per depth segment: 0 | 64 | 128 (saturation_skip needs 128)        */
+    int32_t seg_len;        /* list entries per depth segment: 0 | a multiple of 64 up to 512 (saturation_skip: 128) */
     int32_t fwd_variant;    /* forward work split: 0 | 1, 2, 4 = depth-split forward with that many list parts
                                (waves) per tile | -1, -2, -4 = row-split forward with that many waves per tile.
                                Phase path: |fwd_variant| = waves per tile.                                      */
