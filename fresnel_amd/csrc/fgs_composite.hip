@@ -357,13 +357,21 @@ __global__ __launch_bounds__(64 * NP * (1 + WIDE)) __attribute__((amdgpu_waves_p
 #pragma unroll
             for (int s = 0; s < 4; ++s) ckpt_store<PL>(ck + cell(s), BlendState{Cr[s], Cg[s], Cb[s], T[s], Dm[s]});
         }
+        // staging COMPACTS the chunk: only the records that touch this wave's 16 x 16 pixels are parked (in list order),
+        // so the list loop below has no skip test -- on 32 x 16 tiles ~15 % of a list's entries touch only the other half
+        float4 q0, q1, q2;
+        uint32_t flags = 0, cbits = 0;
         if (lane < n) {
             const uint32_t gid = dup_ids[base + lane];
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
-            float4 q0 = r[0], q1 = r[1], q2 = r[2];
-            q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
-            uint32_t flags, cbits;
+            q0 = r[0]; q1 = r[1]; q2 = r[2];
             stage_decode_w<2>(X0, c.Y0, __float_as_uint(q2.z), __float_as_uint(q2.w), q1.y, flags, cbits);
+        }
+        const unsigned long long tmask = __ballot((flags & 15u) != 0u);
+        const uint32_t nt = (uint32_t)__popcll(tmask);
+        if (flags & 15u) {
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+            q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
             q2.z = __uint_as_float(cbits); q2.w = __uint_as_float(flags);
             // alpha = min(G op, 0.99) = 0.99 clamp01(G op / 0.99): the list loop forms a' = clamp01(G op') with the
             // FREE clamp modifier of v_mul instead of a v_min (4.3 issue cycles on gfx950), the 0.99 rides on the
@@ -371,13 +379,12 @@ __global__ __launch_bounds__(64 * NP * (1 + WIDE)) __attribute__((amdgpu_waves_p
             // literal): one instruction and ~10 % of the pass's issue cycles less
             q1.y = q1.y / ALPHA_MAX;
             q1.z *= ALPHA_MAX; q1.w *= ALPHA_MAX; q2.x *= ALPHA_MAX; q2.y *= ALPHA_MAX;
-            sh0[wave][lane] = q0; sh1[wave][lane] = q1; sh2[wave][lane] = q2;
+            sh0[wave][slot] = q0; sh1[wave][slot] = q1; sh2[wave][slot] = q2;
         }
         __builtin_amdgcn_wave_barrier();  // wave-private LDS: one wave's LDS instructions execute in order
-        for (uint32_t j = 0; j < n; ++j) {
+        for (uint32_t j = 0; j < nt; ++j) {
             const uint32_t fl = __builtin_amdgcn_readfirstlane(__float_as_uint(sh2[wave][j].w));  // stage_decode_w flags
             const uint32_t msk = fl & 15u;
-            if (!msk) continue;  // (WIDE: also the entries that touch only the other half of the tile)
             const float4 q0 = sh0[wave][j], q1 = sh1[wave][j], q2 = sh2[wave][j];
             // (Skipping the lane masks for entries whose bbox covers the tile, or the min for opacities <= 0.98, behind
             // wave-uniform branches -- what pays in the backward -- made this loop 10 % SLOWER: 0.68 -> 0.75 ms at config 3;

@@ -59,8 +59,8 @@ def test_workspace_and_layout():
     assert L2.tile_w == 32 and L2.dup_capacity == 8 * 32768 * 60 and L2.tiles_x == 16 and L2.tiles_y == 32
     assert B.saved_layout(B.make_dims(8, 32768, 512, 512, tuning=dict(tile_w=16))).dup_capacity == 8 * 32768 * 100
     # the phase path, the row-split forward and saturation_skip keep 16 x 16 tiles and refuse 32
-    assert B.saved_layout(B.make_dims(2, 1000, 512, 512, use_phase=True)).tile_w == 16
-    assert B.saved_layout(B.make_dims(2, 1000, 512, 512, saturation_skip=True)).tile_w == 16
+    assert B.saved_layout(B.make_dims(8, 1000, 512, 512, use_phase=True)).tile_w == 16
+    assert B.saved_layout(B.make_dims(8, 1000, 512, 512, saturation_skip=True)).tile_w == 16
     with pytest.raises(B.FgsError):
         B.workspace_bytes(B.make_dims(2, 1000, 100, 72, use_phase=True, tuning=dict(tile_w=32)))
     with pytest.raises(B.FgsError):
@@ -121,7 +121,8 @@ def test_tuning_fields_are_validated_and_change_only_the_split():
         B.workspace_bytes(B.make_dims(1, 100, 8192, 16, tuning=dict(bin_mode=1, tile_w=16)))
     B.workspace_bytes(B.make_dims(1, 100, 8192, 16, tuning=dict(tile_w=16)))
     B.workspace_bytes(B.make_dims(1, 100, 8176, 16, tuning=dict(bin_mode=1, tile_w=16)))
-    B.workspace_bytes(B.make_dims(1, 100, 8192, 16, tuning=dict(bin_mode=1)))  # 256 + 1 lines of 32 x 16 tiles (automatic)
+    B.workspace_bytes(B.make_dims(1, 100, 8192, 16, tuning=dict(bin_mode=1, tile_w=32)))  # 256 + 1 lines of 32 x 16 tiles
+    B.workspace_bytes(B.make_dims(8, 100, 8192, 16, tuning=dict(bin_mode=1)))  # 4096 16 x 16 tiles: 32 x 16 automatically
 
 
 def test_new_entries_validate_arguments_without_a_gpu(lib):

@@ -402,6 +402,44 @@ def test_wide_tiles_vs_oracle(W, H, N, smax, fwd, seg):
             assert rel_to_max(out["grad_" + k][b], go[k]) <= TOL, (b, k)
 
 
+def test_automatic_tile_width_vs_oracle():
+    """FgsDims.tile_w = 0: 32 x 16 tiles from 512-pixel-wide frames on when the call has >= 4096 16 x 16 tiles, on the
+    blend path with the depth-split forward only; 16 x 16 otherwise, on the phase path and with saturation_skip.  Sixteen
+    520 x 120 frames (a ragged last wide tile) against the oracle with nothing forced."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd import _binding as B
+    from fresnel_amd.renderer import Camera
+    assert B.saved_layout(B.make_dims(8, 1000, 512, 512)).tile_w == 32
+    assert B.saved_layout(B.make_dims(4, 1000, 512, 512)).tile_w == 32
+    assert B.saved_layout(B.make_dims(3, 1000, 512, 512)).tile_w == 16
+    assert B.saved_layout(B.make_dims(1, 1000, 1024, 1024)).tile_w == 32
+    assert B.saved_layout(B.make_dims(64, 1000, 511, 512)).tile_w == 16
+    assert B.saved_layout(B.make_dims(8, 1000, 512, 512, use_phase=True)).tile_w == 16
+    assert B.saved_layout(B.make_dims(8, 1000, 512, 512, saturation_skip=True)).tile_w == 16
+    assert B.saved_layout(B.make_dims(8, 1000, 512, 512, tuning=dict(fwd_variant=-2))).tile_w == 16
+    with pytest.raises(B.FgsError):
+        B.saved_layout(B.make_dims(8, 1000, 512, 512, use_phase=True, tuning=dict(tile_w=32)))
+    W, H, N, Bn = 520, 120, 400, 16
+    per_image = [list(synth_aniso(N, 770 + b, smax=0.1, spread=0.9)) for b in range(Bn)]
+    batch = [np.stack([a[i] for a in per_image]) for i in range(5)]
+    cam = Camera(0.5 * W, 0.5 * W, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.5 * W, 0.5 * W, W / 2, H / 2, W, H)
+    bg = (0.2, 0.4, 0.1)
+    st = _hip_stages(batch, cam, W, H, bg)
+    assert int(st["layout"].tile_w) == 32 and int(st["layout"].tiles_x) == 17
+    rs = np.random.RandomState(5)
+    gI = rs.standard_normal((Bn, 3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((Bn, H, W)) * 0.1).astype(np.float32)
+    out = _hip_render(batch, cam, W, H, bg, grads=(gI, gD))
+    for b in (0, 7, 15):
+        r = _oracle(per_image[b], ocam, bg)
+        _check_integer_stages(st, b, r, W, H)
+        go = orc.render_backward(r, gI[b], gD[b])
+        assert rel_to_max(out["image"][b], r.image) <= TOL and rel_to_max(out["depth"][b], r.depth) <= TOL
+        for k in ["positions", "scales", "rotations", "colors", "opacities"]:
+            assert rel_to_max(out["grad_" + k][b], go[k]) <= TOL, (b, k)
+
+
 def test_wide_frame_direct_binning_division_is_exact():
     """A frame of 80 tile columns with Gaussians whose bbox spans > 64 of them (radius cap 700): the tile-row
     division of the direct binning's scatter must be exact for any width (the rounded-up reciprocal alone
