@@ -14,12 +14,14 @@ for (W, H, N, smax) in [(1024, 768, 6000, 0.1), (2000, 40, 3000, 0.1), (16, 16, 
     r = orc.render(*arrs, ocam, bg=bg)
     gI = rs.standard_normal((3, H, W)).astype(np.float32); gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
     go = orc.render_backward(r, gI, gD)
-    for skip in (False, True):
+    for skip, tw in ((False, 0), (False, 16), (False, 32), (True, 0)):
         ts = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in arrs]
-        img, dep = TileBasedRenderer(W, H, background=bg, saturation_skip=skip)(*ts, cam, return_depth=True)
+        ren = TileBasedRenderer(W, H, background=bg, saturation_skip=skip)
+        ren.tuning = dict(tile_w=tw) if tw else None
+        img, dep = ren(*ts, cam, return_depth=True)
         ((img * torch.from_numpy(gI).to(dev)).sum() + (dep * torch.from_numpy(gD).to(dev)).sum()).backward()
         errs = dict(image=rel_to_max(img.detach().cpu().numpy(), r.image), depth=rel_to_max(dep.detach().cpu().numpy(), r.depth))
         for t, k in zip(ts, ["positions", "scales", "rotations", "colors", "opacities"]):
             errs[k] = rel_to_max(t.grad.cpu().numpy(), go[k])
         m = max(errs.values())
-        print(f"W{W} H{H} N{N} skip={skip} P={r.P} max err {m:.2e} ({max(errs, key=errs.get)})" + ('' if m <= 1e-4 else '  <-- FAIL'), flush=True)
+        print(f"W{W} H{H} N{N} skip={skip} tile_w={tw} P={r.P} max err {m:.2e} ({max(errs, key=errs.get)})" + ('' if m <= 1e-4 else '  <-- FAIL'), flush=True)
