@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256) void k_mask_count(uint32_t B, uint32_t N, uint
 }
 
 constexpr uint32_t ME_CAP = 2048;       // list entries a wave parks in LDS per flush (k_mask_emit)
+#ifndef FGS_EMIT_BLOCK_MAX_LISTS
+#define FGS_EMIT_BLOCK_MAX_LISTS 8192u  // up to this many lists per launch: one block per list (k_mask_emit_block)
+#endif
 
 // (Staging `order` in LDS per block of eight tiles, to turn the sparse ids gather into coalesced loads, was tried: no
 // faster at config 3 -- 43.7 us -- and slower on long lists, 150 vs 110 us on the decoder-like scene: the per-lane
@@ -416,6 +419,108 @@ __global__ __launch_bounds__(256) void k_mask_emit(uint32_t B, uint32_t N, uint3
             __builtin_amdgcn_wave_barrier();
         }
         base += total;
+    }
+}
+
+// The same emission with ONE BLOCK (four waves) per list, for launches of few, long lists (config 3 on 32 x 16 tiles: 4096
+// lists of ~1000 entries; decoder-like: ~2500): the 256 lanes take consecutive rank words, a block scan (wave scans + the
+// four wave totals) gives each lane its run of list slots, and the bit walk, the `order` gather and the stores of a list
+// are spread over four waves instead of one -- a list's critical path is a quarter as long and the launch has four times
+// the waves to hide the gather latency with.
+template <int WPL>
+__global__ __launch_bounds__(256) void k_mask_emit_block(uint32_t B, uint32_t N, uint32_t layers,
+                                                         const uint32_t *__restrict__ plane_start, uint32_t tiles,
+                                                         uint32_t tiles_x, uint32_t lines, uint32_t w64p, uint32_t nrb,
+                                                         uint32_t bpi, uint32_t dcap,
+                                                         const unsigned long long *__restrict__ masks,
+                                                         const uint32_t *__restrict__ order,
+                                                         const uint32_t *__restrict__ tile_count,
+                                                         const uint32_t *__restrict__ ranges,
+                                                         const uint32_t *__restrict__ bsum,
+                                                         uint32_t *__restrict__ dup_ids, uint32_t *__restrict__ dup_off) {
+    constexpr uint32_t CAP = 4u * ME_CAP;
+    __shared__ uint32_t park[CAP];
+    __shared__ uint32_t wtot[4];
+    if (blockIdx.x < nrb) {  // duplicate offsets of one block of depth ranks (as in k_mask_emit)
+        const uint32_t b = blockIdx.x / bpi, blk = blockIdx.x - b * bpi;
+        const uint32_t r = blk * MB_RANKS + threadIdx.x;
+        uint32_t g = 0, c = 0, tot;
+        if (r < N) { g = b * N + order[b * N + r]; c = tile_count[g]; }
+        const uint32_t ex = block_exclusive_scan_256(c, &tot);
+        if (r < N) dup_off[g] = bsum[blockIdx.x] + ex;
+        return;
+    }
+    const uint32_t ntb = gridDim.x - nrb;  // = number of lists
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tile = fgs_xcd_remap(blockIdx.x - nrb, ntb);
+    const RankRange rr = rank_range(tile, N, tiles, layers, plane_start);
+    const uint32_t b = rr.b, y = rr.t / tiles_x, x = rr.t - y * tiles_x;
+    const unsigned long long *col = masks + ((size_t)b * lines + x) * w64p;
+    const unsigned long long *row = masks + ((size_t)b * lines + tiles_x + y) * w64p;
+    const uint32_t *ord = order + (size_t)b * N;
+    uint32_t base = ranges[2 * tile];  // next list slot
+    const uint32_t w_end = min(w64p, (rr.r_hi + 63u) / 64u);
+    for (uint32_t c0 = (rr.r_lo / 64u) / (256u * WPL) * (256u * WPL); c0 < w_end; c0 += 256u * WPL) {
+        const uint32_t w0 = c0 + tid * WPL;
+        unsigned long long m[WPL];
+#pragma unroll
+        for (int k = 0; k < WPL; ++k) m[k] = 0ull;
+        if (w0 < w_end) {
+            mask_words<WPL>(col, row, w0, m);
+#pragma unroll
+            for (int k = 0; k < WPL; ++k) m[k] = clip_word(m[k], w0 + k, rr.r_lo, rr.r_hi);
+        }
+        uint32_t cl = 0;
+#pragma unroll
+        for (int k = 0; k < WPL; ++k) cl += (uint32_t)__popcll(m[k]);
+        uint32_t inc = cl;  // inclusive wave scan of the lanes' entry counts
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += v;
+        }
+        if (lane == 63u) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t wpre = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            const uint32_t t = wtot[w];
+            wpre += w < wave ? t : 0u;
+            total += t;
+        }
+        const uint32_t ex = wpre + inc - cl;
+        // flush windows of CAP entries (one window unless a tile collects more than CAP of these ranks)
+        for (uint32_t win = 0; win < total; win += CAP) {
+            uint32_t e = ex;
+#pragma unroll
+            for (int k = 0; k < WPL; ++k) {
+                unsigned long long mm = m[k];
+                const uint32_t rank0 = (w0 + k) * 64u;
+                while (mm) {
+                    const uint32_t bit = (uint32_t)__ffsll((long long)mm) - 1u;
+                    mm &= mm - 1ull;
+                    if (e - win < CAP) park[e - win] = rank0 + bit;  // unsigned: e < win wraps past CAP
+                    ++e;
+                }
+            }
+            __syncthreads();
+            const uint32_t n = min(CAP, total - win);
+            for (uint32_t i = tid; i < n; i += 1024) {
+                uint32_t rk[4], id[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rk[u] = (i + 256u * u < n) ? park[i + 256u * u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) id[u] = ord[rk[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t pos = base + win + i + 256u * u;
+                    if (i + 256u * u < n && pos < dcap) dup_ids[pos] = b * N + id[u];
+                }
+            }
+            __syncthreads();
+        }
+        base += total;
+        __syncthreads();  // wtot is rewritten by the next chunk
     }
 }
 
@@ -701,8 +806,18 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
 #define FGS_MASK_EMIT(W) hipLaunchKernelGGL(k_mask_emit<W>, dim3(nrb + ntb), dim3(256), 0, st, B, N, layers, plane_start, \
                                             (uint32_t)p.tiles, tiles_x, lines, w64p, nrb, bpi, dcap, masks, order,         \
                                             tile_count, ranges, bsum, dup_ids, dup_off)
-        if (wpl == 1) FGS_MASK_EMIT(1); else if (wpl == 2) FGS_MASK_EMIT(2); else if (wpl == 4) FGS_MASK_EMIT(4); else FGS_MASK_EMIT(8);
+#define FGS_MASK_EMIT_BLOCK(W) hipLaunchKernelGGL(k_mask_emit_block<W>, dim3(nrb + ntiles_all), dim3(256), 0, st, B, N, layers, \
+                                                  plane_start, (uint32_t)p.tiles, tiles_x, lines, w64p, nrb, bpi, dcap, masks, \
+                                                  order, tile_count, ranges, bsum, dup_ids, dup_off)
+        // few lists (<= 8192: the blend path's frames; the ASM renderer's (image, plane, tile) lists are many and short)
+        // over more than 128 rank words (N > 8192 per image): a block per list, a quarter of the rank words per wave.
+        // Measured: config 3 (4096 lists of ~1000 entries) 40 -> 28 us, decoder-like (~2500 entries) 119 -> 38 us;
+        // config 2 (N = 8192, ~130 entries per list) 13 -> 17 us, so it keeps the wave-per-list kernel.
+        if (ntiles_all <= FGS_EMIT_BLOCK_MAX_LISTS && wpl >= 4) {
+            if (wpl == 4) FGS_MASK_EMIT_BLOCK(1); else FGS_MASK_EMIT_BLOCK(2);
+        } else if (wpl == 1) FGS_MASK_EMIT(1); else if (wpl == 2) FGS_MASK_EMIT(2); else if (wpl == 4) FGS_MASK_EMIT(4); else FGS_MASK_EMIT(8);
 #undef FGS_MASK_EMIT
+#undef FGS_MASK_EMIT_BLOCK
         FGS_LAUNCH_CHECK("k_mask_emit");
         fgs_stage_end(ST_TILE_SORT, st);
         return FGS_OK;
