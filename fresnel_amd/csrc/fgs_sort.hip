@@ -15,6 +15,7 @@
 // comes from wave64 ballots: 8 ballots give the mask of lanes holding the same digit,
 // popcount below the lane gives the stable rank -- no atomics, no order dependence).
 // HBM-bound: 8 B read in upsweep+downsweep and 8 B written per element per pass.
+#include <type_traits>
 #include "fgs_internal.h"
 
 namespace {
@@ -47,8 +48,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(
     h[threadIdx.x] = 0;
     __syncthreads();
     const SegInfo r = block_range(seg_len, seg_len_dev, seg_capacity, seg_stride);
-    for (uint32_t i = r.begin + threadIdx.x; i < r.end; i += RS_THREADS)
-        atomicAdd(&h[(keys[i] >> shift) & dmask], 1u);
+    for (uint32_t i = r.begin + threadIdx.x; i < r.end; i += 4 * RS_THREADS) {  // four loads in flight
+        uint32_t k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = i + u * RS_THREADS < r.end ? keys[i + u * RS_THREADS] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * RS_THREADS < r.end) atomicAdd(&h[(k[u] >> shift) & dmask], 1u);
+    }
     __syncthreads();
     // layout: hist[(seg*256 + digit) * bps + blk]
     hist[((size_t)blockIdx.y * 256 + threadIdx.x) * gridDim.x + blockIdx.x] = h[threadIdx.x];
@@ -118,12 +125,39 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
             t = dtot[blockIdx.y * 256 + tid];
             mine = hist[((size_t)blockIdx.y * 256 + tid) * gridDim.x + blockIdx.x];
         } else {
+            // (all the loads of a batch are issued before the first is used: the plain loop waited for every load in turn,
+            // 16 serialised L2 round trips of the 10 us this kernel took at config 3)
             const uint32_t *row = hist + ((size_t)blockIdx.y * 256 + tid) * gridDim.x;
+            const uint32_t bps = gridDim.x, me = blockIdx.x;
             t = 0; mine = 0;
-            for (uint32_t k = 0; k < gridDim.x; ++k) {
-                const uint32_t c = row[k];
-                mine += k < blockIdx.x ? c : 0u;
-                t += c;
+            auto sum_vectors = [&](auto nv_tag) {  // rows of whole 16-byte groups (the histogram base is 256-byte aligned)
+                constexpr uint32_t NV = decltype(nv_tag)::value;
+                const uint4 *row4 = reinterpret_cast<const uint4 *>(row);
+                uint4 v[NV];
+#pragma unroll
+                for (uint32_t k = 0; k < NV; ++k) v[k] = 4u * k < bps ? row4[k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (uint32_t k = 0; k < NV; ++k) {
+                    t += v[k].x + v[k].y + v[k].z + v[k].w;
+                    mine += (4u * k < me ? v[k].x : 0u) + (4u * k + 1u < me ? v[k].y : 0u) +
+                            (4u * k + 2u < me ? v[k].z : 0u) + (4u * k + 3u < me ? v[k].w : 0u);
+                }
+            };
+            if ((bps & 3u) == 0u && bps <= 16u) {
+                sum_vectors(std::integral_constant<uint32_t, 4>{});
+            } else if ((bps & 3u) == 0u) {  // bps <= 64
+                sum_vectors(std::integral_constant<uint32_t, 16>{});
+            } else {
+                for (uint32_t k0 = 0; k0 < bps; k0 += 8) {
+                    uint32_t c[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; ++u) c[u] = k0 + u < bps ? row[k0 + u] : 0u;
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; ++u) {
+                        mine += k0 + u < me ? c[u] : 0u;
+                        t += c[u];
+                    }
+                }
             }
         }
         uint32_t s = t;
