@@ -410,8 +410,8 @@ __global__ __launch_bounds__(64 * NP * (1 + WIDE)) __attribute__((amdgpu_waves_p
                     float G = __builtin_amdgcn_exp2f(t * dx + cyy);
                     const uint32_t mk = my & mxc[col];
                     G = __uint_as_float(__float_as_uint(G) & mk);
-                    float a1;  // alpha / 0.99, opacity >= 0 here
-                    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(a1) : "v"(G), "v"(q1.y));
+                    // alpha / 0.99 (opacity >= 0 here); v_med3(x, 0, 1) of a product folds into the product's clamp modifier
+                    const float a1 = __builtin_amdgcn_fmed3f(G * q1.y, 0.0f, 1.0f);
                     const float w = a1 * T[s];  // (alpha T) / 0.99
                     Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
                     T[s] = fmaf(w, -ALPHA_MAX, T[s]);
@@ -661,8 +661,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6
                     const float t = ca * dx + (row ? bdyb : bdya);
                     const float Gu = __builtin_amdgcn_exp2f(t * dx + (row ? cyyb : cyya));
                     const float G = __uint_as_float(__float_as_uint(Gu) & mk);
-                    float a1;  // alpha / 0.99
-                    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(a1) : "v"(G), "v"(op));
+                    const float a1 = __builtin_amdgcn_fmed3f(G * op, 0.0f, 1.0f);  // alpha / 0.99: v_mul ... clamp
                     const float w = a1 * T[s];  // w / 0.99
                     const float q = gr[s] * q1.z + gg[s] * q1.w + gb[s] * q2.x + gd[s] * q2.y;  // 0.99 q
                     S[s] -= w * q;

@@ -339,6 +339,37 @@ def test_mask_binning_dense_tiles_flush_in_windows():
     assert np.array_equal(outs[0]["dup_off"], outs[1]["dup_off"])
 
 
+@pytest.mark.parametrize("N,W,H,scale,min_len", [(20000, 48, 32, 0.25, 2 * 8192), (40000, 200, 136, 0.03, 64)])
+def test_mask_binning_block_per_list_vs_oracle(N, W, H, scale, min_len):
+    """k_mask_emit_block (launches of <= 8192 lists over more than 8192 Gaussians per image: one block per list, 256 lanes
+    over the rank words).  (a) 20 000 wide Gaussians over 3 x 2 tiles: every list collects more than the 8192 entries a
+    block parks per flush, so the windowed flush runs; (b) 40 000 small ones: two chunks of 32 768 depth ranks per list.
+    Bit-exact against the oracle and against the radix path, two images per call."""
+    from oracle import fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    rs = np.random.RandomState(N)
+    batch = []
+    for b in range(2):
+        pos = (rs.randn(N, 3) * [0.3, 0.25, 0.3] + [0, 0, -2.0]).astype(np.float32)
+        sc = (scale * rs.uniform(0.5, 1.5, (N, 3))).astype(np.float32)
+        batch.append([pos, sc, rs.randn(N, 4).astype(np.float32), rs.rand(N, 3).astype(np.float32),
+                      rs.uniform(0.002, 0.02, N).astype(np.float32)])
+    arrs = [np.stack([batch[0][i], batch[1][i]]) for i in range(5)]
+    cam = Camera(0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * H, W / 2, H / 2, W, H)
+    outs = [_hip_stages(arrs, cam, W, H, tuning=dict(bin_mode=m)) for m in (1, 2)]
+    lens = outs[0]["ranges"][:, :, 1] - outs[0]["ranges"][:, :, 0]
+    assert lens.max() > min_len
+    for b in range(2):
+        _check_integer_stages(outs[0], b, _oracle(batch[b], ocam, (0, 0, 0)), W, H)
+    D = int(outs[0]["counters"][0])
+    assert np.array_equal(outs[0]["dup_ids"][:D], outs[1]["dup_ids"][:D])
+    lens2 = outs[1]["ranges"][:, :, 1] - outs[1]["ranges"][:, :, 0]
+    assert np.array_equal(lens, lens2)
+    assert np.array_equal(outs[0]["ranges"][lens > 0], outs[1]["ranges"][lens > 0])  # (an empty list's start is free)
+    assert np.array_equal(outs[0]["dup_off"], outs[1]["dup_off"])
+
+
 def test_count_pairs_equals_the_bbox_areas():
     """fgs_count_pairs (the benchmark's unit of work, SURVEY 8d: composited Gaussian-pixels = sum of the visible
     Gaussians' integer bbox areas) against numpy on the saved records and against the oracle's P."""
