@@ -66,7 +66,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
         return FGS_EINVAL;
     }
     const int fv = d->fwd_variant, afv = fv < 0 ? -fv : fv;
-    if (d->seg_len < 0 || d->seg_len > 512 || d->seg_len % 64 != 0 || (afv != 0 && afv != 1 && afv != 2 && afv != 4) ||
+    if (d->seg_len < 0 || d->seg_len > 512 || d->seg_len % 64 != 0 || (afv != 0 && afv != 1 && afv != 2 && afv != 4 && !(fv == 8 || fv == 16)) ||
         d->bin_mode < 0 || d->bin_mode > 2 || (d->tile_w != 0 && d->tile_w != 16 && d->tile_w != 32)) {
         fgs_set_error("invalid tuning: seg_len=%d fwd_variant=%d bin_mode=%d tile_w=%d", d->seg_len, d->fwd_variant,
                       d->bin_mode, d->tile_w);
@@ -132,6 +132,10 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     // the serial length of the longest lists, one wins with >= 24576 tiles, four for launches that cannot fill the
     // chip once.  Phase path: the recurrence is latency-bound (serial cos / divide chain per pixel), four waves.
     const uint32_t grid_tiles = (uint32_t)(B * p->tiles);
+    if (afv > 4 && (d->use_phase || d->saturation_skip || layers != 1 || !segment_ckpt)) {
+        fgs_set_error("fwd_variant=%d: 8 / 16 list parts exist on the blend path's depth-split forward only", fv);
+        return FGS_EINVAL;
+    }
     if (d->use_phase) {
         p->fwd_parts = 0;
         p->fwd_waves = afv ? afv : 4;
@@ -141,7 +145,12 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
         p->fwd_waves = fv < 0 ? afv : (grid_tiles >= 24576u ? 1 : (grid_tiles <= 6144u ? 4 : 2));
         p->fwd_variant = -p->fwd_waves;
     } else {
-        p->fwd_parts = fv > 0 ? fv : (grid_tiles >= 24576u ? 1 : 4);
+        // few tiles: the launch is as long as its longest list, so more parts per tile (fwd ms at 4 / 8 / 16 parts, 16 x 16
+        // tiles: config 3 at 1 image -- 1024 tiles -- 0.186 / 0.120 / 0.111, at 2 images 0.204 / 0.167 / 0.204, at 3 images
+        // 0.243 / 0.250 / 0.31; config 2 at 2 images -- 512 tiles -- 0.076 / 0.054 / 0.046, at 8 images 0.083 / 0.076 / 0.103;
+        // 32 x 16 tiles -- launches of >= 2048 of them, two waves per part -- stay at 4: 0.315 vs 0.344 with 8 at config 3, 4 images)
+        p->fwd_parts = fv > 0 ? fv : (grid_tiles >= 24576u ? 1 : (p->tile_w != 16 ? 4 : (grid_tiles <= 1024u ? 16 : (grid_tiles <= 2048u ? 8 : 4))));
+        if (p->tile_w == 32 && p->fwd_parts > 8) p->fwd_parts = 8;  // two waves per part there: 16 waves per block
         p->fwd_waves = p->fwd_parts;
         p->fwd_variant = p->fwd_parts;
     }

@@ -912,9 +912,11 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
                        p.d.background[1], p.d.background[2], tile_order, ranges, dup_ids, rec, pix, out_rgb,  \
                        out_depth, seg_off, seg_ckpt, (uint32_t)p.L.seg_len)
         if (p.tile_w == 32) {
-            if (np == 1) FGS_PARTS_LAUNCH(1, 1); else if (np == 2) FGS_PARTS_LAUNCH(2, 1); else FGS_PARTS_LAUNCH(4, 1);
+            if (np == 1) FGS_PARTS_LAUNCH(1, 1); else if (np == 2) FGS_PARTS_LAUNCH(2, 1); else if (np == 4) FGS_PARTS_LAUNCH(4, 1);
+            else FGS_PARTS_LAUNCH(8, 1);
         } else {
-            if (np == 1) FGS_PARTS_LAUNCH(1, 0); else if (np == 2) FGS_PARTS_LAUNCH(2, 0); else FGS_PARTS_LAUNCH(4, 0);
+            if (np == 1) FGS_PARTS_LAUNCH(1, 0); else if (np == 2) FGS_PARTS_LAUNCH(2, 0); else if (np == 4) FGS_PARTS_LAUNCH(4, 0);
+            else if (np == 8) FGS_PARTS_LAUNCH(8, 0); else FGS_PARTS_LAUNCH(16, 0);
         }
 #undef FGS_PARTS_LAUNCH
         FGS_LAUNCH_CHECK("k_blend_fwd_parts");

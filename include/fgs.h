@@ -59,8 +59,8 @@ typedef struct FgsDims {
      * forward and its backward agree because both derive the plan from the same FgsDims, and the forward also
      * records (seg_len, fwd_variant) in saved.counters[4..5], which the backward kernels read. */
     int32_t seg_len;        /* list entries per depth segment: 0 | a multiple of 64 up to 512 (saturation_skip: 128) */
-    int32_t fwd_variant;    /* forward work split: 0 | 1, 2, 4 = depth-split forward with that many list parts
-                               (waves) per tile | -1, -2, -4 = row-split forward with that many waves per tile.
+    int32_t fwd_variant;    /* forward work split: 0 | 1, 2, 4, 8, 16 = depth-split forward with that many list parts
+                               per tile (16 x 16 tiles; at most 8 on 32 x 16 tiles) | -1, -2, -4 = row-split forward with that many waves per tile.
                                Phase path: |fwd_variant| = waves per tile.                                      */
     int32_t bin_mode;       /* tile binning: 0 | 1 = direct (column / row rank masks) | 2 = emit + stable radix sort */
     int32_t tile_w;         /* tile width in pixels: 0 | 16 | 32 (tiles are always 16 rows high).  0 = automatic:

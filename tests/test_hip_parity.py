@@ -400,7 +400,7 @@ def test_count_pairs_equals_the_bbox_areas():
 
 
 @pytest.mark.parametrize("W,H,N,smax,fwd,seg", [(72, 40, 900, 0.15, 4, 64), (200, 136, 4000, 0.2, 2, 128), (48, 32, 1500, 0.5, 1, 64),
-                                                (33, 17, 300, 0.3, 4, 128)])
+                                                (33, 17, 300, 0.3, 4, 128), (48, 32, 1500, 0.5, 8, 64)])
 def test_wide_tiles_vs_oracle(W, H, N, smax, fwd, seg):
     """32 x 16 tiles (FgsDims.tile_w = 32: eight sub-tiles per lane in the backward, two waves per list part -- one per
     16 x 16 half -- in the forward, [5][8][64] checkpoint slots) on frames that are not whole numbers of tiles, with every
@@ -592,7 +592,7 @@ def test_long_lists_many_depth_segments_vs_oracle():
 @pytest.mark.parametrize("use_phase", [False, True])
 def test_forward_variants_agree(use_phase):
     """The forward picks its work split from the launch size; FgsDims.fwd_variant / seg_len force one.  Blend path:
-    the depth-split kernel with 1, 2 or 4 list parts per tile (partial results composed with
+    the depth-split kernel with 1, 2, 4, 8 or 16 list parts per tile (partial results composed with
     (C,T)o(C',T') = (C + T C', T T'), the backward re-bases part-local checkpoints), with 64- or 128-entry depth
     segments, or the row-split kernel with 1, 2 or 4 waves per tile.  Phase path: 1, 2 or 4 waves per tile.  All
     variants must agree on image, depth and -- through the saved state and checkpoints -- on every gradient, to
@@ -612,7 +612,9 @@ def test_forward_variants_agree(use_phase):
         variants = [dict(fwd_variant=w) for w in (1, 2, 4)]
     else:
         variants = ([dict(fwd_variant=p, seg_len=sl) for p in (1, 2, 4) for sl in (64, 128)] +
-                    [dict(fwd_variant=-w) for w in (1, 2, 4)])
+                    [dict(fwd_variant=-w) for w in (1, 2, 4)] +
+                    [dict(fwd_variant=8, seg_len=64), dict(fwd_variant=16, seg_len=64), dict(fwd_variant=16, seg_len=128),
+                     dict(fwd_variant=8, seg_len=64, tile_w=32), dict(fwd_variant=16, seg_len=64, tile_w=32)])
     bg = (0.1, 0.2, 0.3)
     outs = [_hip_render(arrs, cam, S, S, bg, phases=phases, use_phase=use_phase, grads=(gI, gD), tuning=t)
             for t in variants]
