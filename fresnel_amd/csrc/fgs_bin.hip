@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256) void k_mask_count(uint32_t B, uint32_t N, uint
 }
 
 constexpr uint32_t ME_CAP = 2048;       // list entries a wave parks in LDS per flush (k_mask_emit)
+#ifndef FGS_GROUP_MIN_LISTS
+#define FGS_GROUP_MIN_LISTS 4096u  // from this many lists of <= 16 rank words on: sixteen lanes per list (k_mask_*_group)
+#endif
 #ifndef FGS_EMIT_BLOCK_MAX_LISTS
 #define FGS_EMIT_BLOCK_MAX_LISTS 8192u  // up to this many lists per launch: one block per list (k_mask_emit_block)
 #endif
@@ -417,6 +420,128 @@ __global__ __launch_bounds__(256) void k_mask_emit(uint32_t B, uint32_t N, uint3
                 }
             }
             __builtin_amdgcn_wave_barrier();
+        }
+        base += total;
+    }
+}
+
+// SHORT lists over few rank words (the ASM renderer's (image, plane, tile) lists: a plane's share of the depth ranks is
+// ~10 words, a list ~13 entries; 131 072 lists at 8 images): SIXTEEN LANES per list, four lists per wave -- a wave per
+// list left 50+ lanes idle in every instruction.  Same algorithm per group: the 16 lanes take consecutive rank words,
+// a 16-lane scan gives each lane its run of list slots, bits parked in the group's LDS region, ids gathered side by side.
+constexpr uint32_t MG_CAP = 512;  // list entries a 16-lane group parks per flush
+
+__global__ __launch_bounds__(256) void k_mask_count_group(uint32_t B, uint32_t N, uint32_t layers,
+                                                          const uint32_t *__restrict__ plane_start, uint32_t tiles,
+                                                          uint32_t tiles_x, uint32_t lines, uint32_t w64p, uint32_t nrb,
+                                                          const unsigned long long *__restrict__ masks,
+                                                          uint32_t *__restrict__ lens, uint32_t *__restrict__ bsum,
+                                                          uint32_t *__restrict__ counters, uint32_t dcap) {
+    if (blockIdx.x == gridDim.x - 1) {  // scan of k_mask_build's block sums (as in k_mask_count)
+        unsigned long long carry = 0;
+        for (uint32_t base = 0; base < nrb; base += 256) {
+            const uint32_t i = base + threadIdx.x;
+            const uint32_t v = i < nrb ? bsum[i] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_exclusive_scan_256(v, &tot);
+            if (i < nrb) bsum[i] = (uint32_t)carry + ex;
+            carry += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            counters[0] = carry > dcap ? dcap : (uint32_t)carry;
+            counters[1] = carry > dcap ? 1u : 0u;
+        }
+        return;
+    }
+    const uint32_t glane = threadIdx.x & 15u;
+    const uint32_t list = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const bool valid = list < B * layers * tiles;
+    uint32_t c = 0;
+    if (valid) {
+        const RankRange rr = rank_range(list, N, tiles, layers, plane_start);
+        const uint32_t y = rr.t / tiles_x, x = rr.t - y * tiles_x;
+        const unsigned long long *col = masks + ((size_t)rr.b * lines + x) * w64p;
+        const unsigned long long *row = masks + ((size_t)rr.b * lines + tiles_x + y) * w64p;
+        const uint32_t w_end = min(w64p, (rr.r_hi + 63u) / 64u);
+        for (uint32_t w = rr.r_lo / 64u + glane; w < w_end; w += 16u)
+            c += (uint32_t)__popcll(clip_word(col[w] & row[w], w, rr.r_lo, rr.r_hi));
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (valid && glane == 0) lens[list] = c;
+}
+
+__global__ __launch_bounds__(256) void k_mask_emit_group(uint32_t B, uint32_t N, uint32_t layers,
+                                                         const uint32_t *__restrict__ plane_start, uint32_t tiles,
+                                                         uint32_t tiles_x, uint32_t lines, uint32_t w64p, uint32_t nrb,
+                                                         uint32_t bpi, uint32_t dcap,
+                                                         const unsigned long long *__restrict__ masks,
+                                                         const uint32_t *__restrict__ order,
+                                                         const uint32_t *__restrict__ tile_count,
+                                                         const uint32_t *__restrict__ ranges,
+                                                         const uint32_t *__restrict__ bsum,
+                                                         uint32_t *__restrict__ dup_ids, uint32_t *__restrict__ dup_off) {
+    __shared__ uint32_t park[16][MG_CAP];
+    if (blockIdx.x < nrb) {  // duplicate offsets of one block of depth ranks (as in k_mask_emit)
+        const uint32_t b = blockIdx.x / bpi, blk = blockIdx.x - b * bpi;
+        const uint32_t r = blk * MB_RANKS + threadIdx.x;
+        uint32_t g = 0, c = 0, tot;
+        if (r < N) { g = b * N + order[b * N + r]; c = tile_count[g]; }
+        const uint32_t ex = block_exclusive_scan_256(c, &tot);
+        if (r < N) dup_off[g] = bsum[blockIdx.x] + ex;
+        return;
+    }
+    const uint32_t ntb = gridDim.x - nrb;
+    const uint32_t glane = threadIdx.x & 15u, grp = threadIdx.x >> 4;
+    const uint32_t list = fgs_xcd_remap(blockIdx.x - nrb, ntb) * 16u + grp;
+    if (list >= B * layers * tiles) return;  // whole groups leave together
+    const RankRange rr = rank_range(list, N, tiles, layers, plane_start);
+    const uint32_t b = rr.b, y = rr.t / tiles_x, x = rr.t - y * tiles_x;
+    const unsigned long long *col = masks + ((size_t)b * lines + x) * w64p;
+    const unsigned long long *row = masks + ((size_t)b * lines + tiles_x + y) * w64p;
+    const uint32_t *ord = order + (size_t)b * N;
+    uint32_t *pk = park[grp];
+    uint32_t base = ranges[2 * list];  // next list slot
+    const uint32_t w_end = min(w64p, (rr.r_hi + 63u) / 64u);
+    // every bound below is the same for the 16 lanes of a group, so a group stays converged (groups of one wave may
+    // diverge from each other: they share nothing)
+    for (uint32_t c0 = rr.r_lo / 64u; c0 < w_end; c0 += 16u) {
+        const uint32_t w = c0 + glane;
+        const unsigned long long m = w < w_end ? clip_word(col[w] & row[w], w, rr.r_lo, rr.r_hi) : 0ull;
+        const uint32_t cl = (uint32_t)__popcll(m);
+        uint32_t inc = cl;  // inclusive scan over the group's lanes
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o, 16);
+            if ((int)glane >= o) inc += v;
+        }
+        const uint32_t total = __shfl(inc, 15, 16);
+        const uint32_t ex = inc - cl;
+        for (uint32_t win = 0; win < total; win += MG_CAP) {
+            uint32_t e = ex;
+            unsigned long long mm = m;
+            while (mm) {
+                const uint32_t bit = (uint32_t)__ffsll((long long)mm) - 1u;
+                mm &= mm - 1ull;
+                if (e - win < MG_CAP) pk[e - win] = w * 64u + bit;  // unsigned: e < win wraps past MG_CAP
+                ++e;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t n = min(MG_CAP, total - win);
+            for (uint32_t i = glane; i < n; i += 64) {
+                uint32_t rk[4], id[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rk[u] = (i + 16u * u < n) ? pk[i + 16u * u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) id[u] = ord[rk[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t pos = base + win + i + 16u * u;
+                    if (i + 16u * u < n && pos < dcap) dup_ids[pos] = b * N + id[u];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         base += total;
     }
@@ -793,7 +918,13 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         FGS_LAUNCH_CHECK("k_mask_build");
 #define FGS_MASK_COUNT(W) hipLaunchKernelGGL(k_mask_count<W>, dim3(ntb + 1), dim3(256), 0, st, B, N, layers, plane_start, \
                                              (uint32_t)p.tiles, tiles_x, lines, w64p, nrb, masks, lens, bsum, counters, dcap)
-        if (wpl == 1) FGS_MASK_COUNT(1); else if (wpl == 2) FGS_MASK_COUNT(2); else if (wpl == 4) FGS_MASK_COUNT(4); else FGS_MASK_COUNT(8);
+        // many short lists over <= 16 rank words each (the ASM renderer's depth planes): 16 lanes per list
+        const bool grouped = wspan <= 16u && ntiles_all >= FGS_GROUP_MIN_LISTS;
+        const uint32_t ngb = (ntiles_all + 15) / 16;  // sixteen lists per block
+        if (grouped)
+            hipLaunchKernelGGL(k_mask_count_group, dim3(ngb + 1), dim3(256), 0, st, B, N, layers, plane_start, (uint32_t)p.tiles,
+                               tiles_x, lines, w64p, nrb, masks, lens, bsum, counters, dcap);
+        else if (wpl == 1) FGS_MASK_COUNT(1); else if (wpl == 2) FGS_MASK_COUNT(2); else if (wpl == 4) FGS_MASK_COUNT(4); else FGS_MASK_COUNT(8);
 #undef FGS_MASK_COUNT
         FGS_LAUNCH_CHECK("k_mask_count");
         fgs_stage_end(ST_DUP_EMIT, st);
@@ -813,7 +944,10 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         // over more than 128 rank words (N > 8192 per image): a block per list, a quarter of the rank words per wave.
         // Measured: config 3 (4096 lists of ~1000 entries) 40 -> 28 us, decoder-like (~2500 entries) 119 -> 38 us;
         // config 2 (N = 8192, ~130 entries per list) 13 -> 17 us, so it keeps the wave-per-list kernel.
-        if (ntiles_all <= FGS_EMIT_BLOCK_MAX_LISTS && wpl >= 4) {
+        if (grouped) {
+            hipLaunchKernelGGL(k_mask_emit_group, dim3(nrb + ngb), dim3(256), 0, st, B, N, layers, plane_start, (uint32_t)p.tiles,
+                               tiles_x, lines, w64p, nrb, bpi, dcap, masks, order, tile_count, ranges, bsum, dup_ids, dup_off);
+        } else if (ntiles_all <= FGS_EMIT_BLOCK_MAX_LISTS && wpl >= 4) {
             if (wpl == 4) FGS_MASK_EMIT_BLOCK(1); else FGS_MASK_EMIT_BLOCK(2);
         } else if (wpl == 1) FGS_MASK_EMIT(1); else if (wpl == 2) FGS_MASK_EMIT(2); else if (wpl == 4) FGS_MASK_EMIT(4); else FGS_MASK_EMIT(8);
 #undef FGS_MASK_EMIT

@@ -191,18 +191,22 @@ def test_asm_column_fused_transforms_vs_oracle(W, H):
     assert rel_to_max(out["grad_wavelengths"], gw) <= 1e-3
 
 
-def test_asm_layered_mask_binning_equals_radix_binning():
+@pytest.mark.parametrize("W,H,N,spread,smin,smax", [(136, 72, 1237, 0.5, 0.03, 0.12), (264, 200, 1237, 0.5, 0.03, 0.12),
+                                                    (264, 200, 9000, 0.04, 0.5, 1.0)])
+def test_asm_layered_mask_binning_equals_radix_binning(W, H, N, spread, smin, smax):
     """(image, plane, tile) lists two ways: the mask binning over a depth order grouped by plane (default) and the
     emit + stable radix sort over (image, plane, tile) keys (FgsAsmDims.bin_mode = 2).  Same lists in the same order, so
     the splat sums, the image and every gradient must agree BITWISE.  Two images, 11 planes, a frame that is not a whole
-    number of tiles, a Gaussian count that is not a multiple of 64."""
+    number of tiles, a Gaussian count that is not a multiple of 64.  The 264 x 200 frames have 4862 lists over <= 16 rank
+    words each and take the sixteen-lanes-per-list kernels (k_mask_count_group / k_mask_emit_group); the 9000 clustered,
+    radius-capped Gaussians put more than the 512 entries a group parks per flush into the central lists."""
     from fresnel_amd.renderer import ASMWaveFieldRenderer, Camera
     dev = _cuda()
-    W, H, N, Bn = 136, 72, 1237, 2
+    Bn = 2
     rs = np.random.RandomState(5)
     per = []
     for b in range(Bn):
-        pos, scale, quat, col, opa = synth_aniso(N, 270 + b, opacity_max=0.9, smin=0.03, smax=0.12)
+        pos, scale, quat, col, opa = synth_aniso(N, 270 + b, opacity_max=0.9, spread=spread, smin=smin, smax=smax)
         pos[:, 2] = -rs.uniform(0.3, 2.5, N).astype(np.float32)
         per.append((pos, scale, quat, col, opa))
     arrs = [np.stack([p[i] for p in per]) for i in range(5)]
