@@ -87,13 +87,13 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
         fgs_set_error("tile_w=32 needs the blend path with the depth-split forward");
         return FGS_EINVAL;
     }
-    // automatic: wide tiles from 512-pixel-wide frames on, when the call has at least 4096 16 x 16 tiles (fewer do not fill
+    // automatic: wide tiles from 512-pixel-wide frames on, when the call has at least 3072 16 x 16 tiles (fewer do not fill
     // the chip and the finer tiles' parallelism wins).  What really decides is how many tiles a Gaussian touches, which the
     // dims do not say; measured on the benchmark scenes, 32 x 16 against 16 x 16 per step: 512^2 at 8 images -4 % (config 3:
-    // backward -4 ... -6 %, row sums -29 %, forward equal) and -5 % decoder-like, at 4 / 3 images equal, at 2 / 1 images
-    // +3 / +4.5 %; 256^2 (config 2, Gaussians half as large in pixels) +3 %.
+    // backward -4 ... -6 %, row sums -29 %, forward equal) and -5 % decoder-like, at 4 images -2.8 %, at 3 images -2.3 %
+    // (decoder-like: equal), at 2 / 1 images +1 / +4.5 %; 256^2 (config 2, Gaussians half as large in pixels) +3 %.
     const size_t tiles16 = B * (size_t)((d->width + 15) / 16) * (size_t)((d->height + 15) / 16);
-    p->tile_w = d->tile_w ? d->tile_w : ((wide_ok && d->width >= 512 && tiles16 >= 4096) ? 32 : 16);
+    p->tile_w = d->tile_w ? d->tile_w : ((wide_ok && d->width >= 512 && tiles16 >= 3072) ? 32 : 16);
     const int tx = (d->width + p->tile_w - 1) / p->tile_w, ty = (d->height + FGS_TILE - 1) / FGS_TILE;
     p->tiles = tx * ty;
     // bbox width <= floor(2r)+2 pixels -> spans at most floor((2r+1)/tile)+2 tile columns

@@ -65,7 +65,7 @@ typedef struct FgsDims {
     int32_t bin_mode;       /* tile binning: 0 | 1 = direct (column / row rank masks) | 2 = emit + stable radix sort */
     int32_t tile_w;         /* tile width in pixels: 0 | 16 | 32 (tiles are always 16 rows high).  0 = automatic:
                                32 on the blend path with the depth-split forward for frames >= 512 pixels wide
-                               in calls of >= 4096 16 x 16 tiles, 16 elsewhere (FgsSavedLayout.tile_w tells)    */
+                               in calls of >= 3072 16 x 16 tiles, 16 elsewhere (FgsSavedLayout.tile_w tells)    */
 } FgsDims;
 
 /* Camera record on the DEVICE: FGS_CAMERA_FLOATS floats per camera (Camera, DR:27-52):

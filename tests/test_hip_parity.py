@@ -434,7 +434,7 @@ def test_wide_tiles_vs_oracle(W, H, N, smax, fwd, seg):
 
 
 def test_automatic_tile_width_vs_oracle():
-    """FgsDims.tile_w = 0: 32 x 16 tiles from 512-pixel-wide frames on when the call has >= 4096 16 x 16 tiles, on the
+    """FgsDims.tile_w = 0: 32 x 16 tiles from 512-pixel-wide frames on when the call has >= 3072 16 x 16 tiles, on the
     blend path with the depth-split forward only; 16 x 16 otherwise, on the phase path and with saturation_skip.  Sixteen
     520 x 120 frames (a ragged last wide tile) against the oracle with nothing forced."""
     from oracle import fgs_oracle as orc
@@ -442,7 +442,8 @@ def test_automatic_tile_width_vs_oracle():
     from fresnel_amd.renderer import Camera
     assert B.saved_layout(B.make_dims(8, 1000, 512, 512)).tile_w == 32
     assert B.saved_layout(B.make_dims(4, 1000, 512, 512)).tile_w == 32
-    assert B.saved_layout(B.make_dims(3, 1000, 512, 512)).tile_w == 16
+    assert B.saved_layout(B.make_dims(3, 1000, 512, 512)).tile_w == 32
+    assert B.saved_layout(B.make_dims(2, 1000, 512, 512)).tile_w == 16
     assert B.saved_layout(B.make_dims(1, 1000, 1024, 1024)).tile_w == 32
     assert B.saved_layout(B.make_dims(64, 1000, 511, 512)).tile_w == 16
     assert B.saved_layout(B.make_dims(8, 1000, 512, 512, use_phase=True)).tile_w == 16
