@@ -747,10 +747,15 @@ __global__ __launch_bounds__(256) void k_tile_post(uint32_t ntiles, uint32_t *__
     {
         uint32_t before = 0, all = 0;
         const uint32_t b = threadIdx.x & 63u;
-        for (uint32_t k = threadIdx.x >> 6; k < nblk; k += 4) {
-            const uint32_t h = bhist[k * 64 + b];
-            all += h;
-            if (k < blk) before += h;
+        for (uint32_t k0 = threadIdx.x >> 6; k0 < nblk; k0 += 32) {  // eight loads in flight (rows k0, k0 + 4, ...)
+            uint32_t h[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) h[u] = k0 + 4u * u < nblk ? bhist[(k0 + 4u * u) * 64 + b] : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                all += h[u];
+                if (k0 + 4u * u < blk) before += h[u];
+            }
         }
         __shared__ uint32_t pb[4][64], pa[4][64];
         pb[threadIdx.x >> 6][b] = before; pa[threadIdx.x >> 6][b] = all;
