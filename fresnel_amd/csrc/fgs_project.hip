@@ -287,14 +287,29 @@ __global__ __launch_bounds__(256) void k_project_bwd(
                 acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
                 acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z; acc[11] += cq.w;
             }
-        } else
-        for (uint32_t k = sub; k < cnt && off + k < dcap * rows_per_dup; k += 4) {
-            const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * ROWF);
-            const float4 a = r[0], bq = r[1], cq = r[2];
-            if (MODE == 2) acc[12] += r[3].x;
-            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-            acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
-            acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z; acc[11] += cq.w;
+        } else {
+            // rows sub, sub + 4, ...: two rows in flight per lane, added in the same order as one at a time
+            const uint32_t room = dcap * rows_per_dup, lim = off >= room ? 0u : min(cnt, room - off);
+            auto add_row = [&](const float4 &a, const float4 &bq, const float4 &cq, float extra) {
+                if (MODE == 2) acc[12] += extra;
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
+                acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z; acc[11] += cq.w;
+            };
+            uint32_t k = sub;
+            for (; k + 4 < lim; k += 8) {
+                const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * ROWF);
+                const float4 *r2 = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k + 4) * ROWF);
+                const float4 a = r[0], bq = r[1], cq = r[2], a2 = r2[0], bq2 = r2[1], cq2 = r2[2];
+                const float e = MODE == 2 ? r[3].x : 0.0f, e2 = MODE == 2 ? r2[3].x : 0.0f;
+                add_row(a, bq, cq, e);
+                add_row(a2, bq2, cq2, e2);
+            }
+            if (k < lim) {
+                const float4 *r = reinterpret_cast<const float4 *>(grad_rows + (size_t)(off + k) * ROWF);
+                const float4 a = r[0], bq = r[1], cq = r[2];
+                add_row(a, bq, cq, MODE == 2 ? r[3].x : 0.0f);
+            }
         }
     }
     if constexpr (!PRESUM) {
