@@ -23,14 +23,24 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# numpy / torch are imported by _import_compute(), AFTER the launcher decision in main(): the parent of a --gpus N > 1
+# run must start its N ranks before anything in this process can have touched a GPU.
+np = torch = None
+
+
+def _import_compute():
+    global np, torch
+    import numpy
+    import torch as _torch
+    np, torch = numpy, _torch
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (packed / dual-issue rate)
@@ -161,7 +171,63 @@ def cpu_baseline_leg(leaves, gI, gD, N, S, budget_s=8.0):
             "host_cpus_visible": os.cpu_count(), "note": "baseline, not the target (see roofline.frac)"}
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _visible_gpus():
+    """Number of GPUs a rank would see, counted in a CHILD process so that this one stays clean of any GPU state."""
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                       capture_output=True, text=True)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves -- one process
+    per GPU under torch.distributed.run, rendezvous on 127.0.0.1 -- relay their output (rank 0 prints the JSON line)
+    and exit with their status.  Nothing in THIS process has imported torch or touched a GPU.  Never falls back to
+    fewer ranks: too few devices is an error, not an n_gpus: 1 measurement."""
+    if args.backend == "nccl" and not args.rendezvous_only:
+        have = _visible_gpus()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to measure "
+                             f"fewer ranks than asked for\n")
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank job failed (exit status {rc}); no result line\n")
+    return rc
+
+
+def rendezvous_only(args, world, rank):
+    """Launcher / rendezvous rehearsal without a GPU (tests/test_bench_launch.py): the ranks form the process group,
+    run the same collectives the timed region uses on CPU tensors, rank 0 prints what it saw."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    ranks = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo",
+                          "rank_sum": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -179,17 +245,34 @@ def main():
                          "the default leaves every choice to the library)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a 1-GPU box")
-    args = ap.parse_args()
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="rehearse launcher + rendezvous + collectives on CPU tensors (gloo), no GPU work, no bench line")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # ---- launcher decision: BEFORE torch / fresnel_amd are imported or any GPU call is made ----
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args, argv))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    _import_compute()
+    if args.rendezvous_only:
+        return rendezvous_only(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU fallback)")
-    local_rank = local_rank % torch.cuda.device_count()  # (rehearsal: several ranks may share one GPU)
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > 1 and n_dev < world:
+        raise SystemExit(f"rank {rank}: {world} RCCL ranks but only {n_dev} GPU(s) visible (one process per GPU; "
+                         f"--backend gloo rehearses several ranks on one GPU)")
+    local_rank = local_rank % n_dev  # (gloo rehearsal only: several ranks may share one GPU)
+    torch.cuda.set_device(local_rank)  # pin the rank to its GPU before the process group exists
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
@@ -198,6 +281,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)  # nccl IS RCCL on ROCm
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from fresnel_amd import _binding as B
     from fresnel_amd import renderer as R
@@ -298,11 +383,14 @@ def main():
     B.stage_timing_enable(False)
 
     tot = torch.tensor([elapsed, float(pairs_local)], dtype=torch.float64, device=device)
+    rank_ms = [elapsed / args.steps * 1e3] * 2  # [min, max] over ranks of each rank's own clock
     if dist is not None:
-        tmax = tot[:1].clone()
+        tmax, tmin = tot[:1].clone(), tot[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         psum = tot[1:].clone()
         dist.all_reduce(psum, op=dist.ReduceOp.SUM)
+        rank_ms = [float(tmin.item()) / args.steps * 1e3, float(tmax.item()) / args.steps * 1e3]
         elapsed, pairs_all = float(tmax.item()), float(psum.item())
     else:
         pairs_all = float(pairs_local)
@@ -387,6 +475,8 @@ def main():
             "metric": "composited Gaussian-pixels/sec + train-step ms, 512^2 render",
             "value": value, "unit": "Gaussian-pixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "rccl_ranks": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None,
+            "ms_per_step_rank_min": rank_ms[0], "ms_per_step_rank_max": rank_ms[1],
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE {args.workload}: {N} Gaussians, {S}x{S}, {per_gpu} images/GPU "
                                    f"({per_gpu * world} global), {dist_name}, rasterizer fwd+bwd through the nn.Module call"

@@ -25,6 +25,7 @@ NO_SLP = ["-fno-slp-vectorize"]
 # per-file extra flags.  fgs_project.hip carries the "canonical fp32" contract: no FMA
 # contraction, IEEE divide/sqrt, so integer decisions match the CPU oracle bit for bit.
 SOURCES = {
+    "fgs_plan.cpp": ["-x", "c++"],  # host-only plan / layout arithmetic (also built by g++ under ASan/UBSan in tests/)
     "fgs_api.hip": [],
     "fgs_project.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "fgs_sort.hip": [],
@@ -66,11 +67,12 @@ def build(force=False, verbose=False, defines=(), suffix=""):
         src = os.path.join(CSRC, name)
         if not os.path.exists(src):
             continue
-        obj = os.path.join(OBJ_DIR, name.replace(".hip", ".o"))
+        obj = os.path.join(OBJ_DIR, os.path.splitext(name)[0] + ".o")
         if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_time:
             # experiment builds: FGS_BUILD_EXTRA_<FILE STEM> = extra compiler flags for one file (e.g. scheduler options)
             more = os.environ.get("FGS_BUILD_EXTRA_" + name.split(".")[0].upper(), "").split()
-            cmd = [hipcc] + COMMON + extra + more + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
+            common = COMMON if name.endswith(".hip") else [c for c in COMMON if "offload" not in c and "gpu-rdc" not in c]
+            cmd = [hipcc] + common + extra + more + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

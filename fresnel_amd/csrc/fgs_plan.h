@@ -1,0 +1,55 @@
+// Plan / layout arithmetic of libfgs_hip.so: every buffer offset, capacity and work-split choice as a pure function of
+// FgsDims.  HOST-ONLY C++ with no HIP include, so that the same translation unit (fgs_plan.cpp) is also compiled by g++
+// under AddressSanitizer / UBSan on the CPU (tests/test_sanitizers.py; GPU sanitizers are not available on the pool).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/fgs.h"
+
+#define FGS_REC_FLOATS 12
+#define FGS_WAVE 64
+
+// record field indices (saved.rec)
+// gradient-row field indices (scratch.grows): one 12-float row per (tile, Gaussian) duplicate
+enum { G_U = 0, G_V, G_CA, G_CBC, G_CD, G_OP, G_CR, G_CG, G_CB, G_DEPTH, G_PHASE, G_PAD1 };
+#define FGS_GROW_FLOATS 12
+#define FGS_BLEND_ROW_FLOATS 10  /* gradient rows of the (non-phase) blend backward: exactly its ten sums */
+#define FGS_BIN_G 256  /* depth ranks per block of the direct binning (fgs_bin.hip) */
+enum { R_U = 0, R_V, R_CA, R_CBC, R_CD, R_OP, R_CR, R_CG, R_CB, R_DEPTH, R_BBX, R_BBY };
+
+struct FgsPlan {
+    FgsDims d;
+    FgsSavedLayout L;
+    int32_t layers;           // independent tile grids per image (ASM depth planes; 1 for TBR)
+    size_t s_layer;           // saved: uint32 [B][N] layer of each Gaussian (layers > 1 only)
+    int32_t tile_w;           // tile width in pixels: 16, or 32 on the blend path (FgsDims.tile_w / automatic)
+    int32_t tiles;            // tiles per image
+    int32_t tiles_per_gauss;  // worst-case tiles touched by one Gaussian
+    uint32_t tile_key_bits;   // bits of (image*T + tile)
+    // resolved tuning (FgsDims.seg_len / fwd_variant / bin_mode with FGS_TUNE_AUTO replaced by the choice)
+    int32_t fwd_parts;        // list parts of the depth-split forward; 0 = the row-split forward (k_composite_fwd)
+    int32_t fwd_waves;        // waves per tile of the row-split forward (also the phase path)
+    int32_t fwd_variant;      // the same choice in FgsDims.fwd_variant encoding (recorded in saved.counters[5])
+    bool direct_binning;      // counting sort straight from the bboxes instead of emit + radix sort
+    // scratch layout (bytes)
+    size_t s_total;
+    size_t s_keys0, s_keys1;  // uint32 [max(B*N, Dcap)] radix ping/pong keys
+    size_t s_vals0, s_vals1;  // uint32 [max(B*N, Dcap)] radix ping/pong payloads (vals of the final pass land in saved.dup_ids)
+    size_t s_hist;            // uint32 radix histograms
+    size_t s_bsum;            // uint32 block sums for the duplicate-offset scan
+    size_t s_grows;           // float [Dcap][12]: per-duplicate gradient rows (composite bwd -> reduce)
+    size_t s_plane;           // uint32 [B][layers + 1]: first depth rank of every layer (layered direct binning)
+    size_t s_rsum;            // float [B*N][12]: per-Gaussian totals of the blend path's rows (k_row_sum -> k_project_bwd)
+};
+
+// `segment_ckpt`: reserve the per-segment forward checkpoints of the tile-based compositing path (the splat
+// renderers cut their lists into the same depth segments but carry no state between them)
+int fgs_make_plan(const FgsDims *dims, FgsPlan *plan, int layers = 1, bool segment_ckpt = true);
+void fgs_set_error(const char *fmt, ...);
+
+#define FGS_BIN_MAX_TILES 4096  /* direct binning: tiles per image */
+#define FGS_MASK_MAX_LINES 512  /* mask binning: tile columns + tile rows per image (LDS of k_mask_build: 16 KB) */
+/* 64-bit rank words per mask line of the mask binning (fgs_bin.hip), padded to a multiple of 8 */
+static inline uint32_t fgs_mask_words(uint32_t n) { return (((n + 63u) / 64u) + 7u) & ~7u; }
+size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs);
+uint32_t fgs_radix_blocks_per_seg(uint32_t seg_capacity, uint32_t num_segs);

@@ -223,17 +223,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
     }
 }
 
-uint32_t blocks_per_seg(uint32_t seg_capacity, uint32_t num_segs) {
-    // <= 1024 blocks per segment, >= 1024 keys per block (measured on the 6.9 M-key tile sort: 256 / 512 / 1024 /
-    // 2048 / 4096 blocks -> 0.217 / 0.160 / 0.148 / 0.166 / 0.198 ms)
-    uint32_t bps = (seg_capacity + 1023) / 1024;
-    uint32_t cap = 1024;
-    if (num_segs > 1) cap = 64;
-    if (bps > cap) bps = cap;
-    if (bps < 1) bps = 1;
-    return bps;
-}
-
 uint32_t dmask_of(uint32_t p, uint32_t width, uint32_t key_bits) {
     const uint32_t left = key_bits - p * width;
     return (1u << (left < width ? left : width)) - 1u;
@@ -241,17 +230,12 @@ uint32_t dmask_of(uint32_t p, uint32_t width, uint32_t key_bits) {
 
 }  // namespace
 
-size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs) {
-    const size_t bps = blocks_per_seg(seg_capacity, num_segs);
-    return ((size_t)num_segs * 256 * bps + (size_t)num_segs * 256) * sizeof(uint32_t);
-}
-
 int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_alt, uint32_t *vals_alt,
                           uint32_t *vals_final, uint32_t **keys_sorted, uint32_t **vals_sorted,
                           uint32_t seg_len, const uint32_t *seg_len_dev, uint32_t seg_capacity,
                           uint32_t seg_stride, uint32_t num_segs, uint32_t key_bits, uint32_t *hist,
                           hipStream_t st, const uint32_t *keys_first, uint32_t index_payload_mod) {
-    const uint32_t bps = blocks_per_seg(seg_capacity, num_segs);
+    const uint32_t bps = fgs_radix_blocks_per_seg(seg_capacity, num_segs);
     uint32_t *dtot = hist + (size_t)num_segs * 256 * bps;
     const uint32_t passes = (key_bits + 7) / 8;
     // equal digit widths over the passes (13 key bits -> 7 + 6, not 8 + 5): fewer bins per pass means longer

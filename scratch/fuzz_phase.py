@@ -5,21 +5,13 @@ from helpers import rel_to_max, synth_aniso
 from oracle import fgs_oracle as orc
 from fresnel_amd.renderer import Camera, TileBasedRenderer
 dev = torch.device('cuda:0')
-rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+from fuzz_cases import phase_cases
 worst = 0.0
-for it in range(24):
-    W, H = int(rs.randint(5, 160)), int(rs.randint(5, 120))
-    N = int(rs.choice([1, 17, 64, 65, 200, 900, 2000]))
-    amp = float(rs.choice([0.1, 0.25, 0.45]))  # < 0.5: the interference factor stays positive (no clamp kink at 0)
-    arrs = list(synth_aniso(N, int(rs.randint(1 << 30)), opacity_max=float(rs.choice([0.5, 1.0, 1.3])), smax=float(rs.choice([0.03, 0.1, 0.3]))))
-    if rs.rand() < 0.5:  # zone-quantised depths (config 4)
-        arrs[0][:, 2] = -2.0 - 2.0 * (np.floor(rs.rand(N) * 8) + 0.5) / 8
-    phases = rs.rand(N).astype(np.float32)
-    bg = tuple(float(x) for x in rs.rand(3))
+for c in phase_cases(int(sys.argv[1]) if len(sys.argv) > 1 else 0):
+    it, W, H, N, amp, arrs, phases, bg, gI, gD = (c[k] for k in ("it", "W", "H", "N", "amp", "arrs", "phases", "bg", "gI", "gD"))
     cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
     ocam = orc.make_camera(np.eye(4, dtype=np.float32), cam.fx, cam.fy, cam.cx, cam.cy, W, H)
     r = orc.render(*arrs, ocam, bg=bg, phases=phases, phase_amp=amp)
-    gI = rs.standard_normal((3, H, W)).astype(np.float32); gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
     go = orc.render_backward(r, gI, gD)
     ts = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in arrs]
     ph = torch.from_numpy(phases).to(dev).requires_grad_(True)

@@ -72,3 +72,32 @@ def synth_decoder_like(N, seed):
     color = rs.random_sample((M, 3)).astype(np.float32)
     opacity = (0.4 + 0.2 * rs.random_sample(M)).astype(np.float32)
     return pos, scale, quat, color, opacity
+
+
+def upstream_grads(seed, H, W):
+    """Upstream gradients of the fixtures (tests/golden/make_goldens.py upstream()): gI ~ N(0,1), gD ~ N(0,0.01) from
+    numpy's frozen legacy RandomState, regenerated bit-exactly from the stored seed."""
+    rs = np.random.RandomState(seed)
+    gI = rs.standard_normal((3, H, W)).astype(np.float32)
+    gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
+    return gI, gD
+
+
+def referee(ref32, ref64):
+    """Which reference run referees a tensor, and with what tolerance (fixtures G14 / K1-K4 hold the reference's result
+    in fp32 AND in fp64).  spread = distance of the reference's own fp32 result from its fp64 one, relative to max.
+      * spread <= 5e-5: fp32 arithmetic is adequate here -> the usual statement, 1e-4 of max against the fp32 reference;
+      * otherwise the reference's fp32 result is itself not a 1e-4 answer (needles, kinks of the phase recurrence,
+        strongly interfering ASM scenes) -> the fp64 run is the referee and the result must be no further from it than
+        twice the reference's own fp32 run is (two independent fp32 evaluations; at least 1e-4)."""
+    spread = rel_to_max(ref32, ref64)
+    if spread <= 5e-5:
+        return np.asarray(ref32), 1e-4, spread
+    return np.asarray(ref64), max(1e-4, 2.0 * spread), spread
+
+
+def assert_with_referee(x, ref32, ref64, what):
+    ref, tol, spread = referee(ref32, ref64)
+    err = rel_to_max(x, ref)
+    assert err <= tol, f"{what}: {err:.2e} > {tol:.2e} (reference fp32-vs-fp64 spread {spread:.1e})"
+    return err

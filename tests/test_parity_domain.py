@@ -1,0 +1,177 @@
+"""The parity DOMAIN: reference-generated fixtures beyond toy size and inside the regimes the
+randomized sweeps flagged, each checked on the CPU (oracle) and on the GPU (HIP through the C ABI).
+
+  G13  1024 Gaussians @ 256^2, 785 at the 64-px radius cap, 240 composited entries per pixel, tile lists of ~5 depth
+       segments: image / depth rows and all gradients from the reference itself (DR:412-686 + autograd).
+  G14  needles and discs at scale ratios 30:1, 100:1, 500:1: the reference in fp32 AND fp64.  Its fp32 autograd is
+       6.7e-4 (30:1) ... >100 % (100:1 and up) away from its fp64 autograd on positions / scales / rotations, so the
+       fp64 run referees those tensors (helpers.referee): this is what decides that the projection adjoint is evaluated
+       in double (fgs_project.hip k_project_bwd, oracle fgs_or_project_bwd) -- the double adjoint lands 1e-5 ... 1e-4
+       from fp64 where the reference's fp32 lands 1e-3 ... 1e+2.
+  K1-K4 the four sweep cases above 1e-4 (phase-recurrence kinks, strongly interfering ASM scenes), replayed from their
+       (seed, iteration) with the reference-derived referee in fp32 and fp64.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (assert_with_referee, load_golden, oracle_camera, referee, rel_to_max, upstream_grads)
+
+NAMES = ["positions", "scales", "rotations", "colors", "opacities"]
+G14 = ["G14_needles_r30_96", "G14_needles_r100_96", "G14_needles_r500_96"]
+K_PHASE = ["K1_phase_kink_s2_it12", "K2_phase_kink_s1_it23"]
+K_ASM = ["K3_asm_kink_s3_it10", "K4_asm_kink_s5_it8"]
+
+
+def _arrs(g):
+    return [g[k] for k in NAMES]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU: the oracle against the new fixtures
+# ------------------------------------------------------------------------------------------------------------------
+def _oracle_run(g, gI, gD, phases=None, amp=0.25):
+    from oracle import fgs_oracle as orc
+    r = orc.render(*_arrs(g), oracle_camera(g), bg=g["background"], phases=phases, phase_amp=amp)
+    return r, orc.render_backward(r, gI, gD)
+
+
+def _check_ints(r, g):
+    vis = g["visible"].astype(bool)
+    assert np.array_equal(r.proj["visible"], g["visible"])
+    assert np.array_equal(r.proj["bbox"][vis], g["bbox"][vis])
+    assert np.array_equal(g["depth_order"][vis[g["depth_order"]]], r.vis_sorted)
+
+
+def test_oracle_vs_g13_midsize():
+    g = load_golden("G13_midsize1024_256")
+    W, H = [int(v) for v in g["size"]]
+    r, gr = _oracle_run(g, *upstream_grads(int(g["seed_up"]), H, W))
+    _check_ints(r, g)
+    assert r.P == int(g["pairs"]) and r.P / (W * H) > 200          # long accumulation chains
+    assert (g["radii"][g["visible"].astype(bool)] >= 64).sum() > 500  # radius cap active
+    rows = g["rows"]
+    assert np.abs(r.image[:, rows] - g["image"]).max() <= 1e-5
+    assert np.abs(r.depth[rows] - g["depth"]).max() <= 1e-5
+    for k in NAMES:
+        assert rel_to_max(gr[k], g["grad_" + k]) <= 1e-4, k
+
+
+@pytest.mark.parametrize("case", G14)
+def test_oracle_vs_g14_needles(case):
+    g = load_golden(case)
+    assert int(g["f64_same_integer_stages"]) == 1
+    W, H = [int(v) for v in g["size"]]
+    r, gr = _oracle_run(g, *upstream_grads(int(g["seed_up"]), H, W))
+    _check_ints(r, g)
+    assert_with_referee(r.image, g["image"], g["f64_image"], "image")
+    assert_with_referee(r.depth, g["depth"], g["f64_depth"], "depth")
+    for k in NAMES:
+        assert_with_referee(gr[k], g["grad_" + k], g["f64_grad_" + k], k)
+
+
+def test_g14_settles_the_projection_adjoint_contract():
+    """The evidence itself: at 30:1 the reference's fp32 autograd already misses 1e-4 of its own fp64 result on the
+    geometry gradients, at 100:1 it is off by 100 % -- so 'within 1e-4 of the reference' can only mean the fp64 run
+    there, and an adjoint evaluated in double is the implementation that meets it."""
+    g30, g100 = load_golden(G14[0]), load_golden(G14[1])
+    assert rel_to_max(g30["grad_rotations"], g30["f64_grad_rotations"]) > 1e-3
+    assert rel_to_max(g100["grad_positions"], g100["f64_grad_positions"]) > 0.5
+    for k in ("colors", "opacities"):  # what does not pass through the covariance inverse stays well-conditioned
+        assert rel_to_max(g100["grad_" + k], g100["f64_grad_" + k]) <= 1e-4
+
+
+@pytest.mark.parametrize("case", K_PHASE)
+def test_oracle_vs_phase_kink_cases(case):
+    g = load_golden(case)
+    r, gr = _oracle_run(g, g["gI"], g["gD"], phases=g["phases"], amp=float(g["phase_amplitude"]))
+    _check_ints(r, g)
+    assert_with_referee(r.image, g["image"], g["f64_image"], "image")
+    assert_with_referee(r.depth, g["depth"], g["f64_depth"], "depth")
+    for k in NAMES + ["phases"]:
+        assert_with_referee(gr[k], g["f32_grad_" + k], g["f64_grad_" + k], k)
+
+
+def _asm_kwargs(g):
+    return dict(bg=tuple(float(b) for b in g["background"]), num_planes=int(g["num_depth_planes"]),
+                depth_range=tuple(float(v) for v in g["depth_range"]), focal_depth=float(g["focal_depth"]),
+                pixel_pitch=float(g["pixel_pitch"]))
+
+
+@pytest.mark.parametrize("case", K_ASM)
+def test_asm_oracle_vs_asm_kink_cases(case):
+    from oracle import asm_oracle
+    g = load_golden(case)
+    r = asm_oracle.render(*_arrs(g), g["phases"], g["wavelengths"], oracle_camera(g), grad_out=g["gI"], **_asm_kwargs(g))
+    assert_with_referee(r["image"], g["f32_image"], g["f64_image"], "image")
+    for k in NAMES + ["phases"]:
+        if k == "phases" and len(g["positions"]) == 1:
+            continue  # one Gaussian: its phase is a global phase, the true gradient is 0 (noise / noise)
+        assert_with_referee(r["grad_" + k], g["f32_grad_" + k], g["f64_grad_" + k], k)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path against the same fixtures
+# ------------------------------------------------------------------------------------------------------------------
+def _hip(g, gI, gD, W, H, phases=None, use_phase=False, amp=0.25, tuning=None):
+    from test_hip_parity import _camera_from_golden, _hip_render
+    return _hip_render(_arrs(g), _camera_from_golden(g), W, H, g["background"], phases=phases, use_phase=use_phase, amp=amp,
+                       grads=(gI, gD), tuning=tuning)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_w", [16, 32])
+def test_hip_vs_g13_midsize(tile_w):
+    from test_hip_parity import _camera_from_golden, _check_integer_stages, _hip_stages, _oracle
+    g = load_golden("G13_midsize1024_256")
+    W, H = [int(v) for v in g["size"]]
+    out = _hip(g, *upstream_grads(int(g["seed_up"]), H, W), W, H, tuning=dict(tile_w=tile_w))
+    rows = g["rows"]
+    assert np.abs(out["image"][:, rows] - g["image"]).max() <= 1e-4
+    assert rel_to_max(out["depth"][rows], g["depth"]) <= 1e-4
+    for k in NAMES:
+        assert rel_to_max(out["grad_" + k], g["grad_" + k]) <= 1e-4, k
+    st = _hip_stages([a[None] for a in _arrs(g)], _camera_from_golden(g), W, H, g["background"], tuning=dict(tile_w=tile_w))
+    _check_integer_stages(st, 0, _oracle(_arrs(g), oracle_camera(g), g["background"]), W, H)
+    units = int(st["counters"][2])
+    assert units >= 4 * st["ranges"].shape[1] * 0.9, "G13 is meant to give every tile several depth segments"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G14)
+def test_hip_vs_g14_needles(case):
+    g = load_golden(case)
+    W, H = [int(v) for v in g["size"]]
+    out = _hip(g, *upstream_grads(int(g["seed_up"]), H, W), W, H)
+    assert_with_referee(out["image"], g["image"], g["f64_image"], "image")
+    assert_with_referee(out["depth"], g["depth"], g["f64_depth"], "depth")
+    for k in NAMES:
+        assert_with_referee(out["grad_" + k], g["grad_" + k], g["f64_grad_" + k], k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", K_PHASE)
+def test_hip_vs_phase_kink_cases(case):
+    g = load_golden(case)
+    W, H = [int(v) for v in g["size"]]
+    out = _hip(g, g["gI"], g["gD"], W, H, phases=g["phases"], use_phase=True, amp=float(g["phase_amplitude"]))
+    assert_with_referee(out["image"], g["image"], g["f64_image"], "image")
+    assert_with_referee(out["depth"], g["depth"], g["f64_depth"], "depth")
+    for k in NAMES + ["phases"]:
+        assert_with_referee(out["grad_" + k], g["f32_grad_" + k], g["f64_grad_" + k], k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", K_ASM)
+def test_hip_vs_asm_kink_cases(case):
+    from test_hip_asm import _cam, _hip_asm
+    g = load_golden(case)
+    W, H = [int(v) for v in g["size"]]
+    out = _hip_asm(_arrs(g), g["phases"], g["wavelengths"], _cam(g), W, H, g["background"], gI=g["gI"],
+                   num_depth_planes=int(g["num_depth_planes"]), depth_range=tuple(float(v) for v in g["depth_range"]),
+                   focal_depth=float(g["focal_depth"]), pixel_pitch=float(g["pixel_pitch"]))
+    assert_with_referee(out["image"], g["f32_image"], g["f64_image"], "image")
+    for k in NAMES + ["phases"]:
+        if k == "phases" and len(g["positions"]) == 1:
+            continue
+        assert_with_referee(out["grad_" + k], g["f32_grad_" + k], g["f64_grad_" + k], k)
