@@ -59,6 +59,12 @@ class ImageDataset:
                         saag_colors=torch.zeros(0, 3), saag_opacities=torch.zeros(0))
         return item
 
+    def host_item(self, idx: int):
+        """(image (3,S,S), features (37,37,C) patch-major as the decoder takes them, depth (1,S,S)) on the host: what the
+        training loop's prefetch threads load ahead of the step (fresnel_amd/train.py BatchPrefetcher)."""
+        it = self[idx]
+        return it["image"], it["features"].permute(1, 2, 0).contiguous(), it["depth"]
+
     def batch(self, indices, device):
         """(images (B,3,S,S), features (B,37,37,C) patch-major as the decoder takes them, depth (B,1,S,S))."""
         items = [self[i] for i in indices]

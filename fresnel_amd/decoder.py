@@ -68,6 +68,8 @@ class PatchGaussianDecoder(nn.Module):
         self.mlp = nn.Sequential(*layers)
         ys, xs = torch.meshgrid(torch.linspace(-1, 1, grid), torch.linspace(-1, 1, grid), indexing="ij")
         self.register_buffer("grid_xy", torch.stack([xs, -ys], -1).reshape(grid * grid, 2))
+        # identity-quaternion bias; a buffer so that the forward makes no host-to-device copy (not part of checkpoints)
+        self.register_buffer("quat_bias", torch.tensor([1.0, 0.0, 0.0, 0.0]), persistent=False)
 
     def forward(self, features: torch.Tensor, depth: torch.Tensor, num_gaussians=None, elevation=None, azimuth=None, **_):
         """features (B,grid,grid,C) ; depth (B,1,h,w) in [0,1].
@@ -101,7 +103,7 @@ class PatchGaussianDecoder(nn.Module):
         out = {
             "positions": positions.reshape(Bn, G * G * K, 3),
             "scales": scales.reshape(Bn, G * G * K, 3),
-            "rotations": F.normalize(o[..., 6:10] + torch.tensor([1.0, 0, 0, 0], device=o.device), dim=-1
+            "rotations": F.normalize(o[..., 6:10] + self.quat_bias, dim=-1
                                      ).reshape(Bn, G * G * K, 4),
             "colors": torch.sigmoid(o[..., 10:13]).reshape(Bn, G * G * K, 3),
             "opacities": opacities.reshape(Bn, G * G * K),

@@ -51,12 +51,15 @@ class DPContext:
             for p in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(p.data, src=0)
 
-    def allreduce_gradients(self, params):
-        """Average gradients over ranks through one flat fp32 bucket."""
+    def allreduce_gradients(self, params, extra: torch.Tensor = None):
+        """Average gradients over ranks through ONE flat fp32 bucket (one collective per step).  `extra`: a small 1-D
+        tensor of per-rank scalars (the NaN/Inf flag, the loss) that rides at the end of the same bucket and comes
+        back SUMMED over the ranks -- so the step needs no second collective and no host round trip for them."""
         if not self.enabled:
-            return
+            return extra
         params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in params)
+        ne = 0 if extra is None else extra.numel()
+        n = sum(p.numel() for p in params) + ne
         if self._bucket is None or self._bucket.numel() != n or self._bucket.device != params[0].device:
             self._bucket = torch.zeros(n, dtype=torch.float32, device=params[0].device)
         off = 0
@@ -67,18 +70,24 @@ class DPContext:
             else:
                 self._bucket[off:off + k].copy_(p.grad.reshape(-1))
             off += k
+        if ne:
+            self._bucket[off:].copy_(extra.reshape(-1).float())
         dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
-        self._bucket.div_(self.world)
+        out_extra = self._bucket[off:].clone() if ne else None
+        grads = self._bucket[:off]
+        grads.div_(self.world)
         off = 0
         for p in params:
             k = p.numel()
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-            p.grad.copy_(self._bucket[off:off + k].view_as(p))
+            p.grad.copy_(grads[off:off + k].view_as(p))
             off += k
+        return out_extra
 
     def any_true(self, flag: bool, device) -> bool:
-        """Collective OR (the NaN/Inf batch skip of TGD:1255-1258 must be taken by all ranks)."""
+        """Collective OR, as a HOST bool (one device sync).  The training step does not use it: its NaN/Inf flag rides
+        in the gradient bucket (allreduce_gradients(extra=...)) and stays on the device."""
         if not self.enabled:
             return bool(flag)
         t = torch.tensor([1.0 if flag else 0.0], device=device)

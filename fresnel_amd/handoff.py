@@ -82,7 +82,9 @@ class _GatherGaussians(torch.autograd.Function):
         Bn, N, K = pos.shape[0], pos.shape[1], indices.shape[0]
         ins = [t.detach().contiguous().float() for t in (pos, scale, quat, color, opacity)]
         ph = phase.detach().contiguous().float() if phase is not None else None
-        pc = 0 if ph is None else (3 if ph.dim() == 3 else 1)
+        if ph is not None and not (ph.dim() == 2 or (ph.dim() == 3 and ph.shape[2] in (1, 3))):
+            raise ValueError(f"phases must be (B,N) or (B,N,3), got {tuple(ph.shape)}")
+        pc = 0 if ph is None else (int(ph.shape[2]) if ph.dim() == 3 else 1)  # floats per Gaussian the kernel moves
         idx = indices.detach().to(torch.int64).contiguous()
         dev = pos.device
         with torch.cuda.device(dev):

@@ -43,6 +43,7 @@ class Camera:
     def set_view(self, view_matrix: torch.Tensor):
         """Set view matrix (world-to-camera transform), DR:50-52."""
         self.view_matrix = view_matrix
+        self._packed = None
 
     def project(self, points_3d: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Project (N,3) world points to pixel coordinates + depths (DR:54-86); torch ops."""
@@ -72,9 +73,14 @@ class Camera:
         camera is enough."""
         vm = self.view_matrix
         key = (str(device), float(self.fx), float(self.fy), float(self.cx), float(self.cy), float(self.near),
-               float(self.far), id(vm), vm._version)
-        if self._packed is None or self._packed[0] != key:
-            self._packed = (key, torch.tensor([self.packed()], dtype=torch.float32, device=device))
+               float(self.far), vm._version)
+        # the cache entry holds the matrix OBJECT it was built from (compared with `is`: an id() alone can be reused
+        # by a later tensor once this one is freed) and a copy of its 16 values (catches edits through .data, which
+        # leave _version unchanged; view matrices live on the host, so this costs no device sync)
+        c = self._packed
+        if c is None or c[0] != key or c[2] is not vm or (not vm.is_cuda and not torch.equal(c[3], vm)):
+            self._packed = (key, torch.tensor([self.packed()], dtype=torch.float32, device=device), vm,
+                            vm.detach().clone() if not vm.is_cuda else None)
         return self._packed[1]
 
 
@@ -110,6 +116,17 @@ def pack_cameras(cameras: Union[Camera, Sequence[Camera]], device) -> torch.Tens
     return torch.tensor([c.packed() for c in cameras], dtype=torch.float32, device=device)
 
 
+def _phase_channels(ph: torch.Tensor) -> int:
+    """Phases are (B,N) -- one per Gaussian -- or (B,N,3) per colour channel (DR:772-776, DR:1170-1176); the kernels
+    read exactly that many floats per Gaussian, so anything else is refused here (a (B,N,1) tensor is NOT three
+    channels)."""
+    if ph.dim() == 2:
+        return 1
+    if ph.dim() == 3 and ph.shape[2] in (1, 3):
+        return int(ph.shape[2])
+    raise ValueError(f"phases must be (N,) or (N,3) per image, got {tuple(ph.shape[1:])}")
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -122,7 +139,8 @@ class _Cfg:
     """Static (non-tensor) configuration of one renderer call."""
 
     def __init__(self, width, height, background, max_radius, use_phase, phase_amplitude, saturation_skip=False,
-                 tuning=None):
+                 tuning=None, pair_counter=None):
+        self.pair_counter = pair_counter  # optional device int64[1]: += composited Gaussian-pixels of every forward
         self.saturation_skip = bool(saturation_skip)
         self.tuning = dict(tuning) if tuning else None  # FgsDims.seg_len / fwd_variant / bin_mode overrides
         self.width, self.height = int(width), int(height)
@@ -176,6 +194,11 @@ class GaussianRenderer(torch.autograd.Function):
         out_rgb, out_depth, saved, dims, tensors = forward_raw(
             positions, scales, rotations, colors, opacities, phases, cam_tensor, cfg)
         pos, scl, rot, col, opa, ph = tensors
+        if getattr(cfg, "pair_counter", None) is not None:
+            # unit of work of SURVEY 8d, counted on the device and accumulated asynchronously (no host sync)
+            n = torch.empty(1, dtype=torch.int64, device=pos.device)
+            B.check(B.load().fgs_count_pairs(ctypes.byref(dims), _ptr(saved), _ptr(n), _stream_handle()), "fgs_count_pairs")
+            cfg.pair_counter += n
         ctx.dims = dims
         ctx.has_phase = ph is not None
         ctx.save_for_backward(pos, scl, rot, col, opa, ph if ph is not None else pos.new_empty(0),
@@ -208,7 +231,7 @@ class GaussianRenderer(torch.autograd.Function):
 
 def render_batch(positions, scales, rotations, colors, opacities, cameras, width, height,
                  background=(0.0, 0.0, 0.0), max_radius=64, phases=None, use_phase_blending=False,
-                 phase_amplitude=0.25, cam_tensor=None, saturation_skip=False, tuning=None):
+                 phase_amplitude=0.25, cam_tensor=None, saturation_skip=False, tuning=None, pair_counter=None):
     """Functional batched entry point: tensors are (B,N,.); cameras is one Camera (shared by
     the batch, as in the reference's training loop TGD:1209-1223) or a list of B Cameras.
     `saturation_skip` (off by default = the reference's behaviour, every list entry composited): stop
@@ -216,7 +239,7 @@ def render_batch(positions, scales, rotations, colors, opacities, cameras, width
     if cam_tensor is None:
         cam_tensor = pack_cameras(cameras, positions.device)
     cfg = _Cfg(width, height, background, max_radius, use_phase_blending and phases is not None,
-               phase_amplitude, saturation_skip, tuning)
+               phase_amplitude, saturation_skip, tuning, pair_counter)
     return GaussianRenderer.apply(positions, scales, rotations, colors, opacities, phases, cam_tensor, cfg)
 
 
@@ -237,6 +260,7 @@ class TileBasedRenderer(nn.Module):
         super().__init__()
         self.saturation_skip = saturation_skip  # extension, off by default (see render_batch)
         self.tuning = None  # optional FgsDims work-split overrides (tests / A-B runs); never changes results
+        self.pair_counter = None  # set to a device int64[1] tensor to accumulate composited Gaussian-pixels (metrics)
         self.width = image_width
         self.height = image_height
         self.background = torch.tensor(background)  # plain tensor, as in DR:447
@@ -259,7 +283,7 @@ class TileBasedRenderer(nn.Module):
             # DR:636-637); (N,3) phases make `phase - prev_phase` fail to broadcast there
             raise RuntimeError(
                 f"TileBasedRenderer phase blending expects phases of shape (N,), got {tuple(phases.shape[1:])}")
-        bg = tuple(float(b) for b in self.background.tolist())
+        bg = tuple(float(b) for b in self.background.tolist())  # a plain HOST tensor (DR:447): no device sync
         if positions.shape[1] == 0:
             # no Gaussians at all: the reference's zero-visible branch (DR:545-552) -- background, zero depth
             Bn, dev = positions.shape[0], positions.device
@@ -271,7 +295,7 @@ class TileBasedRenderer(nn.Module):
         img, depth = render_batch(positions, scales, rotations, colors, opacities, camera, self.width,
                                   self.height, bg, self.max_radius, phases if use_phase else None,
                                   use_phase, self.phase_amplitude, saturation_skip=self.saturation_skip,
-                                  tuning=self.tuning)
+                                  tuning=self.tuning, pair_counter=self.pair_counter)
         if not batched:
             img, depth = img[0], depth[0]
         if return_depth:
@@ -330,7 +354,7 @@ class AsmRenderer(torch.autograd.Function):
         d.num_planes = int(cfg["num_depth_planes"])
         d.depth_near, d.depth_far = float(cfg["depth_range"][0]), float(cfg["depth_range"][1])
         d.focal_depth, d.pixel_pitch = float(cfg["focal_depth"]), float(cfg["pixel_pitch"])
-        d.phase_channels = 3 if ph.dim() == 3 else 1
+        d.phase_channels = _phase_channels(ph)
         d.num_cameras = cam_tensor.shape[0]
         d.bin_mode = int(cfg.get("bin_mode", 0))  # FgsAsmDims.bin_mode: list-building override for A/B runs and tests
         sb, cb = ctypes.c_size_t(0), ctypes.c_size_t(0)
@@ -479,6 +503,7 @@ class ASMWaveFieldRenderer(nn.Module):
         self.focal_depth = focal_depth
         self.pixel_pitch = pixel_pitch
         self.wavelength = wavelength
+        self._bg = [float(b) for b in background]  # host copy: reading the registered buffer back would sync every call
         self.register_buffer("background", torch.tensor(background))
         self.register_buffer("depth_planes", torch.linspace(depth_range[0], depth_range[1], num_depth_planes))
         self.propagator = AngularSpectrumPropagator(image_height, image_width, pixel_pitch, wavelength)
@@ -494,7 +519,7 @@ class ASMWaveFieldRenderer(nn.Module):
         if wavelengths_rgb is None:
             wavelengths_rgb = torch.full((3,), float(self.wavelength), device=positions.device)
         cfg = dict(width=self.width, height=self.height, max_radius=self.max_radius,
-                   background=[float(b) for b in self.background.tolist()],
+                   background=self._bg,
                    num_depth_planes=self.num_depth_planes, depth_range=self.depth_range,
                    focal_depth=self.focal_depth, pixel_pitch=self.pixel_pitch,
                    bin_mode=int(getattr(self, "bin_mode", 0)))  # tests set ren.bin_mode = 2 for the radix path
@@ -530,7 +555,7 @@ class WaveRenderer(torch.autograd.Function):
         d.max_radius = float(cfg["max_radius"])
         for i in range(3):
             d.background[i] = float(cfg["background"][i])
-        d.phase_channels = 3 if ph.dim() == 3 else 1
+        d.phase_channels = _phase_channels(ph)
         d.num_cameras = cam_tensor.shape[0]
         sb, cb = ctypes.c_size_t(0), ctypes.c_size_t(0)
         with torch.cuda.device(dev):
@@ -575,6 +600,7 @@ class WaveFieldRenderer(nn.Module):
         super().__init__()
         self.width, self.height = image_width, image_height
         self.max_radius = max_radius
+        self._bg = [float(b) for b in background]
         self.register_buffer("background", torch.tensor(background))
 
     def forward(self, positions, scales, rotations, colors, opacities, camera, return_depth: bool = False,
@@ -585,8 +611,7 @@ class WaveFieldRenderer(nn.Module):
         if not batched:
             positions, scales, rotations = positions[None], scales[None], rotations[None]
             colors, opacities, phases = colors[None], opacities[None], phases[None]
-        cfg = dict(width=self.width, height=self.height, max_radius=self.max_radius,
-                   background=[float(b) for b in self.background.tolist()])
+        cfg = dict(width=self.width, height=self.height, max_radius=self.max_radius, background=self._bg)
         img, dep = WaveRenderer.apply(positions, scales, rotations, colors, opacities, phases,
                                       pack_cameras(camera, positions.device), cfg)
         if not batched:

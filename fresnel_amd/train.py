@@ -19,9 +19,19 @@ Kept from TGD (same flag names / defaults / behaviour):
                     those packages exist, as TGD:53-65) -> NaN/Inf skip -> backward ->
                     clip_grad_norm_(1.0) -> AdamW(lr, weight_decay=1e-5) ; CosineAnnealingLR
                                                                     TGD:890, 922-930, 1255-1266, 1970-1971
+  data order        a fresh permutation of the images every epoch (DataLoader(shuffle=True), TGD:1760-1767), drawn
+                    from seed + epoch so that every rank draws the same one; the last, partial batch is kept when it
+                    divides over the ranks; batches are decoded ahead of the step by worker processes / a prefetch thread
+                    into pinned memory
   checkpoints       {epoch, model_state_dict, optimizer_state_dict, losses, config}    TGD:1304-1310
+  metrics           print every log_interval batches (TGD:1275-1281); training_history_exp{E}.json (TGD:1317-1323) with
+                    the per-epoch losses plus step ms, composited Gaussian-pixels/s and the rasterizer's stage ms
 Changed on purpose:
   * the per-image Python loop TGD:1209-1223 becomes ONE batched renderer call;
+  * NO host synchronisation inside a step: loss terms stay on the device and are fetched once per log_interval; the
+    NaN/Inf batch skip (TGD:1255-1258) is decided on the device -- the flag rides in the gradient bucket's all-reduce
+    and the fused AdamW step takes it as `found_inf` (weights, moments and step count untouched, exactly a skipped
+    batch).  The reference syncs ~5 times per Gaussian (.item(), DR:584-597) plus once per loss term;
   * image-wise data parallelism: one process per GPU, the batch is sharded by image and the
     decoder gradients are all-reduced once per step over RCCL (fresnel_amd/dist.py);
   * no dataset preprocessing tooling (DINOv2 / depth extraction): caches are read when present; when --data_dir has
@@ -31,8 +41,13 @@ Changed on purpose:
     python -m torch.distributed.run --nproc-per-node 8 -m fresnel_amd.train    # 8 GPUs, DP
 """
 import argparse
+import inspect
+import json
 import math
 import os
+import queue
+import threading
+import time
 from dataclasses import asdict, dataclass
 from pathlib import Path
 from typing import Callable, Dict, Optional
@@ -97,6 +112,7 @@ class TrainingConfig:  # subset of TGD:97-162 that this path uses; same names an
     save_interval: int = 10
     seed: int = 0
     steps_per_epoch: int = 8  # synthetic-data mode only
+    num_workers: int = 4      # host threads decoding the NEXT batches (DataLoader(num_workers=4), TGD:1760-1767)
 
 
 class SyntheticDataset:
@@ -118,55 +134,118 @@ class SyntheticDataset:
         depth = F.interpolate(dlow[None], size=(S, S), mode="bilinear", align_corners=False)[0]
         return image, feats, depth
 
+    def __len__(self):
+        return self.n
+
+    def host_item(self, idx):
+        return self.get(idx)
+
     def batch(self, indices, device):
         items = [self.get(i) for i in indices]
         return tuple(torch.stack(t).to(device) for t in zip(*items))
 
 
+def epoch_batches(n_items: int, batch_size: int, world: int, seed: int, epoch: int):
+    """Global batches of one epoch as index lists: a fresh permutation per epoch (DataLoader(shuffle=True),
+    TGD:1760-1767) from a generator seeded with seed + epoch -- every rank draws the SAME permutation and takes its
+    shard of each batch.  The last, partial batch is kept, as the reference keeps it, when it divides over the ranks
+    (equal shards: the mean of shard means stays the global mean); otherwise it is dropped."""
+    perm = torch.randperm(n_items, generator=torch.Generator().manual_seed(seed + epoch)).tolist()
+    out = [perm[i:i + batch_size] for i in range(0, n_items - batch_size + 1, batch_size)]
+    tail = perm[len(out) * batch_size:]
+    if tail and len(tail) % world == 0:
+        out.append(tail)
+    return out
+
+
+class BatchPrefetcher:
+    """Iterates device batches for a list of index lists, decoding AHEAD of the training step: `num_workers` host
+    threads load items (PIL decode / LANCZOS resize / cache reads release the GIL), a producer thread stacks them into
+    pinned memory, at most `depth` batches wait in the queue, and the copy to the GPU is asynchronous.  The reference
+    gets the same overlap from DataLoader(num_workers=4, pin_memory=True) worker processes (TGD:1760-1767)."""
+
+    def __init__(self, data, index_lists, device, num_workers=4, depth=2):
+        self.data, self.lists, self.device = data, index_lists, torch.device(device)
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.pin = self.device.type == "cuda"
+        self.workers = max(1, int(num_workers))
+        self.thread = threading.Thread(target=self._produce, daemon=True)
+        self.thread.start()
+
+    def _produce(self):
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            with ThreadPoolExecutor(self.workers) as pool:
+                for idx in self.lists:
+                    items = list(pool.map(self.data.host_item, idx))
+                    batch = tuple(torch.stack(t) for t in zip(*items))
+                    if self.pin:
+                        batch = tuple(t.pin_memory() for t in batch)
+                    self.q.put(batch)
+            self.q.put(None)
+        except BaseException as e:  # surfaces in the consumer, not in a dead thread
+            self.q.put(e)
+
+    def __iter__(self):
+        while True:
+            b = self.q.get()
+            if b is None:
+                return
+            if isinstance(b, BaseException):
+                raise b
+            yield tuple(t.to(self.device, non_blocking=True) for t in b)
+
+
 def _global_mean_std(x, dp):
-    """mean and unbiased std (torch.std default, as TGD:922-925 uses) of x over the GLOBAL batch: the sums are
-    all-reduced differentiably, so an N-rank step normalises the depth loss exactly like the 1-rank step."""
-    n = x.numel() * (dp.world if dp is not None and dp.enabled else 1)
-    s1, s2 = x.sum(), (x * x).sum()
-    if dp is not None and dp.enabled:
-        s = dp.global_sum(torch.stack([s1, s2]))
-        s1, s2 = s[0], s[1]
+    """mean and unbiased std (torch.std default, as TGD:922-925 uses) of x over the GLOBAL batch, TWO-PASS like
+    torch.std: the sum is all-reduced for the mean, then the sum of squared deviations (the one-pass
+    sum x^2 - n mean^2 loses digits to cancellation for ~2 M depth values whose mean is far from zero).  Both
+    all-reduces are differentiable, so an N-rank step normalises the depth loss exactly like the 1-rank step."""
+    dist_on = dp is not None and dp.enabled
+    n = x.numel() * (dp.world if dist_on else 1)
+    s1 = x.sum()
+    if dist_on:
+        s1 = dp.global_sum(s1.reshape(1))[0]
     mean = s1 / n
-    var = (s2 - n * mean * mean) / max(n - 1, 1)
-    return mean, torch.sqrt(torch.clamp(var, min=0.0))
+    s2 = ((x - mean) ** 2).sum()
+    if dist_on:
+        s2 = dp.global_sum(s2.reshape(1))[0]
+    return mean, torch.sqrt(s2 / max(n - 1, 1))
 
 
 def compute_losses(rendered, target, rendered_depth, target_depth, cfg: TrainingConfig, dp=None):
-    """L1 + (1-SSIM if available) + normalised depth L1 (TGD:890, 906-930)."""
-    d: Dict[str, float] = {}
+    """L1 + (1-SSIM if available) + normalised depth L1 (TGD:890, 906-930).  Returns (total, terms): `terms` holds the
+    individual losses as DETACHED 0-d DEVICE tensors -- nothing here synchronises with the host (the reference's
+    `.item()` per term, TGD:891-1001, would cost a device round trip each)."""
+    d: Dict[str, torch.Tensor] = {}
     rgb = F.l1_loss(rendered, target)
-    d["rgb"] = float(rgb.detach())
+    d["rgb"] = rgb.detach()
     total = cfg.rgb_weight * rgb
     if SSIM_AVAILABLE and cfg.ssim_weight > 0:
         s = 1.0 - ssim_fn(torch.clamp(rendered, 0, 1), target, data_range=1.0, size_average=True)
-        d["ssim"] = float(s.detach())
+        d["ssim"] = s.detach()
         total = total + cfg.ssim_weight * s
     if rendered_depth is not None and target_depth is not None:
         rd_mean, rd_std = _global_mean_std(rendered_depth, dp)
         td_mean, td_std = _global_mean_std(target_depth, dp)
         dl = F.l1_loss((rendered_depth - rd_mean) / torch.clamp(rd_std, min=1e-4),
                        (target_depth - td_mean) / torch.clamp(td_std, min=1e-4))
-        d["depth"] = float(dl.detach())
+        d["depth"] = dl.detach()
         total = total + cfg.depth_weight * dl
     if cfg.wave_equation_weight > 0:  # TGD:957-964
         from .losses import wave_equation_loss
         we = wave_equation_loss(rendered, cfg.wavelength, pixel_spacing=1.0 / cfg.image_size)
-        d["wave_eq"] = float(we.detach())
+        d["wave_eq"] = we.detach()
         total = total + cfg.wave_equation_weight * we
     if cfg.use_phase_retrieval_loss and target_depth is not None:  # TGD:972-983
         pr = _loss_module("phase", cfg)(rendered, target, target_depth)
-        d["phase_retrieval"] = float(pr.detach())
+        d["phase_retrieval"] = pr.detach()
         total = total + cfg.phase_retrieval_weight * pr
     if cfg.use_frequency_loss:  # TGD:990-996
         fq = _loss_module("freq", cfg)(rendered, target)
-        d["frequency"] = float(fq.detach())
+        d["frequency"] = fq.detach()
         total = total + cfg.frequency_loss_weight * fq
-    d["total"] = float(total.detach())
+    d["total"] = total.detach()
     return total, d
 
 
@@ -196,10 +275,35 @@ def default_renderer_factory(cfg: TrainingConfig, device, res: Optional[int] = N
     return renderer, camera
 
 
+class StepResult:
+    """What one train_step leaves behind, all on the device: `terms` (name -> 0-d tensor, this rank's shard; "total"
+    is the mean over the ranks) and `skipped` (0-d float: 1.0 when the global batch was skipped for a NaN/Inf loss).
+    `to_host()` is the only place that synchronises."""
+
+    def __init__(self, terms, skipped):
+        self.terms, self.skipped = terms, skipped
+
+    def to_host(self):
+        keys = sorted(self.terms)
+        vals = torch.stack([self.terms[k].float() for k in keys] + [self.skipped.float()]).tolist()  # one transfer
+        if vals[-1] > 0:
+            return None
+        return dict(zip(keys, vals[:-1]))
+
+
+def make_optimizer(model, cfg: TrainingConfig):
+    """AdamW(lr, weight_decay) as TGD:1970, FUSED: one multi-tensor kernel per step, and it takes the skip flag as a
+    device tensor (`found_inf`, the mechanism GradScaler uses), so the NaN/Inf batch skip needs no host decision."""
+    try:
+        return AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay, fused=True)
+    except (RuntimeError, TypeError):  # a device without the fused kernel: plain AdamW, the skip costs one sync
+        return AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+
+
 def train_step(model, renderer, camera, batch, optimizer, cfg: TrainingConfig, dp: DPContext,
                hfts: Optional[HFTSConfig] = None, epoch: int = 0, train_res: Optional[int] = None,
                pose_rng: Optional[np.random.RandomState] = None, sample_gen: Optional[torch.Generator] = None):
-    """One optimizer step on this rank's image shard.  Returns (loss_dict | None if skipped)."""
+    """One optimizer step on this rank's image shard, without a host synchronisation.  Returns a StepResult."""
     images, feats, depth = batch
     res = train_res or cfg.image_size
     # progressive Gaussian growing (TGD:1069-1076) and the batch's pose (TGD:1078-1098)
@@ -223,18 +327,23 @@ def train_step(model, renderer, camera, batch, optimizer, cfg: TrainingConfig, d
                                 out["opacities"], render_camera, return_depth=True, phases=phases)
     target = F.interpolate(images, size=(res, res), mode="bilinear", align_corners=False)
     tdepth = F.interpolate(depth, size=(res, res), mode="bilinear", align_corners=False).squeeze(1)
-    loss, ld = compute_losses(rendered, target, rdepth, tdepth, cfg, dp)
-    bad = bool(torch.isnan(loss) or torch.isinf(loss))
-    if dp.any_true(bad, loss.device):  # collective NaN/Inf skip (TGD:1255-1258)
-        optimizer.zero_grad()
-        return None
-    optimizer.zero_grad()
+    loss, terms = compute_losses(rendered, target, rdepth, tdepth, cfg, dp)
+    # NaN/Inf batch skip (TGD:1255-1258), decided on the device and by ALL ranks together: the flag and the loss ride
+    # behind the gradients in the one all-reduce of the step
+    bad = (~torch.isfinite(loss.detach())).float()
+    optimizer.zero_grad(set_to_none=True)
     loss.backward()
-    dp.allreduce_gradients(list(model.parameters()))
-    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)  # TGD:1264
-    optimizer.step()
-    ld["total"] = dp.mean_scalar(ld["total"], loss.device)
-    return ld
+    extra = torch.stack([bad, torch.nan_to_num(loss.detach().float(), nan=0.0, posinf=0.0, neginf=0.0)])
+    extra = dp.allreduce_gradients(list(model.parameters()), extra=extra)
+    skipped = (extra[0] > 0).float()
+    terms["total"] = extra[1] / dp.world
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)  # TGD:1264 (foreach, no host sync)
+    if getattr(optimizer, "_step_supports_amp_scaling", False) and optimizer.defaults.get("fused"):
+        optimizer.grad_scale, optimizer.found_inf = None, skipped.reshape(())  # skipped batch: the fused step is a no-op
+        optimizer.step()
+    elif not bool(skipped):  # non-fused optimizer: the skip is a host decision (one sync)
+        optimizer.step()
+    return StepResult(terms, skipped)
 
 
 def save_checkpoint(model, optimizer, epoch, losses, cfg: TrainingConfig):
@@ -262,6 +371,27 @@ def make_dataset(cfg: TrainingConfig, log=print):
     return SyntheticDataset(n_items, cfg), n_items
 
 
+def _make_renderer(renderer_factory, cfg, device, train_res):
+    """Factories take (cfg, device) or (cfg, device, res): chosen from the signature (a TypeError raised INSIDE a
+    three-argument factory must not be mistaken for a two-argument one)."""
+    try:
+        params = inspect.signature(renderer_factory).parameters.values()
+        takes_res = len(params) >= 3 or any(p.kind == p.VAR_POSITIONAL for p in params)
+    except (TypeError, ValueError):
+        takes_res = True
+    return renderer_factory(cfg, device, train_res) if takes_res else renderer_factory(cfg, device)
+
+
+def save_training_history(history: Dict[str, list], cfg: TrainingConfig):
+    """training_history_exp{E}.json (TGD:1317-1323): one list per loss term, one entry per epoch, plus this repo's
+    step ms, composited Gaussian-pixels/s (whole job) and the rasterizer's stage ms."""
+    os.makedirs(cfg.output_dir, exist_ok=True)
+    path = Path(cfg.output_dir) / f"training_history_exp{cfg.experiment}.json"
+    with open(path, "w") as f:
+        json.dump(history, f, indent=2)
+    return path
+
+
 def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
                  renderer_factory: Callable = default_renderer_factory, resume: Optional[str] = None,
                  log=print, hfts: Optional[HFTSConfig] = None):
@@ -278,15 +408,12 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
                                  edge_opacity_boost=cfg.edge_opacity_boost).to(device)
     dp.broadcast_parameters(model)
     train_res = hfts.get_effective_train_resolution(cfg.image_size) if hfts is not None else cfg.image_size
-    try:
-        renderer, camera = renderer_factory(cfg, device, train_res)
-    except TypeError:  # factories that predate the resolution argument
-        renderer, camera = renderer_factory(cfg, device)
+    renderer, camera = _make_renderer(renderer_factory, cfg, device, train_res)
     # host-side draws that every rank must make identically (the pose is shared by the global batch; the K sampled
     # indices differ per rank like any other per-shard quantity)
     pose_rng = np.random.RandomState(cfg.seed + 7919)
     sample_gen = torch.Generator(device=device).manual_seed(cfg.seed * 104729 + dp.rank) if device.type == "cuda" else None
-    optimizer = AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+    optimizer = make_optimizer(model, cfg)
     scheduler = CosineAnnealingLR(optimizer, T_max=cfg.epochs)
     start_epoch = 0
     if resume:
@@ -295,32 +422,80 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
         optimizer.load_state_dict(ck["optimizer_state_dict"])
         start_epoch = ck["epoch"] + 1
     data, n_items = make_dataset(cfg, log if dp.rank == 0 else (lambda *a: None))
-    history = []
+    # metrics beyond the losses: composited Gaussian-pixels counted on the device by the renderer,
+    # the rasterizer's stage timers sampled on the logged steps
+    pair_counter = None
+    stage_timers = None
+    if device.type == "cuda" and hasattr(renderer, "pair_counter"):
+        pair_counter = torch.zeros(1, dtype=torch.int64, device=device)
+        renderer.pair_counter = pair_counter
+        from . import _binding as stage_timers
+    history: Dict[str, list] = {}
+    epoch_history = []
     for epoch in range(start_epoch, cfg.epochs):
         model.train()
-        sums, nb = {}, 0
-        for bi in range(0, n_items - cfg.batch_size + 1, cfg.batch_size):
-            lo, hi = dp.shard(cfg.batch_size)  # image-wise shard of the global batch
-            idx = list(range(bi + lo, bi + hi))
-            ld = train_step(model, renderer, camera, data.batch(idx, device), optimizer, cfg, dp, hfts=hfts, epoch=epoch,
-                            train_res=train_res, pose_rng=pose_rng, sample_gen=sample_gen)
-            if ld is None:
+        batches = epoch_batches(n_items, cfg.batch_size, dp.world, cfg.seed, epoch)
+        shards = []
+        for gb in batches:
+            lo, hi = dp.shard(len(gb))  # image-wise shard of the global batch
+            shards.append(gb[lo:hi])
+        acc: Dict[str, torch.Tensor] = {}
+        n_ok = torch.zeros((), device=device)
+        if pair_counter is not None:
+            pair_counter.zero_()
+            stage_timers.stage_timing_read()
+        t0 = time.perf_counter()
+        for bi, batch in enumerate(BatchPrefetcher(data, shards, device, cfg.num_workers)):
+            logged = bi % cfg.log_interval == 0
+            if stage_timers is not None and logged:
+                stage_timers.stage_timing_enable(True)
+            res = train_step(model, renderer, camera, batch, optimizer, cfg, dp, hfts=hfts, epoch=epoch,
+                             train_res=train_res, pose_rng=pose_rng, sample_gen=sample_gen)
+            if stage_timers is not None and logged:
+                stage_timers.stage_timing_enable(False)
+            ok = 1.0 - res.skipped
+            n_ok = n_ok + ok
+            for k, v in res.terms.items():  # device-side sums over the batches that were not skipped
+                acc[k] = acc.get(k, 0.0) + torch.where(ok > 0, v.float(), torch.zeros_like(v, dtype=torch.float32))
+            if logged:  # the only host round trip inside the epoch: once per log_interval (TGD:1275-1281)
+                ld = res.to_host()
                 if dp.rank == 0:
-                    log(f"  Warning: NaN/Inf loss at batch {bi // cfg.batch_size}, skipping")
-                continue
-            for k, v in ld.items():
-                sums[k] = sums.get(k, 0.0) + v
-            nb += 1
-            if dp.rank == 0 and (bi // cfg.batch_size) % cfg.log_interval == 0:
-                log(f"  Batch {bi // cfg.batch_size} | Loss: {ld['total']:.4f} | RGB: {ld['rgb']:.4f}")
+                    if ld is None:
+                        log(f"  Warning: NaN/Inf loss at batch {bi}, skipping")
+                    else:
+                        log(f"  Batch {bi}/{len(shards)} | Loss: {ld['total']:.4f} | RGB: {ld['rgb']:.4f}")
         scheduler.step()
-        losses = {k: v / max(nb, 1) for k, v in sums.items()}
-        history.append(losses)
+        keys = sorted(acc)
+        extra = [pair_counter[0].float()] if pair_counter is not None else []
+        vals = torch.stack([acc[k] for k in keys] + [n_ok] + extra).double()
+        if dp.enabled and pair_counter is not None:
+            import torch.distributed as tdist  # whole-job pair count (the losses are this rank's shard, as before)
+            tdist.all_reduce(vals[-1:], op=tdist.ReduceOp.SUM)
+        vals = vals.tolist()  # epoch end: one transfer (also the sync that closes the epoch's clock)
+        elapsed = time.perf_counter() - t0
+        nb = vals[len(keys)]
+        losses = {k: v / nb for k, v in zip(keys, vals)} if nb > 0 else {}
+        epoch_history.append(losses)
+        steps = max(len(shards), 1)
+        metrics = {"step_ms": elapsed / steps * 1e3, "skipped_batches": len(shards) - int(nb)}
+        if pair_counter is not None:
+            metrics["pairs_per_s"] = vals[-1] / max(elapsed, 1e-9)
+            st = stage_timers.stage_timing_read()
+            metrics["stage_ms"] = {k: v[0] / v[1] for k, v in st.items() if v[1]}
+        for k, v in list(losses.items()) + list(metrics.items()):
+            if isinstance(v, dict):
+                for kk, vv in v.items():
+                    history.setdefault(k, {}).setdefault(kk, []).append(vv)
+            else:
+                history.setdefault(k, []).append(v)
         if dp.rank == 0:
-            log(f"Epoch {epoch + 1}/{cfg.epochs} | " + " ".join(f"{k}={v:.4f}" for k, v in losses.items()))
+            log(f"Epoch {epoch + 1}/{cfg.epochs} | Time: {elapsed:.1f}s | {metrics['step_ms']:.2f} ms/step | "
+                + " ".join(f"{k}={v:.4f}" for k, v in losses.items()))
             if (epoch + 1) % cfg.save_interval == 0 or epoch + 1 == cfg.epochs:
                 save_checkpoint(model, optimizer, epoch, losses, cfg)
-    return model, history
+    if dp.rank == 0 and history:
+        save_training_history(history, cfg)
+    return model, epoch_history
 
 
 def main(argv=None):

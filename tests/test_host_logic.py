@@ -2,6 +2,7 @@
 (DR:1461-1497), orbit camera (TGD:684-757), Camera defaults (DR:27-52), decoder output
 shapes/ranges, training flags."""
 import numpy as np
+import pytest
 import torch
 
 from helpers import load_golden
@@ -182,3 +183,106 @@ def test_column_fft_pass_structure_numpy_model():
         assert np.abs(fft_cols(v, logn, False) - np.fft.fft(v)[br]).max() < 1e-10 * N
         g = rs.randn(N) + 1j * rs.randn(N)
         assert np.abs(fft_cols(g[br], logn, True) - np.fft.ifft(g) * N).max() < 1e-10 * N
+
+
+def test_epoch_batches_shuffle_per_epoch_same_on_all_ranks_and_keep_the_tail():
+    """a fresh permutation per epoch from seed + epoch (what every rank draws), the last partial
+    batch kept when it divides over the ranks (DataLoader(shuffle=True) without drop_last, TGD:1760-1767)."""
+    from fresnel_amd.train import epoch_batches
+    e0, e1 = epoch_batches(22, 4, 2, seed=5, epoch=0), epoch_batches(22, 4, 2, seed=5, epoch=1)
+    assert e0 == epoch_batches(22, 4, 2, seed=5, epoch=0)          # deterministic: identical on every rank
+    assert e0 != e1                                                # reshuffled every epoch
+    assert sorted(i for b in e0 for i in b) == list(range(22))     # tail of 2 kept: divides over 2 ranks
+    assert [len(b) for b in e0] == [4] * 5 + [2]
+    assert sum(len(b) for b in epoch_batches(23, 4, 2, seed=5, epoch=0)) == 20   # tail of 3 on 2 ranks: dropped
+    assert e0 != [list(range(i, i + 4)) for i in range(0, 20, 4)] + [[20, 21]]   # not the sorted-filename order
+
+
+def test_batch_prefetcher_yields_the_batches_in_order_and_surfaces_errors():
+    import torch
+    from fresnel_amd.train import BatchPrefetcher, SyntheticDataset, TrainingConfig
+    cfg = TrainingConfig(image_size=16, feature_size=4, feature_dim=8, device="cpu")
+    data = SyntheticDataset(12, cfg)
+    lists = [[3, 1], [0, 7], [11, 2], [5]]
+    got = list(BatchPrefetcher(data, lists, "cpu", num_workers=3, depth=2))
+    assert len(got) == 4
+    for idx, b in zip(lists, got):
+        want = data.batch(idx, "cpu")
+        assert all(torch.equal(x, y) for x, y in zip(b, want))
+
+    class Broken(SyntheticDataset):
+        def host_item(self, i):
+            raise OSError("unreadable image")
+    with pytest.raises(OSError):
+        list(BatchPrefetcher(Broken(4, cfg), [[0, 1]], "cpu"))
+
+
+def test_training_history_json_and_device_side_nan_skip(tmp_path):
+    """run_training on CPU with a stand-in renderer: history file of TGD:1317-1323 (+ step_ms), and a poisoned batch
+    is skipped by the fused optimizer's found_inf path without touching weights or step count."""
+    import json
+    import torch
+    from fresnel_amd import train as T
+
+    class Ren(torch.nn.Module):
+        def __init__(self, res, poison):
+            super().__init__()
+            self.res, self.poison, self.calls = res, poison, 0
+
+        def forward(self, pos, scale, rot, col, opa, camera, return_depth=False, phases=None):
+            self.calls += 1
+            img = (col.mean(1)[:, :, None, None] + 0 * (pos.sum() + scale.sum() + rot.sum() + opa.sum())).expand(-1, 3, self.res, self.res)
+            if self.calls in self.poison:
+                img = img * float("nan")
+            return img, (-pos[..., 2]).mean(1)[:, None, None].expand(-1, self.res, self.res) + 0 * opa.sum()
+
+    def run(poison):
+        cfg = T.TrainingConfig(batch_size=2, epochs=2, lr=1e-2, image_size=8, feature_size=3, feature_dim=4, gaussians_per_patch=1,
+                               ssim_weight=0.0, device="cpu", steps_per_epoch=3, save_interval=100, log_interval=100,
+                               output_dir=str(tmp_path / f"o{len(poison)}"), num_workers=1)
+        ren = Ren(8, poison)
+        model, hist = T.run_training(cfg, renderer_factory=lambda c, d, r: (ren, None), log=lambda *a: None)
+        return cfg, model, hist
+    cfg, model, hist = run(set())
+    h = json.load(open(tmp_path / "o0" / "training_history_exp2.json"))
+    assert {"total", "rgb", "depth", "step_ms", "skipped_batches"} <= set(h) and len(h["total"]) == 2
+    assert h["skipped_batches"] == [0, 0] and abs(h["total"][-1] - hist[-1]["total"]) < 1e-12
+    # every batch of the run poisoned: nothing learned, parameters exactly the initial ones, history has no losses
+    cfg2, model2, hist2 = run(set(range(1, 100)))
+    torch.manual_seed(cfg2.seed)
+    fresh = T.PatchGaussianDecoder(cfg2.feature_dim, cfg2.gaussians_per_patch, grid=cfg2.feature_size)
+    for a, b in zip(model2.parameters(), fresh.parameters()):
+        assert torch.equal(a, b)
+    assert hist2 == [{}, {}]
+    # one poisoned batch: skipped, the others train
+    _, model3, hist3 = run({2})
+    h3 = json.load(open(tmp_path / "o1" / "training_history_exp2.json"))
+    assert h3["skipped_batches"] == [1, 0] and all(torch.isfinite(p).all() for p in model3.parameters())
+
+
+def test_camera_record_cache_follows_set_view_and_data_edits():
+    """the packed-camera cache must not serve a stale record after set_view (id() reuse) or an edit through
+    .data (which leaves _version unchanged)."""
+    import torch
+    from fresnel_amd.renderer import Camera
+    cam = Camera(10.0, 10.0, 4.0, 4.0, 8, 8)
+    r0 = cam.packed_tensor("cpu").clone()
+    for k in range(3):  # fresh matrices that may reuse a freed tensor's id with _version 0
+        v = torch.eye(4)
+        v[0, 3] = float(k + 1)
+        cam.set_view(v)
+        assert cam.packed_tensor("cpu")[0, 3].item() == float(k + 1)
+        del v
+    cam.view_matrix.data[1, 3] = 7.0
+    assert cam.packed_tensor("cpu")[0, 7].item() == 7.0
+    assert cam.packed_tensor("cpu") is cam.packed_tensor("cpu")  # unchanged camera: one upload
+    assert not torch.equal(r0, cam.packed_tensor("cpu"))
+
+
+def test_phase_tensor_shapes_are_validated_before_any_kernel_sees_them():
+    import torch
+    from fresnel_amd.renderer import _phase_channels
+    assert _phase_channels(torch.zeros(2, 5)) == 1 and _phase_channels(torch.zeros(2, 5, 3)) == 3
+    assert _phase_channels(torch.zeros(2, 5, 1)) == 1   # one float per Gaussian, NOT three
+    with pytest.raises(ValueError):
+        _phase_channels(torch.zeros(2, 5, 2))

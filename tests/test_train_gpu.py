@@ -118,3 +118,73 @@ def test_harness_hfts_flags_and_data_dir(tmp_path):
     for p in model.parameters():
         assert torch.isfinite(p).all()
     assert any(p.grad is not None and p.grad.abs().sum() > 0 for p in model.edge_detector.parameters())
+
+
+def test_train_step_makes_no_host_synchronisation(tmp_path):
+    """<= 1 host sync per step -- in fact none: loss terms stay on the device, the NaN/Inf skip flag
+    rides in the gradient bucket and reaches the fused AdamW step as `found_inf`.  torch's sync debug mode turns any
+    synchronising call (.item(), .tolist(), bool(tensor), a pageable H2D copy) into an error."""
+    import numpy as np
+    from fresnel_amd.dist import DPContext
+    from fresnel_amd.train import (PatchGaussianDecoder, StepResult, SyntheticDataset, TrainingConfig,
+                                   default_renderer_factory, make_optimizer, train_step)
+    dev = torch.device("cuda:0")
+    cfg = TrainingConfig(batch_size=2, epochs=1, lr=1e-3, image_size=64, feature_size=6, feature_dim=16, gaussians_per_patch=4,
+                         device="cuda:0", use_frequency_loss=True, wave_equation_weight=1e-9)
+    torch.manual_seed(0)
+    model = PatchGaussianDecoder(cfg.feature_dim, cfg.gaussians_per_patch, grid=cfg.feature_size).to(dev)
+    renderer, camera = default_renderer_factory(cfg, dev)
+    opt = make_optimizer(model, cfg)
+    assert opt.defaults.get("fused"), "the fused AdamW is what takes the skip flag on the device"
+    dp = DPContext(device=dev)
+    data = SyntheticDataset(8, cfg)
+    rng = np.random.RandomState(0)
+    batches = [data.batch([2 * i, 2 * i + 1], dev) for i in range(3)]
+    train_step(model, renderer, camera, batches[0], opt, cfg, dp, pose_rng=rng)  # warm-up: plan caches, camera upload
+    torch.cuda.synchronize()
+    before = [p.detach().clone() for p in model.parameters()]
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        res = train_step(model, renderer, camera, batches[1], opt, cfg, dp, pose_rng=rng)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert isinstance(res, StepResult)
+    ld = res.to_host()  # the one transfer, outside the step
+    assert ld is not None and {"rgb", "depth", "frequency", "wave_eq", "total"} <= set(ld) and all(v == v for v in ld.values())
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    # a poisoned batch: skipped on the device -- weights and the optimizer's step count stay exactly as they were
+    before = [p.detach().clone() for p in model.parameters()]
+    steps = [float(opt.state[p]["step"]) for p in model.parameters()]
+    bad = (batches[2][0] * float("nan"), batches[2][1], batches[2][2])
+    res = train_step(model, renderer, camera, bad, opt, cfg, dp, pose_rng=rng)
+    assert res.to_host() is None
+    assert all(torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    assert steps == [float(opt.state[p]["step"]) for p in model.parameters()]
+
+
+def test_harness_writes_history_with_pairs_per_second_and_stage_ms(tmp_path):
+    """SURVEY section 5 metrics: training_history_exp{E}.json carries the epoch losses (TGD:1317-1323) plus step ms,
+    composited Gaussian-pixels/s (counted on the device by fgs_count_pairs) and the rasterizer's stage timers."""
+    import json
+    from fresnel_amd.train import TrainingConfig, run_training
+    cfg = TrainingConfig(batch_size=2, epochs=2, lr=1e-3, image_size=64, feature_size=6, feature_dim=16, gaussians_per_patch=4,
+                         device="cuda:0", steps_per_epoch=3, save_interval=100, output_dir=str(tmp_path), log_interval=2)
+    seen = []
+    run_training(cfg, log=lambda *a: seen.append(" ".join(str(x) for x in a)))
+    h = json.load(open(tmp_path / "training_history_exp2.json"))
+    assert len(h["total"]) == 2 and len(h["pairs_per_s"]) == 2 and all(v > 0 for v in h["pairs_per_s"])
+    assert {"composite_fwd", "composite_bwd", "project"} <= set(h["stage_ms"]) and h["skipped_batches"] == [0, 0]
+    assert any(s.strip().startswith("Batch 0/3") for s in seen) and any("Batch 2/3" in s for s in seen)
+
+
+def test_spectral_loss_refuses_a_second_backward():
+    """fgs_spectral_loss_backward consumes the saved spectra in place; a second backward through the same node
+    must raise instead of returning garbage."""
+    from fresnel_amd.losses import FrequencyDomainLoss
+    dev = torch.device("cuda:0")
+    r = torch.rand(1, 3, 32, 32, device=dev, requires_grad=True)
+    t = torch.rand(1, 3, 32, 32, device=dev)
+    loss = FrequencyDomainLoss()(r, t)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
