@@ -683,6 +683,19 @@ __device__ __forceinline__ uint32_t length_bucket(uint32_t len) {
     return q >= 62u ? 0u : 62u - q;
 }
 
+// XCD groups of the launch order (ngroups = 8, blend forward only): group g = the tiles whose index lies in the g-th of the
+// eight contiguous ranges fgs_xcd_remap deals to XCD g -- for a batch of 8 images that is one image per XCD, for fewer
+// images a band of tile rows.  tile_order then holds group 0's tiles heavy-first, then group 1's, ...; the forward reads
+// tile_order[fgs_xcd_remap(blockIdx.x, ntiles)], so XCD g walks ITS group heavy-first and the records (`rec`, 48 B per
+// Gaussian, 1.5 MB per config-3 image) its tiles gather stay in that XCD's 4 MB L2 instead of every L2 streaming the
+// records of all images (12.6 MB): the counting sort simply runs over 64 x ngroups columns, column = 64 g + bucket.
+__device__ __forceinline__ uint32_t tile_group(uint32_t t, uint32_t ntiles, uint32_t ngroups) {
+    if (ngroups == 1u) return 0u;
+    const uint32_t q = ntiles >> 3, r = ntiles & 7u, split = r * (q + 1u);
+    return t < split ? t / (q + 1u) : r + (t - split) / (q ? q : 1u);
+}
+constexpr uint32_t TO_MAX_COLS = 512;  // 64 length buckets x up to 8 XCD groups
+
 __device__ __forceinline__ uint32_t tile_len(const uint32_t *__restrict__ lens, const uint32_t *__restrict__ ranges,
                                              uint32_t t) {
     if (lens) return lens[t];
@@ -693,10 +706,11 @@ __device__ __forceinline__ uint32_t tile_len(const uint32_t *__restrict__ lens, 
 __global__ __launch_bounds__(256) void k_tile_pre(uint32_t ntiles, const uint32_t *__restrict__ ranges,
                                                   const uint32_t *__restrict__ lens, uint32_t seg_len,
                                                   unsigned long long *__restrict__ pre64,
-                                                  uint32_t *__restrict__ bhist) {
-    __shared__ uint32_t hist[64];
+                                                  uint32_t *__restrict__ bhist, uint32_t ngroups) {
+    __shared__ uint32_t hist[TO_MAX_COLS];
     __shared__ unsigned long long wsum[4];
-    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    const uint32_t ncols = 64u * ngroups;
+    for (uint32_t i = threadIdx.x; i < ncols; i += 256) hist[i] = 0;
     __syncthreads();
     unsigned long long v = 0;
     const uint32_t t0 = blockIdx.x * TO_TILES + threadIdx.x * 4u;
@@ -706,7 +720,7 @@ __global__ __launch_bounds__(256) void k_tile_pre(uint32_t ntiles, const uint32_
         if (t < ntiles) {
             const uint32_t len = tile_len(lens, ranges, t);
             v += ((unsigned long long)len << 32) | ((len + seg_len - 1) / seg_len);
-            atomicAdd(&hist[length_bucket(len)], 1u);
+            atomicAdd(&hist[64u * tile_group(t, ntiles, ngroups) + length_bucket(len)], 1u);
         }
     }
 #pragma unroll
@@ -714,7 +728,7 @@ __global__ __launch_bounds__(256) void k_tile_pre(uint32_t ntiles, const uint32_
     if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) pre64[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-    if (threadIdx.x < 64) bhist[blockIdx.x * 64 + threadIdx.x] = hist[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < ncols; i += 256) bhist[blockIdx.x * ncols + i] = hist[i];
 }
 
 __global__ __launch_bounds__(256) void k_tile_post(uint32_t ntiles, uint32_t *__restrict__ ranges,
@@ -723,10 +737,11 @@ __global__ __launch_bounds__(256) void k_tile_post(uint32_t ntiles, uint32_t *__
                                                    uint32_t *__restrict__ seg_tile, uint32_t *__restrict__ counters,
                                                    uint32_t seg_len, uint32_t fwd_variant,
                                                    const unsigned long long *__restrict__ pre64,
-                                                   const uint32_t *__restrict__ bhist) {
-    __shared__ uint32_t bucket_pos[64];         // next slot of every bucket for this block's tiles
+                                                   const uint32_t *__restrict__ bhist, uint32_t ngroups) {
+    __shared__ uint32_t bucket_pos[TO_MAX_COLS];  // next slot of every (group, bucket) column for this block's tiles
     __shared__ unsigned long long wsum[4], carry_sh, total_sh;
-    __shared__ uint32_t col_before[64], col_total[64];
+    __shared__ uint32_t col_before[TO_MAX_COLS], col_total[TO_MAX_COLS];
+    const uint32_t ncols = 64u * ngroups;
     const uint32_t nblk = gridDim.x, blk = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // (1) sums of the blocks before this one (and of all blocks)
     {
@@ -743,31 +758,72 @@ __global__ __launch_bounds__(256) void k_tile_post(uint32_t ntiles, uint32_t *__
         __syncthreads();
         if (threadIdx.x == 0) { carry_sh = (wb[0] + wb[1]) + (wb[2] + wb[3]); total_sh = (wa[0] + wa[1]) + (wa[2] + wa[3]); }
     }
-    // (2) bucket columns: thread (bucket b = tid & 63, quarter q = tid >> 6) sums rows q, q + 4, ...
+    // (2) bucket columns: thread (bucket b = tid & 63, quarter q = tid >> 6) sums rows q, q + 4, ... of every group's
+    // column 64 g + b
     {
-        uint32_t before = 0, all = 0;
         const uint32_t b = threadIdx.x & 63u;
-        for (uint32_t k0 = threadIdx.x >> 6; k0 < nblk; k0 += 32) {  // eight loads in flight (rows k0, k0 + 4, ...)
-            uint32_t h[8];
+        __shared__ uint32_t pb[4][TO_MAX_COLS], pa[4][TO_MAX_COLS];
+        if (ngroups == 1u) {
+            uint32_t before = 0, all = 0;
+            for (uint32_t k0 = threadIdx.x >> 6; k0 < nblk; k0 += 32) {  // eight loads in flight (rows k0, k0 + 4, ...)
+                uint32_t h[8];
 #pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) h[u] = k0 + 4u * u < nblk ? bhist[(k0 + 4u * u) * 64 + b] : 0u;
+                for (uint32_t u = 0; u < 8; ++u) h[u] = k0 + 4u * u < nblk ? bhist[(size_t)(k0 + 4u * u) * 64u + b] : 0u;
 #pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-                all += h[u];
-                if (k0 + 4u * u < blk) before += h[u];
+                for (uint32_t u = 0; u < 8; ++u) {
+                    all += h[u];
+                    if (k0 + 4u * u < blk) before += h[u];
+                }
             }
+            pb[threadIdx.x >> 6][b] = before; pa[threadIdx.x >> 6][b] = all;
+        } else {
+            // 64 x ngroups columns, few rows (the blend path has <= a few dozen blocks of 1024 tiles): a thread owns the
+            // columns tid, tid + 256 and walks the rows, all of a round's loads in flight together
+            for (uint32_t col = threadIdx.x; col < ncols; col += 256) { pb[1][col] = pb[2][col] = pb[3][col] = 0; pa[1][col] = pa[2][col] = pa[3][col] = 0; }
+            uint32_t before[2] = {0, 0}, all[2] = {0, 0};
+            for (uint32_t k0 = 0; k0 < nblk; k0 += 4) {
+                uint32_t h[2][4];
+#pragma unroll
+                for (uint32_t c = 0; c < 2; ++c)
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t col = threadIdx.x + 256u * c;
+                        h[c][u] = (k0 + u < nblk && col < ncols) ? bhist[(size_t)(k0 + u) * ncols + col] : 0u;
+                    }
+#pragma unroll
+                for (uint32_t c = 0; c < 2; ++c)
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        all[c] += h[c][u];
+                        if (k0 + u < blk) before[c] += h[c][u];
+                    }
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c)
+                if (threadIdx.x + 256u * c < ncols) { pb[0][threadIdx.x + 256u * c] = before[c]; pa[0][threadIdx.x + 256u * c] = all[c]; }
         }
-        __shared__ uint32_t pb[4][64], pa[4][64];
-        pb[threadIdx.x >> 6][b] = before; pa[threadIdx.x >> 6][b] = all;
         __syncthreads();
-        if (threadIdx.x < 64) {
-            col_before[b] = (pb[0][b] + pb[1][b]) + (pb[2][b] + pb[3][b]);
-            col_total[b] = (pa[0][b] + pa[1][b]) + (pa[2][b] + pa[3][b]);
+        for (uint32_t col = threadIdx.x; col < ncols; col += 256) {
+            col_before[col] = (pb[0][col] + pb[1][col]) + (pb[2][col] + pb[3][col]);
+            col_total[col] = (pa[0][col] + pa[1][col]) + (pa[2][col] + pa[3][col]);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int i = 0; i < 64; ++i) { bucket_pos[i] = run + col_before[i]; run += col_total[i]; }
+        if (threadIdx.x < 64) {  // exclusive scan of the column totals: one wave, ncols / 64 columns per lane
+            const uint32_t per = ncols / 64u;  // = ngroups
+            uint32_t mine = 0;
+            for (uint32_t i = 0; i < per; ++i) mine += col_total[threadIdx.x * per + i];
+            uint32_t x = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(x, o, 64);
+                if (threadIdx.x >= (uint32_t)o) x += y;
+            }
+            uint32_t run = x - mine;
+            for (uint32_t i = 0; i < per; ++i) {
+                const uint32_t col = threadIdx.x * per + i;
+                bucket_pos[col] = run + col_before[col];
+                run += col_total[col];
+            }
         }
     }
     // (3) this block's tiles: exclusive scan of (length, units) in tile order
@@ -800,7 +856,7 @@ __global__ __launch_bounds__(256) void k_tile_post(uint32_t ntiles, uint32_t *__
             seg_off[t] = off;
             for (uint32_t u = 0; u < n; ++u) seg_tile[off + u] = t;
         }
-        tile_order[atomicAdd(&bucket_pos[length_bucket(len[k])], 1u)] = t;
+        tile_order[atomicAdd(&bucket_pos[64u * tile_group(t, ntiles, ngroups) + length_bucket(len[k])], 1u)] = t;
         off64 += ((unsigned long long)len[k] << 32) | n;
     }
     if (blk == nblk - 1 && threadIdx.x == 0 && seg_off) {
@@ -815,16 +871,16 @@ __global__ __launch_bounds__(256) void k_tile_post(uint32_t ntiles, uint32_t *__
 // scratch of the two kernels above: (sums, histograms) per block of TO_TILES tiles
 static int launch_tile_tables(uint32_t ntiles, uint32_t *ranges, const uint32_t *lens, uint32_t *tile_order,
                               uint32_t *seg_off, uint32_t *seg_tile, uint32_t *counters, uint32_t seg_len,
-                              uint32_t fwd_variant, uint32_t *scratch_words, hipStream_t st) {
+                              uint32_t fwd_variant, uint32_t *scratch_words, hipStream_t st, uint32_t ngroups = 1) {
     const uint32_t nblk = (ntiles + TO_TILES - 1) / TO_TILES;
     unsigned long long *pre64 = reinterpret_cast<unsigned long long *>(scratch_words);
-    uint32_t *bhist = scratch_words + 2 * (size_t)nblk;
+    uint32_t *bhist = scratch_words + 2 * (size_t)nblk;  // [nblk][64 * ngroups]
     // (k_tile_post walking all lengths itself instead of this launch: 21.6 us against 4.8 + 9.2 at config 3 -- the
     // bucket histogram's same-address LDS atomics)
-    hipLaunchKernelGGL(k_tile_pre, dim3(nblk), dim3(256), 0, st, ntiles, ranges, lens, seg_len, pre64, bhist);
+    hipLaunchKernelGGL(k_tile_pre, dim3(nblk), dim3(256), 0, st, ntiles, ranges, lens, seg_len, pre64, bhist, ngroups);
     FGS_LAUNCH_CHECK("k_tile_pre");
     hipLaunchKernelGGL(k_tile_post, dim3(nblk), dim3(256), 0, st, ntiles, ranges, lens, tile_order, seg_off, seg_tile,
-                       counters, seg_len, fwd_variant, pre64, bhist);
+                       counters, seg_len, fwd_variant, pre64, bhist, ngroups);
     FGS_LAUNCH_CHECK("k_tile_post");
     return FGS_OK;
 }
@@ -935,7 +991,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         fgs_stage_end(ST_DUP_EMIT, st);
         fgs_stage_begin(ST_TILE_RANGES, st);
         if ((rc = launch_tile_tables(ntiles_all, ranges, lens, tile_order, seg_off, seg_tile, counters,
-                                     (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant, vals1, st)))
+                                     (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant, vals1, st, (uint32_t)p.order_groups)))
             return rc;
         fgs_stage_end(ST_TILE_RANGES, st);
         fgs_stage_begin(ST_TILE_SORT, st);
@@ -990,7 +1046,8 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
     FGS_LAUNCH_CHECK("k_tile_ranges");
     // (vals0 is free again: the sort's final payload went to dup_ids, its last keys are in `ks`)
     if ((rc = launch_tile_tables(ntiles_all, ranges, nullptr, tile_order, seg_off, seg_tile, counters,
-                                 (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant, ks == keys0 ? keys1 : keys0, st)))
+                                 (uint32_t)p.L.seg_len, (uint32_t)p.fwd_variant, ks == keys0 ? keys1 : keys0, st,
+                                 (uint32_t)p.order_groups)))
         return rc;
     fgs_stage_end(ST_TILE_RANGES, st);
     return FGS_OK;

@@ -304,13 +304,35 @@ __device__ __forceinline__ BlendState compose(const BlendState &a, const BlendSt
     return {a.Cr + a.T * b.Cr, a.Cg + a.T * b.Cg, a.Cb + a.T * b.Cb, a.T * b.T, a.D + a.T * b.D};
 }
 // [5][NS][64] slot (NS = 4 sub-tiles of a 16 x 16 tile, 8 of a 32 x 16 tile), this lane's cell; PL = NS * 64
+// Checkpoints are a write-once / read-once stream (307 MB per config-3 step against 12.6 MB of records).  Non-temporal
+// stores / loads for them (FGS_CKPT_NT=1) were measured in round 3 and are OFF: WRITE_SIZE of the forward ROSE from 450
+// to 547 MB per launch (the nt stores reach the fabric as more, smaller writes), the backward got 1 % slower, and what
+// actually evicted `rec` from L2 was the launch order, not the checkpoint stream (see order_groups above: FETCH_SIZE
+// 330 -> 62 MB).
+#ifndef FGS_CKPT_NT
+#define FGS_CKPT_NT 0
+#endif
+__device__ __forceinline__ void nt_store(float *p, float v) {
+#if FGS_CKPT_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ float nt_load(const float *p) {
+#if FGS_CKPT_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 template <int PL = 256>
 __device__ __forceinline__ void ckpt_store(float *ck, const BlendState &v) {
-    ck[0] = v.Cr; ck[PL] = v.Cg; ck[2 * PL] = v.Cb; ck[3 * PL] = 1.0f - v.T; ck[4 * PL] = v.D;
+    nt_store(ck, v.Cr); nt_store(ck + PL, v.Cg); nt_store(ck + 2 * PL, v.Cb); nt_store(ck + 3 * PL, 1.0f - v.T); nt_store(ck + 4 * PL, v.D);
 }
 template <int PL = 256>
 __device__ __forceinline__ BlendState ckpt_load(const float *ck) {
-    return {ck[0], ck[PL], ck[2 * PL], 1.0f - ck[3 * PL], ck[4 * PL]};
+    return {nt_load(ck), nt_load(ck + PL), nt_load(ck + 2 * PL), 1.0f - nt_load(ck + 3 * PL), nt_load(ck + 4 * PL)};
 }
 
 // WIDE = 1: 32 x 16 tiles (FgsSavedLayout.tile_w = 32; the backward then has eight sub-tiles per lane and ~0.6x as many
@@ -324,12 +346,15 @@ __global__ __launch_bounds__(64 * NP * (1 + WIDE)) __attribute__((amdgpu_waves_p
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, float *__restrict__ pix_state,
     float *__restrict__ out_rgb, float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off,
-    float *__restrict__ seg_ckpt, uint32_t seg_len) {
+    float *__restrict__ seg_ckpt, uint32_t seg_len, uint32_t order_groups) {
     constexpr int NW = NP * (1 + WIDE);                   // waves per block
     constexpr int TSX = WIDE ? 4 : 2;                     // sub-tile columns of the whole tile
     constexpr int PL = 2 * TSX * 64, SLOT = 5 * PL;       // floats per checkpoint plane / slot: [5][2 TSX][64]
     __shared__ float4 sh0[NW][64], sh1[NW][64], sh2[NW][64];
-    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges, 8u * TSX);
+    // launch order: tile_order holds the tiles of XCD group 0 heavy-first, then group 1's, ... (fgs_bin.hip tile_group);
+    // blocks are dealt round-robin over the XCDs, so XCD g walks group g -- one image (or band of tile rows) per L2
+    const uint32_t slot_in_order = order_groups > 1u ? fgs_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const TileCtx c = tile_ctx_of(tile_order[slot_in_order], tiles, tiles_x, ranges, 8u * TSX);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t part = WIDE ? wave >> 1 : wave, half = WIDE ? wave & 1u : 0u;
@@ -458,13 +483,13 @@ __global__ __launch_bounds__(64 * NP * (1 + WIDE)) __attribute__((amdgpu_waves_p
             const size_t o = (size_t)py * W + px;
             float *ps = pix_state + (size_t)c.b * 6 * HW + o;
             const float Tf = T[s];
-            ps[0] = Cr[s]; ps[HW] = Cg[s]; ps[2 * HW] = Cb[s]; ps[3 * HW] = 1.0f - Tf; ps[4 * HW] = Dm[s];
-            ps[5 * HW] = 0.0f;
+            nt_store(ps, Cr[s]); nt_store(ps + HW, Cg[s]); nt_store(ps + 2 * HW, Cb[s]); nt_store(ps + 3 * HW, 1.0f - Tf);
+            nt_store(ps + 4 * HW, Dm[s]);  // (plane 5, Phi, belongs to the phase path: nobody reads it on this one)
             float *img = out_rgb + (size_t)c.b * 3 * HW + o;
-            img[0] = fminf(fmaxf(Cr[s] + Tf * bg0, 0.0f), 1.0f);
-            img[HW] = fminf(fmaxf(Cg[s] + Tf * bg1, 0.0f), 1.0f);
-            img[2 * HW] = fminf(fmaxf(Cb[s] + Tf * bg2, 0.0f), 1.0f);
-            out_depth[(size_t)c.b * HW + o] = Dm[s];
+            nt_store(img, fminf(fmaxf(Cr[s] + Tf * bg0, 0.0f), 1.0f));
+            nt_store(img + HW, fminf(fmaxf(Cg[s] + Tf * bg1, 0.0f), 1.0f));
+            nt_store(img + 2 * HW, fminf(fmaxf(Cb[s] + Tf * bg2, 0.0f), 1.0f));
+            nt_store(out_depth + (size_t)c.b * HW + o, Dm[s]);
         }
     }
 }
@@ -539,7 +564,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6
                 const uint32_t e = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
                 if (e < dcap) {
                     float2 *row = reinterpret_cast<float2 *>(grad_rows + (size_t)e * FGS_BLEND_ROW_FLOATS);
-                    row[0] = row[1] = row[2] = row[3] = row[4] = make_float2(0.0f, 0.0f);
+#pragma unroll
+                    for (int q = 0; q < FGS_BLEND_ROW_FLOATS / 2; ++q) row[q] = make_float2(0.0f, 0.0f);
                 }
             }
             return;
@@ -685,7 +711,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6
                 const float vals[10] = {v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d};
                 const float tot = wave_sum10_addtid(red, vals, lane);
                 const uint32_t kk = lane >> 2, e = she[j];
-                if ((lane & 3u) == 3u && lane < 40u && e < dcap) grad_rows[(size_t)e * FGS_BLEND_ROW_FLOATS + kk] = tot;
+                // (16-float rows: all sixteen quads' last lanes store, lanes >= 40 a zero -- one whole 64-byte line)
+                if ((lane & 3u) == 3u && lane < 4u * FGS_BLEND_ROW_FLOATS && e < dcap) grad_rows[(size_t)e * FGS_BLEND_ROW_FLOATS + kk] = tot;
             }
         }
         __syncthreads();
@@ -910,7 +937,7 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     hipLaunchKernelGGL((k_blend_fwd_parts<NP, WD>), dim3(grid), dim3(64 * NP * (1 + WD)), 0, st, (uint32_t)p.tiles, \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
                        p.d.background[1], p.d.background[2], tile_order, ranges, dup_ids, rec, pix, out_rgb,  \
-                       out_depth, seg_off, seg_ckpt, (uint32_t)p.L.seg_len)
+                       out_depth, seg_off, seg_ckpt, (uint32_t)p.L.seg_len, (uint32_t)p.order_groups)
         if (p.tile_w == 32) {
             if (np == 1) FGS_PARTS_LAUNCH(1, 1); else if (np == 2) FGS_PARTS_LAUNCH(2, 1); else if (np == 4) FGS_PARTS_LAUNCH(4, 1);
             else FGS_PARTS_LAUNCH(8, 1);

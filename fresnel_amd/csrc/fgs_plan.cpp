@@ -137,6 +137,10 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
         return FGS_EINVAL;
     }
     L.tile_w = p->tile_w;
+#ifndef FGS_ORDER_GROUPS
+#define FGS_ORDER_GROUPS 8
+#endif
+    p->order_groups = (p->fwd_parts > 0 && layers == 1 && segment_ckpt) ? FGS_ORDER_GROUPS : 1;
     const size_t ucap = dcap / L.seg_len + B * layers * p->tiles;
     L.seg_off = o; L.seg_tile = o; L.seg_ckpt = o; L.seg_capacity = 0;
     if (!d->use_phase) {
@@ -171,7 +175,8 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     p->s_hist = o; o = align256(o + hist);
     p->s_bsum = o; o = align256(o + nblk * 4);
     // gradient rows: one per duplicate; four (one per sub-tile wave) on the phase path
-    p->s_grows = o; o = align256(o + dcap * FGS_GROW_FLOATS * 4 * (d->use_phase ? 4 : 1));
+    p->s_grows = o; o = align256(o + dcap * 4 * (d->use_phase ? 4 * FGS_GROW_FLOATS
+                                                             : (FGS_BLEND_ROW_FLOATS > FGS_GROW_FLOATS ? FGS_BLEND_ROW_FLOATS : FGS_GROW_FLOATS)));
     p->s_plane = o; o = align256(o + B * ((size_t)layers + 1) * 4);
     p->s_rsum = o; o = align256(o + B * N * 12 * 4);
     p->s_total = o;

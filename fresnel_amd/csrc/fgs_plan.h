@@ -13,7 +13,11 @@
 // gradient-row field indices (scratch.grows): one 12-float row per (tile, Gaussian) duplicate
 enum { G_U = 0, G_V, G_CA, G_CBC, G_CD, G_OP, G_CR, G_CG, G_CB, G_DEPTH, G_PHASE, G_PAD1 };
 #define FGS_GROW_FLOATS 12
-#define FGS_BLEND_ROW_FLOATS 10  /* gradient rows of the (non-phase) blend backward: exactly its ten sums */
+#ifndef FGS_BLEND_ROW_FLOATS
+#define FGS_BLEND_ROW_FLOATS 10  /* gradient rows of the (non-phase) blend backward: exactly its ten sums.  16 (build experiment):
+                                    one 64-byte line per row, written whole by sixteen lanes -- no partial-sector writes, but 1.6x
+                                    the bytes each way; measured in round 3, see DESIGN.md */
+#endif
 #define FGS_BIN_G 256  /* depth ranks per block of the direct binning (fgs_bin.hip) */
 enum { R_U = 0, R_V, R_CA, R_CBC, R_CD, R_OP, R_CR, R_CG, R_CB, R_DEPTH, R_BBX, R_BBY };
 
@@ -31,6 +35,8 @@ struct FgsPlan {
     int32_t fwd_waves;        // waves per tile of the row-split forward (also the phase path)
     int32_t fwd_variant;      // the same choice in FgsDims.fwd_variant encoding (recorded in saved.counters[5])
     bool direct_binning;      // counting sort straight from the bboxes instead of emit + radix sort
+    int32_t order_groups;     // XCD groups of the forward's launch order (fgs_bin.hip tile_group): 8 on the blend path's
+                              // depth-split forward, 1 elsewhere
     // scratch layout (bytes)
     size_t s_total;
     size_t s_keys0, s_keys1;  // uint32 [max(B*N, Dcap)] radix ping/pong keys

@@ -183,6 +183,23 @@ __global__ __launch_bounds__(256) void k_row_sum(int32_t total, int32_t N, uint3
         double m[6] = {0, 0, 0, 0, 0, 0};
         const float *base = grad_rows + (size_t)off * FGS_BLEND_ROW_FLOATS;
         uint32_t k = sub;
+#if FGS_BLEND_ROW_FLOATS == 16
+        // 64-byte rows (build experiment): three aligned 16-byte loads per row
+        auto add_row = [&](const float4 a, const float4 b, const float4 c) {
+            m[0] += a.x; m[1] += a.y; m[2] += a.z; m[3] += a.w; m[4] += b.x; m[5] += b.y;
+            acc[6] += b.z; acc[7] += b.w; acc[8] += c.x; acc[9] += c.y;
+        };
+        for (; k + 4 < cnt; k += 8) {
+            const float4 *r = reinterpret_cast<const float4 *>(base + (size_t)k * 16);
+            const float4 *r2 = reinterpret_cast<const float4 *>(base + (size_t)(k + 4) * 16);
+            const float4 a = r[0], b = r[1], c = r[2], a2 = r2[0], b2 = r2[1], c2 = r2[2];
+            add_row(a, b, c); add_row(a2, b2, c2);
+        }
+        if (k < cnt) {
+            const float4 *r = reinterpret_cast<const float4 *>(base + (size_t)k * 16);
+            add_row(r[0], r[1], r[2]);
+        }
+#else
         for (; k + 4 < cnt; k += 8) {  // rows k and k + 4
             const float2 *r = reinterpret_cast<const float2 *>(base + (size_t)k * FGS_BLEND_ROW_FLOATS);
             const float2 *r2 = reinterpret_cast<const float2 *>(base + (size_t)(k + 4) * FGS_BLEND_ROW_FLOATS);
@@ -199,6 +216,7 @@ __global__ __launch_bounds__(256) void k_row_sum(int32_t total, int32_t N, uint3
             m[0] += a.x; m[1] += a.y; m[2] += bq.x; m[3] += bq.y; m[4] += cq.x; m[5] += cq.y;
             acc[6] += dq.x; acc[7] += dq.y; acc[8] += eq.x; acc[9] += eq.y;
         }
+#endif
         // k_composite_bwd works with alpha / 0.99 and 0.99 x colours: its moment and sum-dG rows carry a factor 0.99, its
         // colour / depth rows 1 / 0.99
         const double ia = 1.0 / (double)0.99f;

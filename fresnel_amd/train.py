@@ -113,6 +113,9 @@ class TrainingConfig:  # subset of TGD:97-162 that this path uses; same names an
     seed: int = 0
     steps_per_epoch: int = 8  # synthetic-data mode only
     num_workers: int = 4      # host threads decoding the NEXT batches (DataLoader(num_workers=4), TGD:1760-1767)
+    hip_graph: bool = False   # replay the whole step (decoder, rasterizer, losses, backward, all-reduce, clip, AdamW) from
+                              # ONE captured HIP graph: the library never allocates or synchronises and the step has no
+                              # host decision left, so it is capturable; pays when the step is host-launch-bound
 
 
 class SyntheticDataset:
@@ -293,11 +296,66 @@ class StepResult:
 
 def make_optimizer(model, cfg: TrainingConfig):
     """AdamW(lr, weight_decay) as TGD:1970, FUSED: one multi-tensor kernel per step, and it takes the skip flag as a
-    device tensor (`found_inf`, the mechanism GradScaler uses), so the NaN/Inf batch skip needs no host decision."""
+    device tensor (`found_inf`, the mechanism GradScaler uses), so the NaN/Inf batch skip needs no host decision.
+    With cfg.hip_graph the learning rate is a device tensor too (capturable): the cosine schedule then reaches a
+    replayed graph by an in-place fill instead of a host scalar baked into the capture."""
+    params = list(model.parameters())
     try:
-        return AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay, fused=True)
+        if cfg.hip_graph and params and params[0].is_cuda:
+            return AdamW(params, lr=torch.tensor(cfg.lr, device=params[0].device), weight_decay=cfg.weight_decay,
+                         fused=True, capturable=True)
+        return AdamW(params, lr=cfg.lr, weight_decay=cfg.weight_decay, fused=True)
     except (RuntimeError, TypeError):  # a device without the fused kernel: plain AdamW, the skip costs one sync
-        return AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+        return AdamW(params, lr=cfg.lr, weight_decay=cfg.weight_decay)
+
+
+class GraphedTrainStep:
+    """train_step captured ONCE in a HIP graph (torch.cuda.CUDAGraph) and replayed per batch: the step's ~200 kernel
+    launches (decoder MLP, the rasterizer's ~20 kernels each way, losses, clip, fused AdamW, the all-reduce) cost one
+    graph launch on the host.  Possible because nothing in the step allocates behind torch's back, synchronises or takes
+    a host decision (the NaN/Inf skip is `found_inf` on the device).  Inputs are copied into static buffers; the
+    StepResult's tensors are static too (overwritten by the next replay -- read them before it).
+    Eager fallback (`matches` is False): a batch of another shape (the epoch's tail batch)."""
+
+    def __init__(self, model, renderer, camera, optimizer, cfg, dp, example_batch, epoch=0, train_res=None):
+        self.static = tuple(torch.empty_like(t) for t in example_batch)
+        for s_, t in zip(self.static, example_batch):
+            s_.copy_(t)
+        args = (model, renderer, camera, self.static, optimizer, cfg, dp)
+        kw = dict(hfts=None, epoch=epoch, train_res=train_res, pose_rng=None, sample_gen=None)
+        # warm-up on a side stream (plan caches, optimizer state, allocator), then put parameters and optimizer state
+        # back: the capture must not cost the run three optimizer steps
+        params = [p.detach().clone() for p in model.parameters()]
+        had_state = len(optimizer.state) > 0
+        saved_state = None
+        if had_state:
+            saved_state = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                           for p, st in optimizer.state.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                train_step(*args, **kw)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), params):
+                p.copy_(q)
+            for p, st in optimizer.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(saved_state[id(p)][k]) if had_state else v.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.result = train_step(*args, **kw)
+
+    def matches(self, batch) -> bool:
+        return all(s_.shape == t.shape and s_.dtype == t.dtype for s_, t in zip(self.static, batch))
+
+    def __call__(self, batch):
+        for s_, t in zip(self.static, batch):
+            s_.copy_(t, non_blocking=True)
+        self.graph.replay()
+        return self.result
 
 
 def train_step(model, renderer, camera, batch, optimizer, cfg: TrainingConfig, dp: DPContext,
@@ -432,6 +490,12 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
         from . import _binding as stage_timers
     history: Dict[str, list] = {}
     epoch_history = []
+    # one captured graph for the whole run: needs a step whose host side is the same every time (no per-batch pose, no
+    # per-epoch Gaussian count / K-subset schedule)
+    use_graph = bool(cfg.hip_graph) and device.type == "cuda" and hfts is None and not cfg.multi_pose_augmentation
+    if cfg.hip_graph and not use_graph and dp.rank == 0:
+        log("  --hip_graph ignored: the step changes from batch to batch (HFTS schedule / per-batch pose) or runs on the CPU")
+    graphed = None
     for epoch in range(start_epoch, cfg.epochs):
         model.train()
         batches = epoch_batches(n_items, cfg.batch_size, dp.world, cfg.seed, epoch)
@@ -447,12 +511,17 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
         t0 = time.perf_counter()
         for bi, batch in enumerate(BatchPrefetcher(data, shards, device, cfg.num_workers)):
             logged = bi % cfg.log_interval == 0
-            if stage_timers is not None and logged:
-                stage_timers.stage_timing_enable(True)
-            res = train_step(model, renderer, camera, batch, optimizer, cfg, dp, hfts=hfts, epoch=epoch,
-                             train_res=train_res, pose_rng=pose_rng, sample_gen=sample_gen)
-            if stage_timers is not None and logged:
-                stage_timers.stage_timing_enable(False)
+            if use_graph and graphed is None and len(shards[bi]) * dp.world == cfg.batch_size:
+                graphed = GraphedTrainStep(model, renderer, camera, optimizer, cfg, dp, batch, epoch=epoch, train_res=train_res)
+            if graphed is not None and graphed.matches(batch):
+                res = graphed(batch)  # (stage timers are event pairs recorded at launch time: not inside a replayed graph)
+            else:
+                if stage_timers is not None and logged:
+                    stage_timers.stage_timing_enable(True)
+                res = train_step(model, renderer, camera, batch, optimizer, cfg, dp, hfts=hfts, epoch=epoch,
+                                 train_res=train_res, pose_rng=pose_rng, sample_gen=sample_gen)
+                if stage_timers is not None and logged:
+                    stage_timers.stage_timing_enable(False)
             ok = 1.0 - res.skipped
             n_ok = n_ok + ok
             for k, v in res.terms.items():  # device-side sums over the batches that were not skipped
@@ -535,6 +604,7 @@ def main(argv=None):
     ap.add_argument("--use_frequency_loss", action="store_true", help="TGD:1498")
     ap.add_argument("--frequency_loss_weight", type=float, default=c.frequency_loss_weight)
     ap.add_argument("--resume", default=None)
+    ap.add_argument("--hip_graph", action="store_true", help="replay the whole training step from one captured HIP graph")
     ap.add_argument("--renderer", default="hip", choices=["hip"],
                     help="only the HIP rasterizer ships; there is no CPU fallback")
     ap.add_argument("--seed", type=int, default=0)
@@ -560,7 +630,7 @@ def main(argv=None):
                          use_phase_retrieval_loss=a.use_phase_retrieval_loss or a.use_qsr,
                          phase_retrieval_weight=a.phase_retrieval_weight,
                          use_frequency_loss=a.use_frequency_loss, frequency_loss_weight=a.frequency_loss_weight,
-                         device=f"cuda:{local_rank}", seed=a.seed)
+                         device=f"cuda:{local_rank}", seed=a.seed, hip_graph=a.hip_graph)
     hfts = HFTSConfig(train_resolution=a.train_resolution, progressive_schedule=a.progressive_schedule,
                       stochastic_k=a.stochastic_k, fast_mode=a.fast_mode)
     dp = DPContext(device=torch.device(cfg.device))

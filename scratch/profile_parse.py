@@ -1,5 +1,5 @@
-"""Collect one run of scratch/profile_r02.sh into <out>/pmc_run.json (merged into profiles/r02_pmc_summary.json
-by scratch/profile_r02_merge.py)."""
+"""Collect one run of scratch/profile_run.sh into <out>/pmc_run.json (merged into profiles/<tag>_pmc_summary.json
+by scratch/profile_merge.py)."""
 import sys, glob, csv, collections, json
 root, key = sys.argv[1], sys.argv[2]
 KEYS = ('k_colfft_fwd', 'k_colfft_bwd', 'k_composite_bwd_phase', 'k_composite_bwd', 'k_blend_fwd_parts', 'k_composite_fwd', 'k_asm_splat', 'k_asm_accumulate_bwd',
@@ -48,6 +48,8 @@ for k in sorted(set(list(acc) + list(stats))):
         row[c if c not in ('FETCH_SIZE', 'WRITE_SIZE') else c + '_KB'] = v / max(len(calls[k][c]), 1)
     if 'FETCH_SIZE_KB' in row and 'WRITE_SIZE_KB' in row:
         row['hbm_bytes_corrected'] = (2 * row['FETCH_SIZE_KB'] + row['WRITE_SIZE_KB']) * 1024
+    if row.get('TCC_HIT_sum') is not None and row.get('TCC_MISS_sum') is not None and row['TCC_HIT_sum'] + row['TCC_MISS_sum'] > 0:
+        row['l2_hit_rate'] = round(row['TCC_HIT_sum'] / (row['TCC_HIT_sum'] + row['TCC_MISS_sum']), 4)
     if row.get('SQ_LDS_IDX_ACTIVE'):
         row['lds_conflict_share'] = round(row.get('SQ_LDS_BANK_CONFLICT', 0.0) / row['SQ_LDS_IDX_ACTIVE'], 4)
     out['kernels'].append(row)
@@ -59,5 +61,5 @@ if field:
 json.dump(out, open(root + '/pmc_run.json', 'w'), indent=1)
 for r in out['kernels']:
     print(r['kernel'], {k: (round(v, 1) if isinstance(v, float) else v) for k, v in r.items() if k in
-                        ('avg_us_kernel_trace', 'hbm_bytes_corrected', 'lds_conflict_share', 'SQ_INSTS_VALU', 'WRITE_SIZE_KB', 'FETCH_SIZE_KB')})
+                        ('avg_us_kernel_trace', 'hbm_bytes_corrected', 'lds_conflict_share', 'SQ_INSTS_VALU', 'WRITE_SIZE_KB', 'FETCH_SIZE_KB', 'l2_hit_rate')})
 print(json.dumps(bench)[:600])

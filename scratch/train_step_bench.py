@@ -9,7 +9,7 @@ import numpy as np, torch
 sys.path.insert(0, '.')
 from fresnel_amd import _binding as B
 from fresnel_amd.dist import DPContext
-from fresnel_amd.train import PatchGaussianDecoder, SyntheticDataset, TrainingConfig, default_renderer_factory, make_optimizer, train_step
+from fresnel_amd.train import GraphedTrainStep, PatchGaussianDecoder, SyntheticDataset, TrainingConfig, default_renderer_factory, make_optimizer, train_step
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device('cuda:0')
@@ -50,8 +50,25 @@ for name, K, S, Bn in (("config2_shape", 6, 256, 16), ("config3_shape", 24, 512,
     st = {k: v[0] / v[1] for k, v in B.stage_timing_read().items() if v[1]}
     B.stage_timing_enable(False)
     ras = sum(st.values())
+    # the same step replayed from ONE captured HIP graph (TrainingConfig.hip_graph)
+    gms = None
+    try:
+        cfg_g = TrainingConfig(batch_size=Bn, image_size=S, gaussians_per_patch=K, device='cuda:0', ssim_weight=0.0, hip_graph=True)
+        opt_g = make_optimizer(model, cfg_g)
+        renderer.pair_counter = None
+        g = GraphedTrainStep(model, renderer, camera, opt_g, cfg_g, dp, batches[0])
+        for i in range(3):
+            g(batches[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            g(batches[i % 4])
+        torch.cuda.synchronize()
+        gms = (time.perf_counter() - t0) / steps * 1e3
+    except Exception as e:  # report, do not hide
+        gms = f"failed: {type(e).__name__}: {e}"
     out[name] = dict(gaussians=37 * 37 * K, resolution=S, images=Bn, step_ms=round(ms, 3), rasterizer_ms=round(ras, 3),
-                     rasterizer_share=round(ras / ms, 3), pairs_per_step=int(P), pairs_per_s=P / (ms * 1e-3),
+                     rasterizer_share=round(ras / ms, 3), step_ms_hip_graph=(round(gms, 3) if isinstance(gms, float) else gms), pairs_per_step=int(P), pairs_per_s=P / (ms * 1e-3),
                      host_syncs_per_step=syncs, stage_ms={k: round(v, 4) for k, v in st.items()},
                      decoder_params=sum(p.numel() for p in model.parameters()), loss=res.to_host())
 print(json.dumps(out))
