@@ -44,6 +44,7 @@ struct AsmPlan {
     size_t v_tw;         // float2 [H/2]            twiddles of the column-fused transforms
     int col_logn;        // log2(H) when the column direction runs in k_colfft_* (H = 64 ... 1024, a power of two), else 0
     int col_tc, col_pg;  // its column tile width, and plane groups per image (> 1 for launches that would not fill the chip)
+    int rows_logw;       // log2(W) when the row direction runs fused with the splat (fgs_asm_rows.h), else 0
     size_t c_accp;       // float2 [B][col_pg][3][H][W] partial plane sums (col_pg > 1)
     size_t v_total_bytes;
     // scratch sections (after base.s_total)
@@ -95,6 +96,21 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
         if (blocks < 512) p->col_pg = (int)((512 + blocks - 1) / blocks);
         if (p->col_pg > (int)P) p->col_pg = (int)P;
     }
+    // Row direction fused with the splat / its adjoint: needs the column kernels (power-of-two height), a power-of-two width
+    // 64 ... 512, and a launch of many short lists (one wave walks a whole list there): (image, plane, tile) lists >= 1024
+    p->rows_logw = 0;
+    // MEASURED IN ROUND 3 AND SWITCHED OFF (FGS_ASM_ROWS=1 builds it in): config 5 at 8 images 2.63 -> 3.33 ms.  The field
+    // stages do get faster (forward 0.84 -> 0.45 ms, backward 0.85 -> 0.52: no rocFFT row passes, empty planes skipped), but
+    // the fused kernels need 133 KB of LDS for the 8-row band, i.e. ONE 16-wave block per CU, and their phases -- the
+    // latency-bound list walk, then the transforms -- run back to back with nothing to overlap them: forward 0.72 ms against
+    // 0.27 (splat) + 0.30 (rocFFT rows), backward 1.50 against 0.60 + 0.33.  The empty-plane skip in the column kernels is
+    // kept for every path (below).
+#ifndef FGS_ASM_ROWS
+#define FGS_ASM_ROWS 0
+#endif
+    if (FGS_ASM_ROWS && p->col_logn && B * P * (size_t)p->base.tiles >= 1024)
+        for (int lg = 6; lg <= 9; ++lg)
+            if (a->width == (1 << lg)) p->rows_logw = lg;
     p->v_total_bytes = o;
     p->work_big = p->work_small = 0;
     if (need_fft) {
@@ -475,12 +491,16 @@ __device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restri
     for (int i = threadIdx.x; i < n; i += NT) tw[i] = tw_g[i];
 }
 
+#include "fgs_asm_rows.h"
+
 // forward: spectra F (in place, for the backward) and acc[b][c] = sum_p F_pc H_pc.  grid (column tiles, 3, B)
+// Planes of image b without any list entry are skipped (`ranges`): their fields are zero (the row-fused build never writes them)
 template <int LOGN, int TC>
 __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(int W, int P, int PG, float2 *__restrict__ field,
                                                                            const float2 *__restrict__ htab,
                                                                            const float2 *__restrict__ tw_g,
-                                                                           float2 *__restrict__ acc) {
+                                                                           float2 *__restrict__ acc,
+                                                                           const uint32_t *__restrict__ ranges, uint32_t tiles) {
     // PG plane groups per image (launches of few images: more blocks, each summing its planes into its own partial
     // acc[(b, group)]; k_sum_groups adds them up): blockIdx.z = b * PG + group
     constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
@@ -493,20 +513,26 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(in
     const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;  // this thread's elements: rows r0 + e * (NT / TC)
     const bool live = c0 + col < W;
     float2 sum[PER], nx[PER];  // nx: the next plane's tile elements, in flight while the current plane is transformed
+    auto next_plane = [&](int q) {  // first plane >= q of this group that has Gaussians (all of them when ranges == nullptr)
+        while (ranges && q < p_hi && asm_plane_empty(ranges, (uint32_t)(b * P + q), tiles)) ++q;
+        return q;
+    };
+    int p = next_plane(p_lo);
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
         sum[e] = make_float2(0.0f, 0.0f);
-        nx[e] = (live && p_lo < p_hi) ? field[(((size_t)b * P + p_lo) * 3 + c) * HW + c0 + col + (size_t)(r0 + e * (NT / TC)) * W]
-                                      : make_float2(0.0f, 0.0f);
+        nx[e] = (live && p < p_hi) ? field[(((size_t)b * P + p) * 3 + c) * HW + c0 + col + (size_t)(r0 + e * (NT / TC)) * W]
+                                   : make_float2(0.0f, 0.0f);
     }
-    for (int p = p_lo; p < p_hi; ++p) {
+    while (p < p_hi) {
+        const int pn = next_plane(p + 1);
         float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
         const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
 #pragma unroll
         for (int e = 0; e < PER; ++e) x[r0 + e * (NT / TC)][col] = nx[e];
         __syncthreads();
-        if (live && p + 1 < p_hi) {
-            const float2 *fn = f + 3 * HW;  // plane p + 1 of this image and channel
+        if (live && pn < p_hi) {
+            const float2 *fn = field + (((size_t)b * P + pn) * 3 + c) * HW + c0 + col;  // the next plane with Gaussians
 #pragma unroll
             for (int e = 0; e < PER; ++e) nx[e] = fn[(size_t)(r0 + e * (NT / TC)) * W];
         }
@@ -526,6 +552,7 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(in
             }
         }
         __syncthreads();
+        p = pn;
     }
     if (live) {
         float2 *a = acc + ((size_t)blockIdx.z * 3 + c) * HW + c0 + col;
@@ -554,7 +581,8 @@ template <int LOGN, int TC>
 __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     int W, int P, int PG, float near_, float far_, float focal, float inv_ndx, float inv_ndy,
     const float *__restrict__ wavelengths, const float2 *__restrict__ gacc, const float2 *__restrict__ htab,
-    const float2 *__restrict__ tw_g, float2 *__restrict__ field, float *__restrict__ pwl) {
+    const float2 *__restrict__ tw_g, float2 *__restrict__ field, float *__restrict__ pwl,
+    const uint32_t *__restrict__ ranges, uint32_t tiles) {
     constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
     __shared__ float2 x[N][TC];
     __shared__ float2 tw[N / 2];
@@ -576,6 +604,8 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     __syncthreads();  // twiddles
     // (requesting the next plane's spectrum before the transform, as the forward does, needs 16 more registers: spills, +10 %)
     for (int p = p_lo; p < p_hi; ++p) {
+        // a plane without Gaussians has a zero spectrum (F = 0: no dL/dlambda term) and nobody reads its gradient
+        if (ranges && asm_plane_empty(ranges, (uint32_t)(b * P + p), tiles)) continue;  // block-uniform
         float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
         const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
         const float z = focal - plane_depth(p, P, near_, far_);
@@ -1030,7 +1060,27 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
                            wavelengths, htab, p.col_logn ? H : 0, reinterpret_cast<float2 *>(sv + p.v_tw));
         FGS_LAUNCH_CHECK("k_asm_prep");
     }
+    const uint32_t *ranges_d = reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges);
+    // the column kernels skip the planes of an image that hold no Gaussian (their fields are zero, or -- row-fused build --
+    // were never written), as the reference skips them (DR:1302)
+    const uint32_t *rows_ranges = ranges_d;
     fgs_stage_begin(ST_SPLAT_FWD, st);
+    if (p.rows_logw) {
+        // splat + row transform in one kernel: the plane fields never exist in HBM (fgs_asm_rows.h)
+#define FGS_SPLAT_ROWS(LW)                                                                                            \
+    hipLaunchKernelGGL((k_asm_splat_rows<LW>), dim3((unsigned)p.base.L.tiles_y, P, B), dim3(ROWS_NT), 0, st,          \
+                       (uint32_t)p.base.tiles, (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)H, ranges_d,        \
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),                                     \
+                       reinterpret_cast<const float *>(sv + p.base.L.rec), ccs, field)
+        switch (p.rows_logw) {
+            case 6: FGS_SPLAT_ROWS(6); break;
+            case 7: FGS_SPLAT_ROWS(7); break;
+            case 8: FGS_SPLAT_ROWS(8); break;
+            default: FGS_SPLAT_ROWS(9); break;
+        }
+#undef FGS_SPLAT_ROWS
+        FGS_LAUNCH_CHECK("k_asm_splat_rows");
+    } else {
 #define FGS_SPLAT_FWD(WV, NPV, DW)                                                                                     \
     hipLaunchKernelGGL((k_asm_splat<false, WV, NPV>), dim3(grid), dim3(64 * NPV), 0, st, (uint32_t)p.base.tiles,       \
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,                              \
@@ -1043,17 +1093,19 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     // one wave per list once the launch has enough lists to fill the chip, else four list parts per list
     if (grid >= ASM_ONE_WAVE_LISTS) FGS_SPLAT_FWD(false, 1, (float2 *)nullptr); else FGS_SPLAT_FWD(false, ASM_FWD_PARTS, (float2 *)nullptr);
     FGS_LAUNCH_CHECK("k_asm_splat");
+    }
     fgs_stage_end(ST_SPLAT_FWD, st);
     fgs_stage_begin(ST_FIELD_FWD, st);
     if (p.col_logn) {
-        // rows by rocFFT, columns + transfer function + plane sum in one pass of our own (k_colfft_fwd)
-        if ((rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
+        // rows by rocFFT (unless fused with the splat), columns + transfer function + plane sum in one pass of our own (k_colfft_fwd)
+        if (!p.rows_logw && (rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
         float2 *tw = reinterpret_cast<float2 *>(sv + p.v_tw);
         float2 *accp = reinterpret_cast<float2 *>(sc + p.c_accp);
         const int PG = p.col_pg;
 #define FGS_COLFFT_FWD(LG, TCV)                                                                                       \
     hipLaunchKernelGGL((k_colfft_fwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B * PG),                    \
-                       dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, PG, field, htab, tw, PG > 1 ? accp : total)
+                       dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, PG, field, htab, tw, PG > 1 ? accp : total,         \
+                       rows_ranges, (uint32_t)p.base.tiles)
         switch (p.col_logn) {
             case 6: FGS_COLFFT_FWD(6, 16); break;
             case 7: FGS_COLFFT_FWD(7, 16); break;
@@ -1131,7 +1183,9 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
         nwl = (unsigned)((W + TCV - 1) / TCV) * (unsigned)(B * p.col_pg);                                             \
         hipLaunchKernelGGL((k_colfft_bwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B * p.col_pg),          \
                            dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, p.col_pg, a.depth_near, a.depth_far,      \
-                           a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, tw, field, pwl);                 \
+                           a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, tw, field, pwl,                  \
+                           reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),                                  \
+                           (uint32_t)p.base.tiles);                                                                   \
     } while (0)
         switch (p.col_logn) {
             case 6: FGS_COLFFT_BWD(6, 16); break;
@@ -1150,7 +1204,9 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     hipLaunchKernelGGL(k_asm_wavelength_grad, dim3(3), dim3(256), 0, st, nwl, pwl, g_wavelengths);
     FGS_LAUNCH_CHECK("k_asm_wavelength_grad");
     // adjoint of the forward FFT is the unnormalised inverse FFT
-    if (p.col_logn) {
+    if (p.rows_logw) {
+        // (the inverse row transform runs inside the splat adjoint, below)
+    } else if (p.col_logn) {
         if ((rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
     } else if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) {
         return rc;
@@ -1159,6 +1215,22 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     fgs_stage_begin(ST_SPLAT_BWD, st);
     const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units
     float *rows = reinterpret_cast<float *>(sc + p.base.s_grows);
+    if (p.rows_logw) {
+#define FGS_ROWS_SPLAT_BWD(LW)                                                                                        \
+    hipLaunchKernelGGL((k_asm_rows_splat_bwd<LW>), dim3((unsigned)p.base.L.tiles_y, P, B), dim3(ROWS_NT), 0, st,      \
+                       (uint32_t)p.base.tiles, (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)H,                  \
+                       (uint32_t)p.base.L.dup_capacity, reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),     \
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),                                     \
+                       reinterpret_cast<const float *>(sv + p.base.L.rec), reinterpret_cast<const float *>(sv + p.v_ccs), \
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows)
+        switch (p.rows_logw) {
+            case 6: FGS_ROWS_SPLAT_BWD(6); break;
+            case 7: FGS_ROWS_SPLAT_BWD(7); break;
+            case 8: FGS_ROWS_SPLAT_BWD(8); break;
+            default: FGS_ROWS_SPLAT_BWD(9); break;
+        }
+#undef FGS_ROWS_SPLAT_BWD
+    } else
     hipLaunchKernelGGL((k_asm_splat<true, false, 1>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
                        (uint32_t)p.base.L.dup_capacity,

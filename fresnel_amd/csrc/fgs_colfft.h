@@ -8,20 +8,22 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a conj(b)
 
-// In-LDS FFT of the TC columns of x[N][TC], N = 2^LOGN, all NT threads of the block; tw = w_N^n, n < N/2, in LDS.
+// In-LDS FFT of TC independent lines of N = 2^LOGN points, element (point r, line col) = X(r, col) -- an accessor, so that
+// callers choose the LDS layout (plain x[N][TC] for the column transforms; a bank-swizzled one for the row transforms of
+// fgs_asm_rows.h); all NT threads of the block; tw = w_N^n, n < N/2, in LDS.
 // INV = false: forward (e^-), decimation in frequency, natural order in, bit-reversed order out.  INV = true: inverse
 // (e^+), decimation in time, bit-reversed order in, natural order out.  Two radix-2 stages per pass over the data
 // (block sizes M and M/2), one more radix-2 pass when LOGN is odd.  (Consecutive lanes = the TC columns of a row, then
 // the next butterfly: a 32-lane group reads two whole rows, conflict-free except in the last pass.)
-template <int LOGN, int TC, int NT, bool INV>
-__device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *tw) {
+template <int LOGN, int TC, int NT, bool INV, class Acc>
+__device__ __forceinline__ void lds_fft_core(Acc X, const float2 *tw) {
     constexpr int N = 1 << LOGN;
-    auto pair_pass = [&]() {  // block size 2: x[2k] = a + b, x[2k+1] = a - b
+    auto pair_pass = [&]() {  // block size 2: point 2k = a + b, point 2k + 1 = a - b
 #pragma unroll 1
         for (int idx = threadIdx.x; idx < (N / 2) * TC; idx += NT) {
             const int col = idx % TC, k = idx / TC;
-            const float2 a = x[2 * k][col], b = x[2 * k + 1][col];
-            x[2 * k][col] = cadd(a, b); x[2 * k + 1][col] = csub(a, b);
+            const float2 a = X(2 * k, col), b = X(2 * k + 1, col);
+            X(2 * k, col) = cadd(a, b); X(2 * k + 1, col) = csub(a, b);
         }
         __syncthreads();
     };
@@ -32,23 +34,23 @@ __device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *t
             const int col = idx % TC, q = idx / TC;
             const int i = q % Q, p0 = (q / Q) * M + i, p1 = p0 + Q, p2 = p0 + 2 * Q, p3 = p0 + 3 * Q;
             const float2 w1 = tw[i * step], w2 = tw[2 * i * step];  // w_M^i, w_M^(2i) = w_(M/2)^i
-            const float2 a0 = x[p0][col], a1 = x[p1][col], a2 = x[p2][col], a3 = x[p3][col];
+            const float2 a0 = X(p0, col), a1 = X(p1, col), a2 = X(p2, col), a3 = X(p3, col);
             if (!INV) {
                 const float2 s02 = cadd(a0, a2), s13 = cadd(a1, a3), d02 = csub(a0, a2), d13 = csub(a1, a3);
                 const float2 u2 = fgs_cmul(d02, w1), u3 = fgs_cmul(make_float2(d13.y, -d13.x), w1);  // w_M^(i + M/4) = -i w_M^i
-                x[p0][col] = cadd(s02, s13);
-                x[p1][col] = fgs_cmul(csub(s02, s13), w2);
-                x[p2][col] = cadd(u2, u3);
-                x[p3][col] = fgs_cmul(csub(u2, u3), w2);
+                X(p0, col) = cadd(s02, s13);
+                X(p1, col) = fgs_cmul(csub(s02, s13), w2);
+                X(p2, col) = cadd(u2, u3);
+                X(p3, col) = fgs_cmul(csub(u2, u3), w2);
             } else {
                 const float2 t1 = cmulc(a1, w2), t3 = cmulc(a3, w2);
                 const float2 r0 = cadd(a0, t1), r1 = csub(a0, t1), r2 = cadd(a2, t3), r3 = csub(a2, t3);
                 const float2 v2 = cmulc(r2, w1), v3t = cmulc(r3, w1);
                 const float2 v3 = make_float2(-v3t.y, v3t.x);  // conj(-i w_M^i) = +i conj(w_M^i)
-                x[p0][col] = cadd(r0, v2);
-                x[p2][col] = csub(r0, v2);
-                x[p1][col] = cadd(r1, v3);
-                x[p3][col] = csub(r1, v3);
+                X(p0, col) = cadd(r0, v2);
+                X(p2, col) = csub(r0, v2);
+                X(p1, col) = cadd(r1, v3);
+                X(p3, col) = csub(r1, v3);
             }
         }
         __syncthreads();
@@ -66,7 +68,7 @@ __device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *t
             const float2 t1 = tw[i * step], t2 = tw[2 * i * step], t4 = tw[4 * i * step];
             float2 a[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a[k] = x[b0 + k * E][col];
+            for (int k = 0; k < 8; ++k) a[k] = X(b0 + k * E, col);
             if (!INV) {
                 float2 s[4], d[4];
 #pragma unroll
@@ -88,8 +90,8 @@ __device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *t
                 }
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
-                    x[b0 + (2 * qd) * E][col] = cadd(b[2 * qd], b[2 * qd + 1]);
-                    x[b0 + (2 * qd + 1) * E][col] = fgs_cmul(csub(b[2 * qd], b[2 * qd + 1]), t4);
+                    X(b0 + (2 * qd) * E, col) = cadd(b[2 * qd], b[2 * qd + 1]);
+                    X(b0 + (2 * qd + 1) * E, col) = fgs_cmul(csub(b[2 * qd], b[2 * qd + 1]), t4);
                 }
             } else {
                 float2 b[8];
@@ -115,8 +117,8 @@ __device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *t
                 d[3] = make_float2(-S * (d[3].x + d[3].y), S * (d[3].x - d[3].y));  // conj(w_8^3)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    x[b0 + k * E][col] = cadd(s[k], d[k]);
-                    x[b0 + (k + 4) * E][col] = csub(s[k], d[k]);
+                    X(b0 + k * E, col) = cadd(s[k], d[k]);
+                    X(b0 + (k + 4) * E, col) = csub(s[k], d[k]);
                 }
             }
         }
@@ -134,6 +136,12 @@ __device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *t
 #pragma unroll
         for (int o = NOCT - 1; o >= 0; --o) oct_pass(1 << (LOGN - 3 * o));
     }
+}
+
+// The same on a plain x[N][TC] tile (column-fused transforms: TC contiguous columns per row, conflict-free by construction).
+template <int LOGN, int TC, int NT, bool INV>
+__device__ __forceinline__ void lds_fft_columns(float2 (*x)[TC], const float2 *tw) {
+    lds_fft_core<LOGN, TC, NT, INV>([x](int r, int col) -> float2 & { return x[r][col]; }, tw);
 }
 
 template <int LOGN>

@@ -320,6 +320,7 @@ def inspect_saved(saved: torch.Tensor, dims) -> dict:
     out["dup_off"] = view(L.dup_off, Bn * N, torch.int32).view(Bn, N)
     out["counters"] = view(L.counters, 16, torch.int32)
     out["ranges"] = view(L.ranges, Bn * T * 2, torch.int32).view(Bn, T, 2)
+    out["tile_order"] = view(L.tile_order, Bn * T, torch.int32)
     out["dup_ids"] = view(L.dup_ids, L.dup_capacity, torch.int32)
     out["pix_state"] = view(L.pix_state, Bn * 6 * dims.height * dims.width, torch.float32).view(
         Bn, 6, dims.height, dims.width)
