@@ -408,7 +408,7 @@ def main(argv=None):
             "project": per_gpu * N * (56 + 48 + 8),
             "depth_sort": per_gpu * N * 8 * (1 + 2 * 4),
             "list_building": per_gpu * N * 8 + 4 * D_local,  # dup_emit + tile_ranges + tile_sort stages together
-            "composite_fwd": per_gpu * (36 * HW) + 52 * D_local + ckpt_bytes * extra_units,  # 5 state planes + rgb + depth out
+            "composite_fwd": per_gpu * ((40 if args.workload == "config4" else 36) * HW) + 52 * D_local + ckpt_bytes * extra_units,  # state planes + rgb + depth out
             "composite_bwd": per_gpu * (36 * HW) + (52 + row_bytes) * D_local + ckpt_bytes * extra_units,
             "project_bwd": row_bytes * D_local + per_gpu * N * 2 * 56,
             "field_fwd": ASM_BYTES_PER_IMAGE * per_gpu, "field_bwd": ASM_BYTES_PER_IMAGE * per_gpu,
