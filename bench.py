@@ -245,6 +245,9 @@ def main(argv=None):
                          "the default leaves every choice to the library)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a 1-GPU box")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="form the process group, barrier and all-reduce even with ONE rank: rehearses the RCCL path "
+                         "(communicator creation, collectives on the compute stream) on a one-GPU box")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="rehearse launcher + rendezvous + collectives on CPU tensors (gloo), no GPU work, no bench line")
     args = ap.parse_args(argv)
@@ -253,7 +256,7 @@ def main(argv=None):
 
     # ---- launcher decision: BEFORE torch / fresnel_amd are imported or any GPU call is made ----
     if "WORLD_SIZE" not in os.environ:
-        if args.gpus > 1:
+        if args.gpus > 1 or args.force_dist:
             sys.exit(launch_ranks(args, argv))
         world, rank, local_rank = 1, 0, 0
     else:
@@ -275,7 +278,7 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)  # pin the rank to its GPU before the process group exists
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)  # nccl IS RCCL on ROCm
@@ -317,7 +320,7 @@ def main(argv=None):
     g = torch.Generator().manual_seed(4242 + rank)
     gI = torch.randn(per_gpu, 3, S, S, generator=g).to(device)
     gD = (torch.randn(per_gpu, S, S, generator=g) * 0.1).to(device)
-    bucket = torch.zeros(DECODER_GRAD_FLOATS, device=device) if world > 1 else None
+    bucket = torch.zeros(DECODER_GRAD_FLOATS, device=device) if dist is not None else None
 
     def step():
         # the nn.Module call the training harness makes (fresnel_amd/train.py train_step): batched tensors, one Camera
@@ -480,7 +483,7 @@ def main(argv=None):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE {args.workload}: {N} Gaussians, {S}x{S}, {per_gpu} images/GPU "
                                    f"({per_gpu * world} global), {dist_name}, rasterizer fwd+bwd through the nn.Module call"
-                                   + (", + all-reduce of the 2.7 MB decoder-grad bucket (" + args.backend + ")" if world > 1 else ""),
+                                   + (", + all-reduce of the 2.7 MB decoder-grad bucket (" + args.backend + ")" if dist is not None else ""),
                        "gaussians": N, "resolution": S, "images_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "distribution": args.distribution, "pairs_per_step": int(pairs_all),
                        "tile_w": tile_w, "tile_duplicates_rank0": D_local, "depth_segments_rank0": U_local,
