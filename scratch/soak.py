@@ -1,7 +1,7 @@
 """Soak: many steps of every path; memory must stay flat and results finite (not a test)."""
 import sys, torch, numpy as np
 sys.path.insert(0, '.')
-import bench
+import bench; bench._import_compute()
 from fresnel_amd import renderer as R
 dev = torch.device('cuda:0')
 def run(tag, n_img, N, S, steps, use_phase=False, skip=False):
