@@ -1,7 +1,7 @@
 import sys, os, time, json, numpy as np, torch
 sys.path.insert(0, '.')
 from fresnel_amd import _binding as B, renderer as R
-import bench
+import bench; bench._import_compute()
 dev = torch.device('cuda:0')
 def run(N, S, nimg, steps=10, warm=3, dist='saag'):
     pos, scale, quat, col, opa = bench.synth_batch(nimg, N, 3000, dev)

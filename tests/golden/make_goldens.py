@@ -23,6 +23,9 @@ Cases:
   G12 caller-side hand-off pieces (HFTSConfig, orbit cameras, ImageDataset)
   G13 mid-size scene: 1024 Gaussians @256x256, radius cap active, several hundred entries per pixel (tile lists of
       >= 4 depth segments): the long accumulation chains are pinned by the reference, not only N <= 400
+  G15 ONE image of the headline configuration (BASELINE config 3: 32 768 Gaussians @512x512, create_dummy_saag distribution)
+      through the reference itself: image / depth rows 0::16 and the gradients of every 8th Gaussian; inputs are regenerated
+      from the seed by tests/helpers.synth_saag
   K1-K4 the randomized sweeps' known kink / conditioning cases (tests/fuzz_cases.py replays the sweep's draws): two
       phase-path scenes and two ASM scenes, each through the reference-derived referee in fp32 and in fp64
   G14 needles / discs at scale ratios 30:1, 100:1, 500:1 through the reference in fp32 AND in fp64 (default dtype
@@ -561,6 +564,33 @@ def midsize_golden():
     save(rec, "G13_midsize1024_256.npz")
 
 
+def config3_image_golden():
+    """G15: the benchmark's own workload under the reference -- one image of config 3 (153 M composited Gaussian-pixels,
+    ~2 minutes and ~12 GB of autograd graph here).  Stored: a subset (rows 0::16 of image / depth, the gradients of every
+    8th Gaussian, the reference's integer stages packed) -- the inputs come from helpers.synth_saag(32768, 1503)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    from helpers import synth_saag
+    R, N, seed = 512, 32768, 1503
+    arrs = [torch.from_numpy(a) for a in synth_saag(N, seed)]
+    # stable=True: ~130 pairs of the 32 768 fp32 depths tie, and the reference's default argsort is not stable (SURVEY 0.5)
+    rec = run_tbr("G15", *arrs, frontal_camera(R), R, R, bg=(0.0, 0.0, 0.0), seed_up=115, stable=True)
+    vis = rec["visible"].astype(bool)
+    bb = rec["bbox"][vis]
+    pairs = int(((bb[:, 1] - bb[:, 0]) * (bb[:, 3] - bb[:, 2])).sum())
+    print(f"G15: visible {int(vis.sum())}, capped {(rec['radii'][vis] >= 64).sum()}, pairs {pairs}")
+    out = dict(name=np.array("G15"), seed=np.int32(seed), num_gaussians=np.int32(N), size=rec["size"], intr=rec["intr"],
+               view=rec["view"], background=rec["background"], seed_up=rec["seed_up"], pairs=np.int64(pairs),
+               rows=np.arange(0, R, 16, dtype=np.int32), image=rec["image"][:, ::16].copy(), depth=rec["depth"][::16].copy(),
+               grad_stride=np.int32(8), visible=np.packbits(rec["visible"]), bbox=rec["bbox"].astype(np.int16),
+               depth_order=rec["depth_order"].astype(np.int32))
+    for n in ("positions", "scales", "rotations", "colors", "opacities"):
+        out["grad_" + n] = rec["grad_" + n][::8].copy()
+        out["gradmax_" + n] = np.float64(np.abs(rec["grad_" + n]).max())  # the tolerance is relative to the FULL tensor's max
+    for k, v in META.items():
+        out["meta_" + k] = np.array(v)
+    save(out, "G15_config3_image_512.npz")
+
+
 def needle_goldens():
     """G14: needles (s, s/r, s/r) and discs (s, s, s/r) at ratio r, reference in fp32 and in fp64.  The fp64 run is
     the reference's own code with torch's default dtype set to float64 and double inputs / view matrix."""
@@ -685,7 +715,9 @@ def kink_goldens():
 
 
 if __name__ == "__main__":
-    if "--kinks-only" in sys.argv:
+    if "--config3-only" in sys.argv:
+        config3_image_golden()
+    elif "--kinks-only" in sys.argv:
         kink_goldens()
     elif "--midsize-only" in sys.argv:
         midsize_golden()
@@ -705,3 +737,4 @@ if __name__ == "__main__":
         midsize_golden()
         needle_goldens()
         kink_goldens()
+        config3_image_golden()
