@@ -12,7 +12,9 @@ __global__ void k_layout(const float *w, const float *c, float *out) {
     for (int r = 0; r < 4; ++r) out[threadIdx.x * 4 + r] = acc[r];
 }
 
-template <bool MFMA>
+typedef float v2f __attribute__((ext_vector_type(2)));
+// KIND 0: four v_fma; 1: one MFMA; 2: two v_pk_fma_f32 written as vector arithmetic; 3: two v_pk_fma_f32 as inline asm with op_sel broadcast of w
+template <int KIND>
 __global__ __launch_bounds__(512) void k_pass(float *out, int entries, const float4 *recs) {
     __shared__ float4 sh[3 * 64];
     __shared__ float shc[64 * 4];
@@ -22,11 +24,12 @@ __global__ __launch_bounds__(512) void k_pass(float *out, int entries, const flo
     const unsigned lane = threadIdx.x & 63u, lx = lane & 7u, ly = lane >> 3;
     float T[4] = {1, 1, 1, 1}, Cr[4] = {0, 0, 0, 0}, Cg[4] = {0, 0, 0, 0}, Cb[4] = {0, 0, 0, 0}, Dm[4] = {0, 0, 0, 0};
     v4f acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    v2f P0[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, P1[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};  // (Cr, Cg), (Cb, D)
     const float fx0 = (float)lx, fx1 = (float)lx + 8.0f, fy0 = (float)ly;
     for (int e = 0; e < entries; ++e) {
         const int j = e & 63;
         const float4 q0 = sh[j], q1 = sh[64 + j], q2 = sh[128 + j];
-        const float cv = MFMA ? shc[4 * j + (lane & 3u)] : 0.0f;  // the colour vector laid across each lane quad
+        const float cv = KIND == 1 ? shc[4 * j + (lane & 3u)] : 0.0f;  // the colour vector laid across each lane quad
         const float dxc[2] = {fx0 - q0.x, fx1 - q0.x};
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
@@ -40,8 +43,16 @@ __global__ __launch_bounds__(512) void k_pass(float *out, int entries, const flo
                 const float G = __builtin_amdgcn_exp2f(t * dx + cyy);
                 const float a1 = __builtin_amdgcn_fmed3f(G * q1.y, 0.0f, 1.0f);
                 const float w = a1 * T[s];
-                if (MFMA) {
+                if (KIND == 1) {
                     acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(w, cv, acc[s], 0, 0, 0);
+                } else if (KIND == 2) {
+                    const v2f wv = {w, w};
+                    P0[s] += wv * v2f{q1.z, q1.w}; P1[s] += wv * v2f{q2.x, q2.y};
+                } else if (KIND == 3) {
+                    v2f wv; wv.x = w;  // .y never read (op_sel_hi picks the low half twice)
+                    const v2f c0 = {q1.z, q1.w}, c1 = {q2.x, q2.y};
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(P0[s]) : "v"(wv), "v"(c0));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(P1[s]) : "v"(wv), "v"(c1));
                 } else {
                     Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
                 }
@@ -50,7 +61,7 @@ __global__ __launch_bounds__(512) void k_pass(float *out, int entries, const flo
         }
     }
     float s = 0;
-    for (int i = 0; i < 4; ++i) s += T[i] + Cr[i] + Cg[i] + Cb[i] + Dm[i] + acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 4; ++i) s += T[i] + Cr[i] + Cg[i] + Cb[i] + Dm[i] + acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + P0[i].x + P0[i].y + P1[i].x + P1[i].y;
     if (s == 1234.5f) out[0] = s;
 }
 
@@ -72,17 +83,20 @@ int main() {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const int entries = 4096;
     for (int rep = 0; rep < 2; ++rep)
-        for (int variant = 0; variant < 2; ++variant) {
+        for (int variant = 0; variant < 4; ++variant) {
             const int blocks = 256 * 4;  // 4 blocks of 8 waves per CU = 8 waves per SIMD
             for (int warm = 0; warm < 2; ++warm) {
                 hipEventRecord(a);
-                if (variant) hipLaunchKernelGGL(k_pass<true>, dim3(blocks), dim3(512), 0, 0, out, entries, recs);
-                else hipLaunchKernelGGL(k_pass<false>, dim3(blocks), dim3(512), 0, 0, out, entries, recs);
+                if (variant == 1) hipLaunchKernelGGL(k_pass<1>, dim3(blocks), dim3(512), 0, 0, out, entries, recs);
+                else if (variant == 2) hipLaunchKernelGGL(k_pass<2>, dim3(blocks), dim3(512), 0, 0, out, entries, recs);
+                else if (variant == 3) hipLaunchKernelGGL(k_pass<3>, dim3(blocks), dim3(512), 0, 0, out, entries, recs);
+                else hipLaunchKernelGGL(k_pass<0>, dim3(blocks), dim3(512), 0, 0, out, entries, recs);
                 hipEventRecord(b); hipEventSynchronize(b);
             }
             float ms; hipEventElapsedTime(&ms, a, b);
             // wave-passes per SIMD: 8 waves x entries x 4 passes
-            printf("%s: %.3f ms, %.2f ns per pass per SIMD (8 waves per SIMD)\n", variant ? "MFMA 4x4x1 colour update" : "VALU (4 v_fma) colour update", ms,
+            static const char *names[4] = {"VALU (4 v_fma) colour update", "MFMA 4x4x1 colour update", "2 v_pk_fma_f32 (vector arithmetic)", "2 v_pk_fma_f32 (asm, op_sel broadcast)"};
+            printf("%s: %.3f ms, %.2f ns per pass per SIMD (8 waves per SIMD)\n", names[variant], ms,
                    ms * 1e6 / (8.0 * entries * 4));
         }
     return 0;
