@@ -140,7 +140,7 @@ class _Cfg:
 
     def __init__(self, width, height, background, max_radius, use_phase, phase_amplitude, saturation_skip=False,
                  tuning=None, pair_counter=None):
-        self.pair_counter = pair_counter  # optional device int64[1]: += composited Gaussian-pixels of every forward
+        self.pair_counter = pair_counter  # optional device int64[1 | 3]: [0] += composited Gaussian-pixels, [1] += tile duplicates, [2] += Gaussians of every forward
         self.saturation_skip = bool(saturation_skip)
         self.tuning = dict(tuning) if tuning else None  # FgsDims.seg_len / fwd_variant / bin_mode overrides
         self.width, self.height = int(width), int(height)
@@ -198,7 +198,11 @@ class GaussianRenderer(torch.autograd.Function):
             # unit of work of SURVEY 8d, counted on the device and accumulated asynchronously (no host sync)
             n = torch.empty(1, dtype=torch.int64, device=pos.device)
             B.check(B.load().fgs_count_pairs(ctypes.byref(dims), _ptr(saved), _ptr(n), _stream_handle()), "fgs_count_pairs")
-            cfg.pair_counter += n
+            cfg.pair_counter[:1] += n
+            if cfg.pair_counter.numel() >= 3:  # [1]: tile duplicates D (saved.counters[0]), [2]: Gaussians -- for the algorithmic HBM bytes
+                L = B.saved_layout(dims)
+                cfg.pair_counter[1:2] += saved[L.counters:L.counters + 4].view(torch.int32).to(torch.int64)
+                cfg.pair_counter[2:3] += int(dims.batch) * int(dims.num_gaussians)
         ctx.dims = dims
         ctx.has_phase = ph is not None
         ctx.save_for_backward(pos, scl, rot, col, opa, ph if ph is not None else pos.new_empty(0),
@@ -260,7 +264,7 @@ class TileBasedRenderer(nn.Module):
         super().__init__()
         self.saturation_skip = saturation_skip  # extension, off by default (see render_batch)
         self.tuning = None  # optional FgsDims work-split overrides (tests / A-B runs); never changes results
-        self.pair_counter = None  # set to a device int64[1] tensor to accumulate composited Gaussian-pixels (metrics)
+        self.pair_counter = None  # set to a device int64[1 | 3] tensor to accumulate composited Gaussian-pixels [, tile duplicates, Gaussians] (metrics)
         self.width = image_width
         self.height = image_height
         self.background = torch.tensor(background)  # plain tensor, as in DR:447

@@ -485,7 +485,7 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
     pair_counter = None
     stage_timers = None
     if device.type == "cuda" and hasattr(renderer, "pair_counter"):
-        pair_counter = torch.zeros(1, dtype=torch.int64, device=device)
+        pair_counter = torch.zeros(3, dtype=torch.int64, device=device)  # [pairs, tile duplicates, Gaussians]
         renderer.pair_counter = pair_counter
         from . import _binding as stage_timers
     history: Dict[str, list] = {}
@@ -535,11 +535,11 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
                         log(f"  Batch {bi}/{len(shards)} | Loss: {ld['total']:.4f} | RGB: {ld['rgb']:.4f}")
         scheduler.step()
         keys = sorted(acc)
-        extra = [pair_counter[0].float()] if pair_counter is not None else []
-        vals = torch.stack([acc[k] for k in keys] + [n_ok] + extra).double()
+        extra = [pair_counter[i].double() for i in range(3)] if pair_counter is not None else []
+        vals = torch.stack([acc[k].double() for k in keys] + [n_ok.double()] + extra)
         if dp.enabled and pair_counter is not None:
-            import torch.distributed as tdist  # whole-job pair count (the losses are this rank's shard, as before)
-            tdist.all_reduce(vals[-1:], op=tdist.ReduceOp.SUM)
+            import torch.distributed as tdist  # whole-job pair / duplicate counts (the losses are this rank's shard, as before)
+            tdist.all_reduce(vals[-3:], op=tdist.ReduceOp.SUM)
         vals = vals.tolist()  # epoch end: one transfer (also the sync that closes the epoch's clock)
         elapsed = time.perf_counter() - t0
         nb = vals[len(keys)]
@@ -548,7 +548,14 @@ def run_training(cfg: TrainingConfig, dp: Optional[DPContext] = None,
         steps = max(len(shards), 1)
         metrics = {"step_ms": elapsed / steps * 1e3, "skipped_batches": len(shards) - int(nb)}
         if pair_counter is not None:
-            metrics["pairs_per_s"] = vals[-1] / max(elapsed, 1e-9)
+            pairs, dups, gauss = vals[-3], vals[-2], vals[-1]
+            metrics["pairs_per_s"] = pairs / max(elapsed, 1e-9)
+            # ALGORITHMIC HBM bytes of the rasterizer per second, whole job, forward + backward: the per-stage figures of
+            # DESIGN.md section 4 / bench.py -- 304 B per Gaussian (projection 112, depth sort 72, lists 8, projection
+            # adjoint 112), 188 B per tile duplicate (lists 4, record gather 52 + 52, gradient row 40 + 40) and 72 B per
+            # pixel (state, outputs, upstream gradients) -- over the epoch's wall time (which includes the decoder)
+            n_img = sum(len(sh) for sh in shards) * dp.world
+            metrics["hbm_gbs_algorithmic"] = (304.0 * gauss + 188.0 * dups + 72.0 * n_img * train_res * train_res) / max(elapsed, 1e-9) / 1e9
             st = stage_timers.stage_timing_read()
             metrics["stage_ms"] = {k: v[0] / v[1] for k, v in st.items() if v[1]}
         for k, v in list(losses.items()) + list(metrics.items()):

@@ -172,7 +172,7 @@ def test_harness_writes_history_with_pairs_per_second_and_stage_ms(tmp_path):
     seen = []
     run_training(cfg, log=lambda *a: seen.append(" ".join(str(x) for x in a)))
     h = json.load(open(tmp_path / "training_history_exp2.json"))
-    assert len(h["total"]) == 2 and len(h["pairs_per_s"]) == 2 and all(v > 0 for v in h["pairs_per_s"])
+    assert len(h["total"]) == 2 and len(h["pairs_per_s"]) == 2 and all(v > 0 for v in h["pairs_per_s"]) and all(v > 0 for v in h["hbm_gbs_algorithmic"])
     assert {"composite_fwd", "composite_bwd", "project"} <= set(h["stage_ms"]) and h["skipped_batches"] == [0, 0]
     assert any(s.strip().startswith("Batch 0/3") for s in seen) and any("Batch 2/3" in s for s in seen)
 
