@@ -142,7 +142,8 @@ def render_wave(pos, scale, quat, color, opacity, phases, cam, bg=(0.0, 0.0, 0.0
         loss = (img * torch.tensor(grad_out, dtype=dtype)).sum()
         if grad_depth is not None:
             loss = loss + (dmap * torch.tensor(grad_depth, dtype=dtype)).sum()
-        loss.backward()
+        if loss.requires_grad:  # (no visible Gaussian: the image is a constant, every gradient is zero)
+            loss.backward()
         z = lambda x: np.zeros_like(np.asarray(x.detach()), dtype=np.float32) if x.grad is None else x.grad.float().numpy()
         import ctypes
         g_pos, g_scale, g_quat = np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32)

@@ -26,7 +26,7 @@ Cases:
   G15 ONE image of the headline configuration (BASELINE config 3: 32 768 Gaussians @512x512, create_dummy_saag distribution)
       through the reference itself: image / depth rows 0::16 and the gradients of every 8th Gaussian; inputs are regenerated
       from the seed by tests/helpers.synth_saag
-  K1-K4 the randomized sweeps' known kink / conditioning cases (tests/fuzz_cases.py replays the sweep's draws): two
+  K1-K5 the randomized sweeps' known kink / conditioning cases (tests/fuzz_cases.py replays the sweep's draws): two
       phase-path scenes and two ASM scenes, each through the reference-derived referee in fp32 and in fp64
   G14 needles / discs at scale ratios 30:1, 100:1, 500:1 through the reference in fp32 AND in fp64 (default dtype
       switched to float64 in this harness): which gradients are well-conditioned enough for a 1e-4 statement
@@ -681,7 +681,7 @@ def kink_goldens():
         rec["sweep"] = np.array(f"fuzz_phase seed {seed} it {it}")
         print(tag, {n: f"{np.abs(rec['f32_grad_' + n] - rec['f64_grad_' + n]).max() / np.abs(rec['f64_grad_' + n]).max():.1e}" for n in names})
         save(rec, f"{tag}_phase_kink_s{seed}_it{it}.npz")
-    for tag, seed, it in (("K3", 3, 10), ("K4", 5, 8)):
+    for tag, seed, it in (("K3", 3, 10), ("K4", 5, 8), ("K5", 8, 0)):  # K5: found by the round-3 sweep on the same build
         c = [c for c in asm_cases(seed) if c["it"] == it][0]
         assert c["kind"] == "asm"
         W, H, bg, kw = c["W"], c["H"], c["bg"], c["kw"]

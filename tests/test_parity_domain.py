@@ -11,7 +11,7 @@ randomized sweeps flagged, each checked on the CPU (oracle) and on the GPU (HIP 
   G15  ONE IMAGE OF THE HEADLINE WORKLOAD under the reference: BASELINE config 3 (32 768 Gaussians @ 512^2, create_dummy_saag
        distribution, 153 M composited Gaussian-pixels), image / depth rows 0::16 and the gradients of every 8th Gaussian; the
        GPU test puts it into the benchmark's own 8-image launch (32 x 16 tiles, four list parts, 128-entry segments).
-  K1-K4 the four sweep cases above 1e-4 (phase-recurrence kinks, strongly interfering ASM scenes), replayed from their
+  K1-K5 the four sweep cases above 1e-4 (phase-recurrence kinks, strongly interfering ASM scenes), replayed from their
        (seed, iteration) with the reference-derived referee in fp32 and fp64.
 """
 import numpy as np
@@ -23,7 +23,7 @@ from helpers import (assert_with_referee, load_golden, oracle_camera, referee, r
 NAMES = ["positions", "scales", "rotations", "colors", "opacities"]
 G14 = ["G14_needles_r30_96", "G14_needles_r100_96", "G14_needles_r500_96"]
 K_PHASE = ["K1_phase_kink_s2_it12", "K2_phase_kink_s1_it23"]
-K_ASM = ["K3_asm_kink_s3_it10", "K4_asm_kink_s5_it8"]
+K_ASM = ["K3_asm_kink_s3_it10", "K4_asm_kink_s5_it8", "K5_asm_kink_s8_it0"]
 
 
 def _arrs(g):
