@@ -697,15 +697,23 @@ __device__ __forceinline__ void pixel_forward(const float2 u[3], float inv_hw, f
 __global__ __launch_bounds__(256) void k_asm_output(size_t HW, float inv_hw, float bg0, float bg1, float bg2,
                                                     const float2 *__restrict__ total,
                                                     const float *__restrict__ pmax, float *__restrict__ scal,
-                                                    float *__restrict__ out) {
+                                                    float *__restrict__ out, const uint32_t *__restrict__ ranges,
+                                                    uint32_t lists_per_image) {
     const int b = blockIdx.y;
     const float maxval = image_max(pmax, b);
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[b] = maxval;  // kept for the backward
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
+    const float bg[3] = {bg0, bg1, bg2};
+    if (asm_plane_empty(ranges, (uint32_t)b, lists_per_image)) {
+        // no visible Gaussian in this image (visible <=> at least one list entry): the reference returns the plain
+        // background (DR:1207-1212), not sqrt(0 + 1e-8) pushed through the normalisation; all gradients are zero by themselves
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((size_t)b * 3 + c) * HW + i] = bg[c];
+        return;
+    }
     const float2 u[3] = {total[((size_t)b * 3 + 0) * HW + i], total[((size_t)b * 3 + 1) * HW + i],
                          total[((size_t)b * 3 + 2) * HW + i]};
-    const float bg[3] = {bg0, bg1, bg2};
     PixOut o;
     pixel_forward(u, inv_hw, maxval, bg, o);
 #pragma unroll
@@ -885,15 +893,22 @@ __global__ __launch_bounds__(256) void k_wave_max(size_t HW, const float2 *__res
 __global__ __launch_bounds__(256) void k_wave_output(size_t HW, float bg0, float bg1, float bg2,
                                                      const float2 *__restrict__ field, const float2 *__restrict__ dw,
                                                      const float *__restrict__ pmax, float *__restrict__ scal,
-                                                     float *__restrict__ out, float *__restrict__ out_depth) {
+                                                     float *__restrict__ out, float *__restrict__ out_depth,
+                                                     const uint32_t *__restrict__ ranges, uint32_t lists_per_image) {
     const int b = blockIdx.y;
     const float maxval = image_max(pmax, b);
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[b] = maxval;  // kept for the backward
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
+    const float bg[3] = {bg0, bg1, bg2};
+    if (asm_plane_empty(ranges, (uint32_t)b, lists_per_image)) {  // no visible Gaussian: plain background, zero depth (DR:801-808)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((size_t)b * 3 + c) * HW + i] = bg[c];
+        out_depth[(size_t)b * HW + i] = 0.0f;
+        return;
+    }
     const float2 u[3] = {field[((size_t)b * 3 + 0) * HW + i], field[((size_t)b * 3 + 1) * HW + i],
                          field[((size_t)b * 3 + 2) * HW + i]};
-    const float bg[3] = {bg0, bg1, bg2};
     WavePix o;
     wave_pixel_forward(u, maxval, bg, o);
 #pragma unroll
@@ -1132,7 +1147,8 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     hipLaunchKernelGGL(k_asm_max, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, inv_hw, total, pmax);
     FGS_LAUNCH_CHECK("k_asm_max");
     hipLaunchKernelGGL(k_asm_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, inv_hw,
-                       a.background[0], a.background[1], a.background[2], total, pmax, scal, out_rgb);
+                       a.background[0], a.background[1], a.background[2], total, pmax, scal, out_rgb, ranges_d,
+                       (uint32_t)P * (uint32_t)p.base.tiles);
     FGS_LAUNCH_CHECK("k_asm_output");
     fgs_stage_end(ST_FIELD_FWD, st);
     return FGS_OK;
@@ -1295,7 +1311,8 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
     hipLaunchKernelGGL(k_wave_max, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, field, pmax);
     FGS_LAUNCH_CHECK("k_wave_max");
     hipLaunchKernelGGL(k_wave_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, p.w.background[0],
-                       p.w.background[1], p.w.background[2], field, dw, pmax, scal, out_rgb, out_depth);
+                       p.w.background[1], p.w.background[2], field, dw, pmax, scal, out_rgb, out_depth,
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges), (uint32_t)p.base.tiles);
     FGS_LAUNCH_CHECK("k_wave_output");
     fgs_stage_end(ST_FIELD_FWD, st);
     return FGS_OK;

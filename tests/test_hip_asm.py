@@ -438,3 +438,43 @@ def test_two_streams_same_shape_are_independent():
         torch.cuda.synchronize()
         for k in range(2):
             assert torch.equal(outs[k][0], seq[k][0]) and torch.equal(outs[k][1], seq[k][1]), (trial, k)
+
+
+@pytest.mark.parametrize("kind", ["asm", "wave"])
+def test_zero_visible_images_return_the_plain_background(kind):
+    """DR:801-808 / DR:1207-1212: with no visible Gaussian both wave renderers return the background itself (not
+    sqrt(0 + 1e-8) pushed through the normalisation) and zero gradients -- per image of a batch: image 0 sits behind the
+    camera, image 1 is an ordinary scene and must be unaffected."""
+    from fresnel_amd.renderer import ASMWaveFieldRenderer, Camera, WaveFieldRenderer
+    dev = _cuda()
+    W, H, N = 64, 64, 120
+    a0, a1 = list(synth_aniso(N, 31)), list(synth_aniso(N, 32))
+    a0[0] = a0[0].copy(); a0[0][:, 2] += 5.0  # z ~ +3: behind the camera
+    arrs = [np.stack([x, y]) for x, y in zip(a0, a1)]
+    rs = np.random.RandomState(4)
+    ph = (rs.rand(2, N) * 6.28).astype(np.float32)
+    bg = (0.0, 0.25, 0.5)
+    ts = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in arrs]
+    pht = torch.from_numpy(ph).to(dev).requires_grad_(True)
+    cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    if kind == "asm":
+        ren = ASMWaveFieldRenderer(W, H, background=bg).to(dev)
+        img = ren(*ts, cam, phases=pht, wavelengths_rgb=torch.tensor([0.0635, 0.05, 0.041], device=dev))
+        dep = None
+    else:
+        img, dep = WaveFieldRenderer(W, H, background=bg).to(dev)(*ts, cam, return_depth=True, phases=pht)
+    img.sum().backward()
+    for c in range(3):
+        assert torch.all(img[0, c] == bg[c]), "image without visible Gaussians must be the background exactly"
+    if dep is not None:
+        assert torch.all(dep[0] == 0)
+    assert float((img[1] - torch.tensor(bg, device=dev).view(3, 1, 1)).abs().max()) > 1e-2   # image 1 renders normally
+    for t in ts + [pht]:
+        assert torch.isfinite(t.grad).all() and not t.grad[0].any()                            # zero gradients for image 0
+        assert t.grad[1].any()
+    # and the single-image case against the oracle of image 1
+    from oracle import asm_oracle, fgs_oracle as orc
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), cam.fx, cam.fy, cam.cx, cam.cy, W, H)
+    if kind == "wave":
+        r = asm_oracle.render_wave(*a1, ph[1], ocam, bg=bg)
+        assert np.abs(img[1].detach().cpu().numpy() - r["image"]).max() <= TOL
