@@ -494,13 +494,13 @@ __device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restri
 #include "fgs_asm_rows.h"
 
 // forward: spectra F (in place, for the backward) and acc[b][c] = sum_p F_pc H_pc.  grid (column tiles, 3, B)
-// Planes of image b without any list entry are skipped (`ranges`): their fields are zero (the row-fused build never writes them)
+// Planes of image b without any list entry are skipped (`seg_off`, see asm_plane_empty): their fields are zero (the row-fused build never writes them)
 template <int LOGN, int TC>
 __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(int W, int P, int PG, float2 *__restrict__ field,
                                                                            const float2 *__restrict__ htab,
                                                                            const float2 *__restrict__ tw_g,
                                                                            float2 *__restrict__ acc,
-                                                                           const uint32_t *__restrict__ ranges, uint32_t tiles) {
+                                                                           const uint32_t *__restrict__ seg_off, uint32_t tiles) {
     // PG plane groups per image (launches of few images: more blocks, each summing its planes into its own partial
     // acc[(b, group)]; k_sum_groups adds them up): blockIdx.z = b * PG + group
     constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
@@ -513,8 +513,8 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(in
     const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;  // this thread's elements: rows r0 + e * (NT / TC)
     const bool live = c0 + col < W;
     float2 sum[PER], nx[PER];  // nx: the next plane's tile elements, in flight while the current plane is transformed
-    auto next_plane = [&](int q) {  // first plane >= q of this group that has Gaussians (all of them when ranges == nullptr)
-        while (ranges && q < p_hi && asm_plane_empty(ranges, (uint32_t)(b * P + q), tiles)) ++q;
+    auto next_plane = [&](int q) {  // first plane >= q of this group that has Gaussians (all of them when seg_off == nullptr)
+        while (seg_off && q < p_hi && asm_plane_empty(seg_off, (uint32_t)(b * P + q), tiles)) ++q;
         return q;
     };
     int p = next_plane(p_lo);
@@ -582,7 +582,7 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     int W, int P, int PG, float near_, float far_, float focal, float inv_ndx, float inv_ndy,
     const float *__restrict__ wavelengths, const float2 *__restrict__ gacc, const float2 *__restrict__ htab,
     const float2 *__restrict__ tw_g, float2 *__restrict__ field, float *__restrict__ pwl,
-    const uint32_t *__restrict__ ranges, uint32_t tiles) {
+    const uint32_t *__restrict__ seg_off, uint32_t tiles) {
     constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
     __shared__ float2 x[N][TC];
     __shared__ float2 tw[N / 2];
@@ -605,7 +605,7 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     // (requesting the next plane's spectrum before the transform, as the forward does, needs 16 more registers: spills, +10 %)
     for (int p = p_lo; p < p_hi; ++p) {
         // a plane without Gaussians has a zero spectrum (F = 0: no dL/dlambda term) and nobody reads its gradient
-        if (ranges && asm_plane_empty(ranges, (uint32_t)(b * P + p), tiles)) continue;  // block-uniform
+        if (seg_off && asm_plane_empty(seg_off, (uint32_t)(b * P + p), tiles)) continue;  // block-uniform
         float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
         const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
         const float z = focal - plane_depth(p, P, near_, far_);
@@ -697,7 +697,7 @@ __device__ __forceinline__ void pixel_forward(const float2 u[3], float inv_hw, f
 __global__ __launch_bounds__(256) void k_asm_output(size_t HW, float inv_hw, float bg0, float bg1, float bg2,
                                                     const float2 *__restrict__ total,
                                                     const float *__restrict__ pmax, float *__restrict__ scal,
-                                                    float *__restrict__ out, const uint32_t *__restrict__ ranges,
+                                                    float *__restrict__ out, const uint32_t *__restrict__ seg_off,
                                                     uint32_t lists_per_image) {
     const int b = blockIdx.y;
     const float maxval = image_max(pmax, b);
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void k_asm_output(size_t HW, float inv_hw, flo
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
     const float bg[3] = {bg0, bg1, bg2};
-    if (asm_plane_empty(ranges, (uint32_t)b, lists_per_image)) {
+    if (asm_plane_empty(seg_off, (uint32_t)b, lists_per_image)) {
         // no visible Gaussian in this image (visible <=> at least one list entry): the reference returns the plain
         // background (DR:1207-1212), not sqrt(0 + 1e-8) pushed through the normalisation; all gradients are zero by themselves
 #pragma unroll
@@ -894,14 +894,14 @@ __global__ __launch_bounds__(256) void k_wave_output(size_t HW, float bg0, float
                                                      const float2 *__restrict__ field, const float2 *__restrict__ dw,
                                                      const float *__restrict__ pmax, float *__restrict__ scal,
                                                      float *__restrict__ out, float *__restrict__ out_depth,
-                                                     const uint32_t *__restrict__ ranges, uint32_t lists_per_image) {
+                                                     const uint32_t *__restrict__ seg_off, uint32_t lists_per_image) {
     const int b = blockIdx.y;
     const float maxval = image_max(pmax, b);
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[b] = maxval;  // kept for the backward
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= HW) return;
     const float bg[3] = {bg0, bg1, bg2};
-    if (asm_plane_empty(ranges, (uint32_t)b, lists_per_image)) {  // no visible Gaussian: plain background, zero depth (DR:801-808)
+    if (asm_plane_empty(seg_off, (uint32_t)b, lists_per_image)) {  // no visible Gaussian: plain background, zero depth (DR:801-808)
 #pragma unroll
         for (int c = 0; c < 3; ++c) out[((size_t)b * 3 + c) * HW + i] = bg[c];
         out_depth[(size_t)b * HW + i] = 0.0f;
@@ -1078,14 +1078,14 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     const uint32_t *ranges_d = reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges);
     // the column kernels skip the planes of an image that hold no Gaussian (their fields are zero, or -- row-fused build --
     // were never written), as the reference skips them (DR:1302)
-    const uint32_t *rows_ranges = ranges_d;
+    const uint32_t *seg_off_d = reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off);
     fgs_stage_begin(ST_SPLAT_FWD, st);
     if (p.rows_logw) {
         // splat + row transform in one kernel: the plane fields never exist in HBM (fgs_asm_rows.h)
 #define FGS_SPLAT_ROWS(LW)                                                                                            \
     hipLaunchKernelGGL((k_asm_splat_rows<LW>), dim3((unsigned)p.base.L.tiles_y, P, B), dim3(ROWS_NT), 0, st,          \
                        (uint32_t)p.base.tiles, (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)H, ranges_d,        \
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),                                     \
+                       seg_off_d, reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),                          \
                        reinterpret_cast<const float *>(sv + p.base.L.rec), ccs, field)
         switch (p.rows_logw) {
             case 6: FGS_SPLAT_ROWS(6); break;
@@ -1120,7 +1120,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
 #define FGS_COLFFT_FWD(LG, TCV)                                                                                       \
     hipLaunchKernelGGL((k_colfft_fwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B * PG),                    \
                        dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, PG, field, htab, tw, PG > 1 ? accp : total,         \
-                       rows_ranges, (uint32_t)p.base.tiles)
+                       seg_off_d, (uint32_t)p.base.tiles)
         switch (p.col_logn) {
             case 6: FGS_COLFFT_FWD(6, 16); break;
             case 7: FGS_COLFFT_FWD(7, 16); break;
@@ -1147,7 +1147,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     hipLaunchKernelGGL(k_asm_max, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, inv_hw, total, pmax);
     FGS_LAUNCH_CHECK("k_asm_max");
     hipLaunchKernelGGL(k_asm_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, inv_hw,
-                       a.background[0], a.background[1], a.background[2], total, pmax, scal, out_rgb, ranges_d,
+                       a.background[0], a.background[1], a.background[2], total, pmax, scal, out_rgb, seg_off_d,
                        (uint32_t)P * (uint32_t)p.base.tiles);
     FGS_LAUNCH_CHECK("k_asm_output");
     fgs_stage_end(ST_FIELD_FWD, st);
@@ -1200,7 +1200,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
         hipLaunchKernelGGL((k_colfft_bwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B * p.col_pg),          \
                            dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, p.col_pg, a.depth_near, a.depth_far,      \
                            a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, tw, field, pwl,                  \
-                           reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),                                  \
+                           reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),                                 \
                            (uint32_t)p.base.tiles);                                                                   \
     } while (0)
         switch (p.col_logn) {
@@ -1236,6 +1236,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     hipLaunchKernelGGL((k_asm_rows_splat_bwd<LW>), dim3((unsigned)p.base.L.tiles_y, P, B), dim3(ROWS_NT), 0, st,      \
                        (uint32_t)p.base.tiles, (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)H,                  \
                        (uint32_t)p.base.L.dup_capacity, reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),     \
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),                                     \
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),                                     \
                        reinterpret_cast<const float *>(sv + p.base.L.rec), reinterpret_cast<const float *>(sv + p.v_ccs), \
                        reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows)
@@ -1312,7 +1313,7 @@ int fgs_wave_forward(const FgsWaveDims *dims, const float *cameras, const float 
     FGS_LAUNCH_CHECK("k_wave_max");
     hipLaunchKernelGGL(k_wave_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, p.w.background[0],
                        p.w.background[1], p.w.background[2], field, dw, pmax, scal, out_rgb, out_depth,
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges), (uint32_t)p.base.tiles);
+                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off), (uint32_t)p.base.tiles);
     FGS_LAUNCH_CHECK("k_wave_output");
     fgs_stage_end(ST_FIELD_FWD, st);
     return FGS_OK;

@@ -38,11 +38,12 @@ __device__ __forceinline__ int rows_slot(int r, int line) {
     return r * ROWS_PITCH + ((line + 8 * (r & 7) + ((r >> 3) & 7) + 4 * (r >> 6)) & (ROWS_PITCH - 1));
 }
 
-// an (image, plane) pair with no list entry at all: lists are stored in key order (key = (b P + p) T + t), so the pair's
-// storage is [start of its first list, end of its last)
-__device__ __forceinline__ bool asm_plane_empty(const uint32_t *__restrict__ ranges, uint32_t bp, uint32_t tiles) {
-    const uint32_t k0 = bp * tiles;
-    return ranges[2 * k0] == ranges[2 * (k0 + tiles - 1) + 1];
+// an (image, plane) pair -- or, with `tiles` = lists per image, an image -- with no list entry at all: seg_off is the
+// exclusive scan of every list's depth-segment count in key order (key = (b P + p) T + t; k_tile_post writes it on both
+// list-building paths, [lists + 1] entries), so a key range without entries is a range without units.  (NOT `ranges`: the
+// radix path leaves the ranges of empty lists zeroed.)
+__device__ __forceinline__ bool asm_plane_empty(const uint32_t *__restrict__ seg_off, uint32_t bp, uint32_t tiles) {
+    return seg_off[(size_t)(bp + 1u) * tiles] == seg_off[(size_t)bp * tiles];
 }
 
 template <int LOGW>
@@ -58,14 +59,14 @@ __device__ __forceinline__ void rows_twiddles(float2 *tw) {
 template <int LOGW>
 __global__ __launch_bounds__(ROWS_NT) void k_asm_splat_rows(
     uint32_t tiles, uint32_t tiles_x, uint32_t P, uint32_t H, const uint32_t *__restrict__ ranges,
-    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ ccs,
-    float2 *__restrict__ field) {
+    const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec,
+    const float *__restrict__ ccs, float2 *__restrict__ field) {
     constexpr int W = 1 << LOGW, TXN = W / 16, TPW = (TXN + 15) / 16;
     static_assert(LOGW >= 6 && LOGW <= ROWS_MAX_LOGW, "row-fused splat: widths 64 ... 512");
     __shared__ __attribute__((aligned(16))) float2 xs[rows_lds_float2<LOGW, ROWS_STG_FWD>()];
     __shared__ float2 tw[W / 2];
     const uint32_t ty = blockIdx.x, p = blockIdx.y, b = blockIdx.z, bp = b * P + p;
-    if (asm_plane_empty(ranges, bp, tiles)) return;
+    if (asm_plane_empty(seg_off, bp, tiles)) return;
     rows_twiddles<LOGW>(tw);
     const uint32_t lane = threadIdx.x & 63u, lx = lane & 7u, ly = lane >> 3;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -163,13 +164,14 @@ __global__ __launch_bounds__(ROWS_NT) void k_asm_splat_rows(
 template <int LOGW>
 __global__ __launch_bounds__(ROWS_NT) void k_asm_rows_splat_bwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t P, uint32_t H, uint32_t dcap, const uint32_t *__restrict__ ranges,
-    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ ccs,
+    const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec,
+    const float *__restrict__ ccs,
     const uint32_t *__restrict__ dup_off, const float2 *__restrict__ field, float *__restrict__ grad_rows) {
     constexpr int W = 1 << LOGW, TXN = W / 16, TPW = (TXN + 15) / 16;
     __shared__ __attribute__((aligned(16))) float2 xs[rows_lds_float2<LOGW, ROWS_STG_BWD>()];
     __shared__ float2 tw[W / 2];
     const uint32_t ty = blockIdx.x, p = blockIdx.y, b = blockIdx.z, bp = b * P + p;
-    if (asm_plane_empty(ranges, bp, tiles)) return;
+    if (asm_plane_empty(seg_off, bp, tiles)) return;
     rows_twiddles<LOGW>(tw);
     const uint32_t lane = threadIdx.x & 63u, lx = lane & 7u, ly = lane >> 3;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
