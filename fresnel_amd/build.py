@@ -72,14 +72,20 @@ def build(force=False, verbose=False, defines=(), suffix=""):
         if not os.path.exists(src):
             continue
         obj = os.path.join(OBJ_DIR, os.path.splitext(name)[0] + ".o")
-        if force or _newer(src, obj) or os.path.getmtime(obj) < hdr_time:
-            # experiment builds: FGS_BUILD_EXTRA_<FILE STEM> = extra compiler flags for one file (e.g. scheduler options)
-            more = os.environ.get("FGS_BUILD_EXTRA_" + name.split(".")[0].upper(), "").split()
-            common = COMMON if name.endswith(".hip") else [c for c in COMMON if "offload" not in c and "gpu-rdc" not in c]
-            cmd = [hipcc] + common + extra + more + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
+        # experiment builds: FGS_BUILD_EXTRA_<FILE STEM> = extra compiler flags for one file (e.g. scheduler options)
+        more = os.environ.get("FGS_BUILD_EXTRA_" + name.split(".")[0].upper(), "").split()
+        common = COMMON if name.endswith(".hip") else [c for c in COMMON if "offload" not in c and "gpu-rdc" not in c]
+        cmd = [hipcc] + common + extra + more + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
+        # an object is stale when its source or a header is newer OR when it was compiled with another command line (the
+        # flags live in this file: editing them must rebuild)
+        stamp = obj + ".cmd"
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if force or not same_cmd or _newer(src, obj) or os.path.getmtime(obj) < hdr_time:
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+            with open(stamp, "w") as f:
+                f.write(" ".join(cmd))
             rebuilt = True
         objs.append(obj)
     if rebuilt or not os.path.exists(LIB):
