@@ -384,6 +384,17 @@ def main(argv=None):
                 step()
             torch.cuda.synchronize()
             spinup_steps += 10
+        # the per-stage split of the line at the same sustained clocks: ten more untimed steps with every stage bracketed
+        B.stage_timing_enable(True)
+        B.stage_timing_read()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        spin_stage = B.stage_timing_read()
+        B.stage_timing_enable(False)
+        spinup_steps += 10
+        warm_avg = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in spin_stage.items()}
+        dom_stage = max(reversed(compute_stages), key=lambda k: warm_avg.get(k, 0.0))
     B.stage_timing_enable(True, stages=[dom_stage])
     B.stage_timing_read()
     if dist is not None:
@@ -484,7 +495,8 @@ def main(argv=None):
                 stages[name] = r
         roofline["stages"] = stages
         roofline["stage_avg_ms"] = {k: round(v, 4) for k, v in avg_ms.items() if v > 0}
-        roofline["stage_avg_ms_note"] = "dominant kernel: timed region; other stages: warm-up steps of this run (every stage bracketed)"
+        roofline["stage_avg_ms_note"] = ("dominant kernel: timed region; other stages: ten untimed steps of this run with every stage "
+                                         "bracketed, taken after the clock spin-up (the W warm-up steps when --spinup-ms 0)")
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             cpu_baseline = cpu_baseline_leg(leaves, gI, gD, N, S)

@@ -16,7 +16,7 @@ for grp in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" 
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $OUT/g$i.log 2>&1 || { echo "$KEY pmc group $i failed"; tail -5 $OUT/g$i.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py $ARGS --steps 3 --warmup 1 --spinup-ms 0 --no-cpu-baseline > $OUT/g$i.log 2>&1 || { echo "$KEY pmc group $i failed"; tail -5 $OUT/g$i.log; exit 1; }
   echo "$KEY pmc group $i done"
 done
 python3 scratch/profile_parse.py $OUT $KEY
