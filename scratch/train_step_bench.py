@@ -26,9 +26,11 @@ for name, K, S, Bn in (("config2_shape", 6, 256, 16), ("config3_shape", 24, 512,
     data = SyntheticDataset(4 * Bn, cfg)
     batches = [data.batch(list(range(i * Bn, (i + 1) * Bn)), dev) for i in range(4)]
     rng = np.random.RandomState(0)
-    for i in range(3):
-        train_step(model, renderer, camera, batches[i % 4], opt, cfg, dp, pose_rng=rng)
-    torch.cuda.synchronize()
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.5:  # plan caches, allocator, and the GPU's sustained clocks (~100 ms of load)
+        for i in range(5):
+            train_step(model, renderer, camera, batches[i % 4], opt, cfg, dp, pose_rng=rng)
+        torch.cuda.synchronize()
     # host syncs inside a step: torch's sync debug mode warns once per synchronising call
     torch.cuda.set_sync_debug_mode("warn")
     with warnings.catch_warnings(record=True) as w:
