@@ -513,8 +513,11 @@ __global__ __launch_bounds__(64 * NP * (1 + WIDE)) __attribute__((amdgpu_waves_p
 // -> S -> rcp -> dalpha), and the sixth wave buys 4 % (1.37 -> 1.31 ms at config 3); a seventh needs spills and loses 35 %.
 // NSX = sub-tile columns of the tile: 2 (16 x 16 tiles) or 4 (32 x 16 tiles: eight sub-tiles per lane, ~0.6x as many list
 // entries, reductions and gradient rows; 5 waves per SIMD instead of 6 -- the loop is issue-bound, not latency-bound).
+#ifndef FGS_BWD_WIDE_WAVES
+#define FGS_BWD_WIDE_WAVES 5  /* waves per SIMD of k_composite_bwd<4>; re-measured in round 3 under the clause scheduler: see DESIGN.md 10.3 */
+#endif
 template <int NSX>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6 : 5, NSX == 2 ? 6 : 5))) void k_composite_bwd(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6 : FGS_BWD_WIDE_WAVES, NSX == 2 ? 6 : FGS_BWD_WIDE_WAVES))) void k_composite_bwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, uint32_t dcap,
     const uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg_off,
     const uint32_t *__restrict__ seg_tile, const float *__restrict__ seg_ckpt, const uint32_t *__restrict__ ranges,
