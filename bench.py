@@ -269,8 +269,14 @@ def main(argv=None):
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # stdout carries ONE thing: rank 0's JSON line.  Libraries print there too (RCCL's version banner at communicator
+    # creation goes to stdout), so file descriptor 1 points at stderr for the whole run and the line is written to the saved one.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     _import_compute()
     if args.rendezvous_only:
+        os.dup2(result_fd, 1)
         return rendezvous_only(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU fallback)")
@@ -517,7 +523,8 @@ def main(argv=None):
                        "saturation_skip": bool(args.saturation_skip), "parallelism": f"image-wise dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
