@@ -211,7 +211,7 @@ def launch_ranks(args, argv):
     return rc
 
 
-def rendezvous_only(args, world, rank):
+def rendezvous_only(args, world, rank, result_fd):
     """Launcher / rendezvous rehearsal without a GPU (tests/test_bench_launch.py): the ranks form the process group,
     run the same collectives the timed region uses on CPU tensors, rank 0 prints what it saw."""
     import torch.distributed as dist
@@ -221,8 +221,8 @@ def rendezvous_only(args, world, rank):
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     ranks = dist.get_world_size()
     if rank == 0:
-        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo",
-                          "rank_sum": float(t.item())}), flush=True)
+        os.write(result_fd, (json.dumps({"rendezvous_only": True, "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo",
+                                         "rank_sum": float(t.item())}) + "\n").encode())
     dist.destroy_process_group()
 
 
@@ -276,8 +276,7 @@ def main(argv=None):
     os.dup2(2, 1)
     _import_compute()
     if args.rendezvous_only:
-        os.dup2(result_fd, 1)
-        return rendezvous_only(args, world, rank)
+        return rendezvous_only(args, world, rank, result_fd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU fallback)")
     n_dev = torch.cuda.device_count()

@@ -21,9 +21,9 @@ def test_gpus2_without_launcher_spawns_two_ranks():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rendezvous-only"],
                        capture_output=True, text=True, env=_clean_env(), timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout  # rank 0 only
-    out = json.loads(lines[0])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout  # stdout = rank 0's one line, nothing else (gloo's
+    out = json.loads(lines[0])                                       # connection chatter and library banners go to stderr)
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
     assert out["rank_sum"] == 3.0  # ranks 0 and 1 both took part in the all-reduce
 
