@@ -10,8 +10,8 @@
 //   + k_asm_accumulate) -> ONE inverse transform per (image, channel) instead of one per plane (linearity of the
 //   propagation, 3 instead of 48) -> k_asm_max / k_asm_output: sqrt(|U|^2 + 1e-8), per-image max-normalisation (two-level
 //   reduction, no atomics), background composition and clamps (DR:1315-1332).
-// Backward retraces this with the adjoint transforms (k_colfft_bwd: gAcc conj(H) + the dL/dlambda terms + inverse column
-// FFT, then rocFFT inverse rows).
+// Backward retraces this with the adjoint transforms (k_colfft_bwd: gAcc conj(H) + inverse column FFT, then rocFFT inverse
+// rows); dL/dlambda comes from Z_c = sum_p z_p F_pc H_pc, summed by the forward beside acc_c -- no plane spectrum is kept.
 //
 // Bounds: the splat is VALU-bound on long lists and HBM-bound on config 5's short ones; the transforms are HBM-bound (8 B
 // per complex sample per pass, two passes per 2-D transform).
@@ -42,6 +42,8 @@ struct AsmPlan {
     size_t v_scal;       // float  [B]              per-image maxval
     size_t v_ccs;        // float  [B][N][8]        phasors c cos(phi), c sin(phi) per channel (k_asm_phasors)
     size_t v_tw;         // float2 [H/2]            twiddles of the column-fused transforms
+    size_t v_zsum;       // float2 [B][3][H][W]     Z_c = sum_p z_p F_pc H_pc (column-fused path): all the backward needs of the
+                         //                         spectra for dL/dlambda, so the spectra themselves are never stored
     int col_logn;        // log2(H) when the column direction runs in k_colfft_* (H = 64 ... 1024, a power of two), else 0
     int col_tc, col_pg;  // its column tile width, and plane groups per image (> 1 for launches that would not fill the chip)
     int rows_logw;       // log2(W) when the row direction runs fused with the splat (fgs_asm_rows.h), else 0
@@ -83,6 +85,7 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     p->v_scal = o; o = align256(o + B * 4 * 4);
     p->v_ccs = o; o = align256(o + B * (size_t)a->num_gaussians * 8 * 4);
     p->v_tw = o; o = align256(o + 512 * 8);
+    p->v_zsum = o; o = align256(o + B * 3 * HW * 8);
     p->col_logn = 0;
     for (int lg = 6; lg <= 10; ++lg)
         if (a->height == (1 << lg)) p->col_logn = lg;
@@ -129,7 +132,7 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
         p->c_part = o; o = align256(o + B * RED_BLOCKS * 8 + 3 * nwl * 4);
     }
     p->c_accp = o;
-    if (p->col_pg > 1) o = align256(o + B * p->col_pg * 3 * HW * 8);
+    if (p->col_pg > 1) o = align256(o + 2 * B * p->col_pg * 3 * HW * 8);  // partial plane sums of acc and of Z
     p->c_fftwork = o; o = align256(o + (p->work_big > p->work_small ? p->work_big : p->work_small) + 256);
     p->c_total_bytes = o;
     return FGS_OK;
@@ -475,12 +478,12 @@ __device__ __forceinline__ float image_max(const float *__restrict__ pmax, int b
 // H = 64 ... 1024 the column direction is done by our own kernels instead, fused with what follows / precedes it:
 //   forward   rocFFT 1-D rows, then k_colfft_fwd: per (image, channel, tile of TC columns) and plane -- load the H x TC
 //             tile into LDS (rows of TC complex: 128-byte segments), radix-4 decimation-in-frequency FFT down the columns
-//             (output in bit-reversed row order, undone by the store addresses), store the spectrum F (the backward needs
-//             it for dL/dlambda), multiply by H_pc and accumulate over the planes in registers; acc_c is written once;
-//   backward  k_colfft_bwd: gF = gAcc conj(H_pc) per plane (and the dL/dlambda terms from the saved F) straight into LDS
-//             in bit-reversed row order, radix-4 decimation-in-time inverse FFT (natural order out), store; then rocFFT
+//             (output in bit-reversed row order, undone by the store addresses), multiply by H_pc and accumulate over the
+//             planes (acc_c in registers, Z_c -- all the backward needs for dL/dlambda -- in LDS); both written once;
+//   backward  k_colfft_bwd: gF = gAcc conj(H_pc) per plane straight into LDS in bit-reversed row order, radix-8
+//             decimation-in-time inverse FFT (natural order out), store; the dL/dlambda terms from Z; then rocFFT
 //             1-D inverse rows.
-// Both directions: one read and one write of the plane data in the column pass instead of two reads and one write plus
+// The column pass reads the plane data once (forward) / writes it once (backward) instead of two reads and one write plus
 // the accumulate kernel's pass.  Unnormalised, like hipFFT.  Twiddles w_N^n = exp(-2 pi i n / N) from a global table (k_asm_prep).
 // Eight tile elements per thread: NT = N * TC / 8 threads per block (1024 for a 512 x 16 tile).  (The first version ran
 // 256 threads with 32 elements each: 270 / 458 VGPRs, one wave per SIMD, 1.9 / 1.3 ms at 8 images.)
@@ -493,25 +496,33 @@ __device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restri
 
 #include "fgs_asm_rows.h"
 
-// forward: spectra F (in place, for the backward) and acc[b][c] = sum_p F_pc H_pc.  grid (column tiles, 3, B)
+// forward: acc[b][c] = sum_p F_pc H_pc and Z[b][c] = sum_p z_p F_pc H_pc.  grid (column tiles, 3, B)
+// The spectra F are NOT stored (round 3): the backward needs them only in dL/dlambda_c = sum_k 2 pi dkz_k sum_p z_p dL/dtheta_pk with
+// dL/dtheta_pk = -Im(conj(gAcc_k) H_pk F_pk), i.e. in Z_k = sum_p z_p H_pk F_pk -- linear in F, so it is summed here beside acc
+// (accumulators in LDS: the block has 94 KB of it to spare and no register left) and the backward reads 50 MB of Z instead of
+// 0.65 GB of spectra, which the forward no longer writes either: -1.3 GB of the 7.4 GB a config-5 step moved at 8 images.
 // Planes of image b without any list entry are skipped (`seg_off`, see asm_plane_empty): their fields are zero (the row-fused build never writes them)
 template <int LOGN, int TC>
 __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(int W, int P, int PG, float2 *__restrict__ field,
                                                                            const float2 *__restrict__ htab,
                                                                            const float2 *__restrict__ tw_g,
-                                                                           float2 *__restrict__ acc,
+                                                                           float2 *__restrict__ acc, float2 *__restrict__ zsum,
+                                                                           float near_, float far_, float focal,
                                                                            const uint32_t *__restrict__ seg_off, uint32_t tiles) {
     // PG plane groups per image (launches of few images: more blocks, each summing its planes into its own partial
     // acc[(b, group)]; k_sum_groups adds them up): blockIdx.z = b * PG + group
     constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
     __shared__ float2 x[N][TC];
     __shared__ float2 tw[N / 2];
+    __shared__ float2 zacc[PER][NT];  // this thread's Z partial sums (element e at [e][tid]: conflict-free)
     load_twiddles<NT>(tw, tw_g, N / 2);
     const int c = blockIdx.y, b = blockIdx.z / PG, grp = blockIdx.z - b * PG, c0 = blockIdx.x * TC;
     const int ppg = (P + PG - 1) / PG, p_lo = grp * ppg, p_hi = min(P, p_lo + ppg);
     const size_t HW = (size_t)N * W;
     const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;  // this thread's elements: rows r0 + e * (NT / TC)
     const bool live = c0 + col < W;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) zacc[e][threadIdx.x] = make_float2(0.0f, 0.0f);
     float2 sum[PER], nx[PER];  // nx: the next plane's tile elements, in flight while the current plane is transformed
     auto next_plane = [&](int q) {  // first plane >= q of this group that has Gaussians (all of them when seg_off == nullptr)
         while (seg_off && q < p_hi && asm_plane_empty(seg_off, (uint32_t)(b * P + q), tiles)) ++q;
@@ -526,8 +537,8 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(in
     }
     while (p < p_hi) {
         const int pn = next_plane(p + 1);
-        float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
         const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
+        const float z = focal - plane_depth(p, P, near_, far_);
 #pragma unroll
         for (int e = 0; e < PER; ++e) x[r0 + e * (NT / TC)][col] = nx[e];
         __syncthreads();
@@ -545,10 +556,11 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(in
 #pragma unroll
             for (int e = 0; e < PER; ++e) {
                 const int r = r0 + e * (NT / TC);
-                const float2 F = x[r][col];
-                f[(size_t)bitrev<LOGN>(r) * W] = F;  // LDS row r holds frequency bitrev(r)
-                const float2 t = cmul(F, hh[e]);
+                const float2 t = cmul(x[r][col], hh[e]);  // LDS row r holds frequency bitrev(r)
                 sum[e].x += t.x; sum[e].y += t.y;
+                float2 zs = zacc[e][threadIdx.x];
+                zs.x += z * t.x; zs.y += z * t.y;
+                zacc[e][threadIdx.x] = zs;
             }
         }
         __syncthreads();
@@ -556,8 +568,13 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(in
     }
     if (live) {
         float2 *a = acc + ((size_t)blockIdx.z * 3 + c) * HW + c0 + col;
+        float2 *zo = zsum + ((size_t)blockIdx.z * 3 + c) * HW + c0 + col;
 #pragma unroll
-        for (int e = 0; e < PER; ++e) a[(size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W] = sum[e];
+        for (int e = 0; e < PER; ++e) {
+            const size_t o = (size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W;
+            a[o] = sum[e];
+            zo[o] = zacc[e][threadIdx.x];
+        }
     }
 }
 
@@ -575,14 +592,14 @@ __global__ __launch_bounds__(256) void k_sum_groups(size_t n_per_image, int PG, 
     total[(size_t)b * n_per_image + i] = s;
 }
 
-// backward: gF_pc = gAcc_c conj(H_pc), inverse-transformed down the columns, over the saved spectra; the block's part of
-// dL/dlambda_c -> pwl[c][block] (see k_asm_accumulate_bwd for the maths).  grid (column tiles, 3, B)
+// backward: gF_pc = gAcc_c conj(H_pc), inverse-transformed down the columns, written where the forward's fields were; the block's part
+// of dL/dlambda_c -> pwl[c][block] from Z (k_colfft_fwd; k_asm_accumulate_bwd has the maths in its per-plane form).  grid (column tiles, 3, B)
 template <int LOGN, int TC>
 __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     int W, int P, int PG, float near_, float far_, float focal, float inv_ndx, float inv_ndy,
     const float *__restrict__ wavelengths, const float2 *__restrict__ gacc, const float2 *__restrict__ htab,
     const float2 *__restrict__ tw_g, float2 *__restrict__ field, float *__restrict__ pwl,
-    const uint32_t *__restrict__ seg_off, uint32_t tiles) {
+    const uint32_t *__restrict__ seg_off, uint32_t tiles, const float2 *__restrict__ zsum) {
     constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
     __shared__ float2 x[N][TC];
     __shared__ float2 tw[N / 2];
@@ -594,35 +611,49 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;
     const bool live = c0 + col < W;
     float2 g[PER];
-    float zs[PER];  // sum_p z_p dL/dtheta_p per frequency
+    // dL/dlambda_c = sum_k 2 pi (sum_p z_p dL/dtheta_pk) d kz_k / d lambda, with sum_p z_p dL/dtheta_pk = -Im(conj(gAcc_k) Z_k): once per
+    // (image, channel), so plane group 0 carries it -- before the plane loop, so that one float stays live across it
     const float2 *ga = gacc + ((size_t)b * 3 + c) * HW + c0 + col;
+    const float2 *zg = zsum + ((size_t)b * 3 + c) * HW + c0 + col;
+    const float wl = wavelengths[c], il = 1.0f / wl;
+    const float fx = fftfreq(c0 + col, W, inv_ndx);
+    float gl = 0.0f;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
-        g[e] = live ? ga[(size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W] : make_float2(0.0f, 0.0f);
-        zs[e] = 0.0f;
-    }
-    __syncthreads();  // twiddles
-    // (requesting the next plane's spectrum before the transform, as the forward does, needs 16 more registers: spills, +10 %)
-    for (int p = p_lo; p < p_hi; ++p) {
-        // a plane without Gaussians has a zero spectrum (F = 0: no dL/dlambda term) and nobody reads its gradient
-        if (seg_off && asm_plane_empty(seg_off, (uint32_t)(b * P + p), tiles)) continue;  // block-uniform
-        float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
-        const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
-        const float z = focal - plane_depth(p, P, near_, far_);
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const int r = r0 + e * (NT / TC);
-            float2 gF = make_float2(0.0f, 0.0f);
-            if (live) {
-                const size_t o = (size_t)bitrev<LOGN>(r) * W;
-                const float2 F = f[o], hh = h[o];
-                const float2 gH = cmul(make_float2(F.x, -F.y), g[e]);      // conj(F) * gAcc
-                zs[e] += -(hh.y * gH.x - hh.x * gH.y) * z;                  // -Im(H * conj(gH)) z_p
-                gF = cmul(g[e], make_float2(hh.x, -hh.y));
-            }
-            x[r][col] = gF;
+        const int ky = bitrev<LOGN>(r0 + e * (NT / TC));
+        const size_t o = (size_t)ky * W;
+        g[e] = live ? ga[o] : make_float2(0.0f, 0.0f);
+        if (live && grp == 0) {
+            const float2 Z = zg[o];
+            const float fy = fftfreq(ky, N, inv_ndy);
+            const float kz2 = il * il - fx * fx - fy * fy;
+            const float dkz = kz2 > 0.0f ? -(il * il * il) / sqrtf(kz2) : 0.0f;
+            gl += 6.28318530717958647692f * (g[e].y * Z.x - g[e].x * Z.y) * dkz;
         }
+    }
+    // a plane without Gaussians has a zero spectrum and nobody reads its gradient: skipped (block-uniform)
+    auto next_plane = [&](int q) {
+        while (seg_off && q < p_hi && asm_plane_empty(seg_off, (uint32_t)(b * P + q), tiles)) ++q;
+        return q;
+    };
+    int p = next_plane(p_lo);
+    float2 hh[PER];  // the plane's transfer-function values; the next plane's are in flight during the transform
+#pragma unroll
+    for (int e = 0; e < PER; ++e)
+        hh[e] = (live && p < p_hi) ? htab[((size_t)c * P + p) * HW + c0 + col + (size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W]
+                                   : make_float2(0.0f, 0.0f);
+    __syncthreads();  // twiddles
+    while (p < p_hi) {
+        const int pn = next_plane(p + 1);
+        float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) x[r0 + e * (NT / TC)][col] = cmul(g[e], make_float2(hh[e].x, -hh[e].y));
         __syncthreads();
+        if (live && pn < p_hi) {
+            const float2 *h = htab + ((size_t)c * P + pn) * HW + c0 + col;
+#pragma unroll
+            for (int e = 0; e < PER; ++e) hh[e] = h[(size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W];
+        }
         lds_fft_columns<LOGN, TC, NT, true>(x, tw);
         if (live) {
 #pragma unroll
@@ -632,19 +663,7 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
             }
         }
         __syncthreads();
-    }
-    // dL/dlambda: sum_k (2 pi sum_p z_p dL/dtheta_pk) d kz_k / d lambda
-    const float wl = wavelengths[c], il = 1.0f / wl;
-    float gl = 0.0f;
-    if (live) {
-        const float fx = fftfreq(c0 + col, W, inv_ndx);
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const float fy = fftfreq(bitrev<LOGN>(r0 + e * (NT / TC)), N, inv_ndy);
-            const float kz2 = il * il - fx * fx - fy * fy;
-            const float dkz = kz2 > 0.0f ? -(il * il * il) / sqrtf(kz2) : 0.0f;
-            gl += 6.28318530717958647692f * zs[e] * dkz;
-        }
+        p = pn;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) gl += __shfl_xor(gl, o, 64);
@@ -1117,10 +1136,11 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
         float2 *tw = reinterpret_cast<float2 *>(sv + p.v_tw);
         float2 *accp = reinterpret_cast<float2 *>(sc + p.c_accp);
         const int PG = p.col_pg;
+        float2 *zsum = reinterpret_cast<float2 *>(sv + p.v_zsum), *zsump = accp + (size_t)B * PG * 3 * HW;
 #define FGS_COLFFT_FWD(LG, TCV)                                                                                       \
     hipLaunchKernelGGL((k_colfft_fwd<LG, TCV>), dim3((unsigned)((W + TCV - 1) / TCV), 3, B * PG),                    \
                        dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, PG, field, htab, tw, PG > 1 ? accp : total,         \
-                       seg_off_d, (uint32_t)p.base.tiles)
+                       PG > 1 ? zsump : zsum, a.depth_near, a.depth_far, a.focal_depth, seg_off_d, (uint32_t)p.base.tiles)
         switch (p.col_logn) {
             case 6: FGS_COLFFT_FWD(6, 16); break;
             case 7: FGS_COLFFT_FWD(7, 16); break;
@@ -1132,6 +1152,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
         FGS_LAUNCH_CHECK("k_colfft_fwd");
         if (PG > 1) {
             hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((3 * HW + 255) / 256), B), dim3(256), 0, st, 3 * HW, PG, accp, total);
+            hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((3 * HW + 255) / 256), B), dim3(256), 0, st, 3 * HW, PG, zsump, zsum);
             FGS_LAUNCH_CHECK("k_sum_groups");
         }
     } else {
@@ -1201,7 +1222,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
                            dim3((1 << LG) * TCV / COLFFT_PER), 0, st, W, P, p.col_pg, a.depth_near, a.depth_far,      \
                            a.focal_depth, inv_ndx, inv_ndy, wavelengths, gtot, htab, tw, field, pwl,                  \
                            reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),                                 \
-                           (uint32_t)p.base.tiles);                                                                   \
+                           (uint32_t)p.base.tiles, reinterpret_cast<const float2 *>(sv + p.v_zsum));                 \
     } while (0)
         switch (p.col_logn) {
             case 6: FGS_COLFFT_BWD(6, 16); break;
