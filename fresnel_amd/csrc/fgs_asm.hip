@@ -19,6 +19,7 @@
 // Compiled WITHOUT fast-math: the transfer-function phase reaches ~200 rad, so sin/cos need the
 // accurate range reduction of sincosf.
 #include <hipfft/hipfft.h>
+#include <type_traits>
 #include "fgs_internal.h"
 #include "fgs_wave.h"
 #include "fgs_colfft.h"
@@ -37,7 +38,7 @@ struct AsmPlan {
     size_t HW;
     // saved sections (after base.L.total_bytes)
     size_t v_field;      // float2 [B][P][3][H][W]  plane fields -> spectra (kept for the backward)
-    size_t v_htab;       // float2 [3][P][H][W]     transfer functions
+    size_t v_htab;       // float2 [3][P][H][W]     transfer functions H_pc, then [3][H][W] their plane-to-plane factor D_c (asm_transfer_block)
     size_t v_total;      // float2 [B][3][H][W]     total field U (unnormalised inverse FFT)
     size_t v_scal;       // float  [B]              per-image maxval
     size_t v_ccs;        // float  [B][N][8]        phasors c cos(phi), c sin(phi) per channel (k_asm_phasors)
@@ -80,19 +81,24 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     p->HW = HW;
     size_t o = p->base.L.total_bytes;
     p->v_field = o; o = align256(o + B * P * 3 * HW * 8);
-    p->v_htab = o; o = align256(o + 3 * P * HW * 8);
+    p->v_htab = o; o = align256(o + 3 * (P + 1) * HW * 8);
     p->v_total = o; o = align256(o + B * 3 * HW * 8);
     p->v_scal = o; o = align256(o + B * 4 * 4);
     p->v_ccs = o; o = align256(o + B * (size_t)a->num_gaussians * 8 * 4);
     p->v_tw = o; o = align256(o + 512 * 8);
     p->v_zsum = o; o = align256(o + B * 3 * HW * 8);
     p->col_logn = 0;
+    // (whole column tiles only: widths that are multiples of the tile's 16 -- 8 for H = 1024 -- columns; the kernels carry no
+    // per-lane guards, so that every load of their plane loops is unconditional and the compiler's wait counts stay exact)
     for (int lg = 6; lg <= 10; ++lg)
-        if (a->height == (1 << lg)) p->col_logn = lg;
+        if (a->height == (1 << lg) && a->width % (lg == 10 ? 8 : 16) == 0) p->col_logn = lg;
 #ifdef FGS_NO_COLFFT  // experiment builds: rocFFT's 2-D plans for every frame
     p->col_logn = 0;
 #endif
-    p->col_tc = p->col_logn == 10 ? 8 : 16;
+#ifndef FGS_COLFFT_TC9
+#define FGS_COLFFT_TC9 16  // column tile width of the 512-row kernels (experiment builds: 8)
+#endif
+    p->col_tc = p->col_logn == 10 ? 8 : p->col_logn == 9 ? FGS_COLFFT_TC9 : 16;
     p->col_pg = 1;
     if (p->col_logn) {
         const size_t blocks = (size_t)((a->width + p->col_tc - 1) / p->col_tc) * 3 * B;
@@ -157,6 +163,9 @@ __device__ __forceinline__ float plane_depth(int k, int P, float near_, float fa
 // fftfreq(n - k) = -fftfreq(k) exactly, and H depends on fx^2, fy^2 only: one thread evaluates the quadrant entry
 // (ky <= H/2, kx <= W/2) -- the accurate sincosf is what this kernel costs -- and stores it at its up to four mirror
 // positions, bit-identical to evaluating every entry (58 -> 20 us for 3 x 16 planes of 512^2).
+// Behind the 3 P planes: D[c][ky][kx] = exp(i * ((2 pi * -step) * kz)), step = (far - near) / (P - 1) -- the planes are equally spaced
+// (torch.linspace, DR:1194), so H_(p+1) = H_p D and the column kernels walk the planes by this recurrence instead of reading H_p
+// (k_colfft_fwd / k_colfft_bwd; the table itself is still what k_asm_accumulate[_bwd] and each block's first plane read).
 __device__ __forceinline__ void asm_transfer_block(uint32_t blk, int W, int H, int P, float near_, float far_, float focal,
                                                    float inv_ndx, float inv_ndy,
                                                    const float *__restrict__ wavelengths,
@@ -165,20 +174,20 @@ __device__ __forceinline__ void asm_transfer_block(uint32_t blk, int W, int H, i
     const int QW = W / 2 + 1, QH = H / 2 + 1;
     const size_t QHW = (size_t)QW * QH;
     const size_t i = (size_t)blk * 256 + threadIdx.x;
-    if (i >= 3 * (size_t)P * QHW) return;
+    if (i >= 3 * (size_t)(P + 1) * QHW) return;
     const int kx = (int)(i % QW), ky = (int)((i / QW) % QH);
-    const int p = (int)((i / QHW) % P), c = (int)(i / (QHW * P));
+    const int p = (int)((i / QHW) % (P + 1)), c = (int)(i / (QHW * (P + 1)));
     const float fx = fftfreq(kx, W, inv_ndx), fy = fftfreq(ky, H, inv_ndy);
     const float il = 1.0f / wavelengths[c];
     float kz2 = il * il - fx * fx - fy * fy;
     kz2 = kz2 < 0.0f ? 0.0f : kz2;
     const float kz = sqrtf(kz2);
-    const float z = focal - plane_depth(p, P, near_, far_);
+    const float z = p < P ? focal - plane_depth(p, P, near_, far_) : (P > 1 ? -(far_ - near_) / (float)(P - 1) : 0.0f);
     const float theta = (6.28318530717958647692f * z) * kz;
     float sn, cs;
     sincosf(theta, &sn, &cs);
     const float2 h = make_float2(cs, sn);
-    float2 *plane = htab + ((size_t)c * P + p) * HW;
+    float2 *plane = p < P ? htab + ((size_t)c * P + p) * HW : htab + ((size_t)3 * P + c) * HW;
     const int mx = (kx > 0 && W - kx != kx) ? W - kx : -1, my = (ky > 0 && H - ky != ky) ? H - ky : -1;
     plane[(size_t)ky * W + kx] = h;
     if (mx >= 0) plane[(size_t)ky * W + mx] = h;
@@ -496,10 +505,65 @@ __device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restri
 
 #include "fgs_asm_rows.h"
 
+// Addressing of the column kernels: buffer loads / stores -- a UNIFORM base (image / plane / channel: a buffer resource in scalar
+// registers, rebuilt per plane by scalar instructions), a uniform 32-bit byte offset per tile element (scalar) and a 32-bit per-thread
+// byte offset that is computed once: no vector arithmetic per access.  (The first version recomputed 64-bit vector addresses per
+// element and plane -- a fifth of the kernels' vector instructions; plain pointers with a 32-bit index are turned back into
+// per-element 64-bit vector addresses by the compiler.)  Offsets stay below 2^31: a plane of one channel is H W 8 <= 2^23 W bytes.
+typedef float colfft_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t colfft_rsrc(const void *ubase) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0, 0x7fffffff, 0x00020000);  // raw buffer, no swizzle
+}
+__device__ __forceinline__ float2 ld_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const colfft_v2f v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void st_f2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float2 v) {
+    colfft_v2f t; t.x = v.x; t.y = v.y;
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, (int)voff, (int)soff, 0);
+}
+// frequency row held by the thread's e-th transformed element = FREQ_T (per thread) + colfft_freq_e (compile time), see k_colfft_fwd:
+// INNER (rows 8 q + e): bitrev(8 q + e) = bitrev3(e) N/8 + bitrev(q); otherwise (rows q + e N/8): 8 bitrev(q) + bitrev3(e)
+template <int LOGN, bool INNER>
+__device__ __forceinline__ constexpr int colfft_freq_e(int e) {
+    const int br3 = ((e & 1) << 2) | (e & 2) | ((e >> 2) & 1);
+    return INNER ? br3 << (LOGN - 3) : br3;
+}
+template <int LOGN, bool INNER>
+__device__ __forceinline__ int colfft_freq_t(int q) { return INNER ? bitrev<LOGN - 3>(q) : 8 * bitrev<LOGN - 3>(q); }
+
+// Launch order of the column kernels' blocks (grid (column tiles, 3, images x plane groups)) -> (column tile, channel, image, group).
+// ORDER 0: as dispatched (round-robin over the XCDs).  1: every XCD walks a contiguous range, column tile fastest.  2: contiguous
+// range, IMAGE fastest: the blocks of all images for one (plane group, channel, column tile) start together on one XCD and walk the
+// planes side by side, so a tile of the transfer-function table is fetched into that XCD's L2 once and found there by the others.
+// Measured (config 5, profiles/r03_ab_config5_colfft.txt): at 8 images order 2 beats order 0 by 15 % on the forward kernel, at one
+// image (six plane groups) order 0 is the faster one by 20 %: the kernels take order 2 from four images up.
+template <int ORDER_MANY>
+__device__ __forceinline__ void colfft_block(int PG, int &bx, int &c, int &b, int &grp) {
+    const int ORDER = gridDim.z / (uint32_t)PG >= 4u ? ORDER_MANY : 0;
+    if (ORDER == 0) { bx = blockIdx.x; c = blockIdx.y; b = blockIdx.z / PG; grp = blockIdx.z - b * PG; return; }
+    const uint32_t lin = fgs_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + 3u * blockIdx.z), gridDim.x * 3u * gridDim.z);
+    if (ORDER == 1) {
+        bx = (int)(lin % gridDim.x); c = (int)((lin / gridDim.x) % 3u);
+        const int bz = (int)(lin / (gridDim.x * 3u));
+        b = bz / PG; grp = bz - b * PG;
+    } else {
+        const uint32_t nimg = gridDim.z / (uint32_t)PG;
+        b = (int)(lin % nimg); bx = (int)((lin / nimg) % gridDim.x); c = (int)((lin / (nimg * gridDim.x)) % 3u);
+        grp = (int)(lin / (nimg * gridDim.x * 3u));
+    }
+}
+#ifndef FGS_COLFFT_ORDER_FWD
+#define FGS_COLFFT_ORDER_FWD 2
+#endif
+#ifndef FGS_COLFFT_ORDER_BWD
+#define FGS_COLFFT_ORDER_BWD 2
+#endif
+
 // forward: acc[b][c] = sum_p F_pc H_pc and Z[b][c] = sum_p z_p F_pc H_pc.  grid (column tiles, 3, B)
 // The spectra F are NOT stored (round 3): the backward needs them only in dL/dlambda_c = sum_k 2 pi dkz_k sum_p z_p dL/dtheta_pk with
 // dL/dtheta_pk = -Im(conj(gAcc_k) H_pk F_pk), i.e. in Z_k = sum_p z_p H_pk F_pk -- linear in F, so it is summed here beside acc
-// (accumulators in LDS: the block has 94 KB of it to spare and no register left) and the backward reads 50 MB of Z instead of
+// (in registers, next to acc) and the backward reads 50 MB of Z instead of
 // 0.65 GB of spectra, which the forward no longer writes either: -1.3 GB of the 7.4 GB a config-5 step moved at 8 images.
 // Planes of image b without any list entry are skipped (`seg_off`, see asm_plane_empty): their fields are zero (the row-fused build never writes them)
 template <int LOGN, int TC>
@@ -511,70 +575,117 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(in
                                                                            const uint32_t *__restrict__ seg_off, uint32_t tiles) {
     // PG plane groups per image (launches of few images: more blocks, each summing its planes into its own partial
     // acc[(b, group)]; k_sum_groups adds them up): blockIdx.z = b * PG + group
-    constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
-    __shared__ float2 x[N][TC];
+    constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER, E1 = N / 8;
+    constexpr bool INNER = lds_fft_inner_in_registers<LOGN>();
+    constexpr int NW = NT / 64, RPI = 128 / TC;  // waves; tile rows covered by one 64-lane x 16-byte load
+    static_assert(PER == 8 && N / RPI == 4 * NW, "one 8-point butterfly per thread and pass; four tile loads per wave");
+    // TWO tile buffers: while plane p is transformed in one, plane p + 1 streams from HBM straight into the other
+    // (buffer_load ... lds: no registers, a whole plane step of latency cover -- the register prefetch of the first version had one
+    // tile of 64 KB in flight per CU for part of the step and the kernel sat at 2.7 TB/s with every arithmetic instruction removed)
+    __shared__ __attribute__((aligned(16))) float2 xa[N][TC];
+    __shared__ __attribute__((aligned(16))) float2 xb[N][TC];
     __shared__ float2 tw[N / 2];
-    __shared__ float2 zacc[PER][NT];  // this thread's Z partial sums (element e at [e][tid]: conflict-free)
     load_twiddles<NT>(tw, tw_g, N / 2);
-    const int c = blockIdx.y, b = blockIdx.z / PG, grp = blockIdx.z - b * PG, c0 = blockIdx.x * TC;
+    int bx, c, b, grp;
+    colfft_block<FGS_COLFFT_ORDER_FWD>(PG, bx, c, b, grp);
+    const int bz = b * PG + grp, c0 = bx * TC;
     const int ppg = (P + PG - 1) / PG, p_lo = grp * ppg, p_hi = min(P, p_lo + ppg);
     const size_t HW = (size_t)N * W;
-    const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;  // this thread's elements: rows r0 + e * (NT / TC)
-    const bool live = c0 + col < W;
-#pragma unroll
-    for (int e = 0; e < PER; ++e) zacc[e][threadIdx.x] = make_float2(0.0f, 0.0f);
-    float2 sum[PER], nx[PER];  // nx: the next plane's tile elements, in flight while the current plane is transformed
-    auto next_plane = [&](int q) {  // first plane >= q of this group that has Gaussians (all of them when seg_off == nullptr)
-        while (seg_off && q < p_hi && asm_plane_empty(seg_off, (uint32_t)(b * P + q), tiles)) ++q;
-        return q;
-    };
-    int p = next_plane(p_lo);
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        sum[e] = make_float2(0.0f, 0.0f);
-        nx[e] = (live && p < p_hi) ? field[(((size_t)b * P + p) * 3 + c) * HW + c0 + col + (size_t)(r0 + e * (NT / TC)) * W]
-                                   : make_float2(0.0f, 0.0f);
-    }
-    while (p < p_hi) {
-        const int pn = next_plane(p + 1);
-        const float2 *h = htab + ((size_t)c * P + p) * HW + c0 + col;
-        const float z = focal - plane_depth(p, P, near_, far_);
-#pragma unroll
-        for (int e = 0; e < PER; ++e) x[r0 + e * (NT / TC)][col] = nx[e];
-        __syncthreads();
-        if (live && pn < p_hi) {
-            const float2 *fn = field + (((size_t)b * P + pn) * 3 + c) * HW + c0 + col;  // the next plane with Gaussians
-#pragma unroll
-            for (int e = 0; e < PER; ++e) nx[e] = fn[(size_t)(r0 + e * (NT / TC)) * W];
-        }
-        float2 hh[PER];  // this plane's transfer-function values, also in flight during the transform
-#pragma unroll
-        for (int e = 0; e < PER; ++e)
-            hh[e] = live ? h[(size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W] : make_float2(0.0f, 0.0f);
-        lds_fft_columns<LOGN, TC, NT, false>(x, tw);
-        if (live) {
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                const int r = r0 + e * (NT / TC);
-                const float2 t = cmul(x[r][col], hh[e]);  // LDS row r holds frequency bitrev(r)
-                sum[e].x += t.x; sum[e].y += t.y;
-                float2 zs = zacc[e][threadIdx.x];
-                zs.x += z * t.x; zs.y += z * t.y;
-                zacc[e][threadIdx.x] = zs;
-            }
-        }
-        __syncthreads();
-        p = pn;
-    }
-    if (live) {
-        float2 *a = acc + ((size_t)blockIdx.z * 3 + c) * HW + c0 + col;
-        float2 *zo = zsum + ((size_t)blockIdx.z * 3 + c) * HW + c0 + col;
+    // The thread's tile elements: rows q + e N/8 of its column in the opening block-size-N butterfly (LDS -> registers -> LDS), and
+    // (LDS row r holds frequency bitrev(r) at the end) for N = 8^k the eight consecutive rows 8 q + e of the closing block-size-8
+    // butterfly, in registers (its twiddles are all 1) straight into the epilogue; otherwise the rows q + e N/8 once more.
+    const int col = threadIdx.x % TC, q = threadIdx.x / TC;  // (W is a multiple of TC: make_asm_plan)
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto out_row = [&](int e) { return INNER ? 8 * q + e : q + e * E1; };
+    // NO transfer-function value is read per plane: the planes are equally spaced, H_p = H_lo D^(p - lo) (lo = the group's first
+    // plane), so   acc = sum_p H_p F_p = H_lo S   and   Z = sum_p z_p H_p F_p = H_lo (z_lo S - step T)   with the Horner sums
+    //     S_k = F_k + D S_(k+1),   T_k = D (T_(k+1) + S_(k+1))      [S_k = sum_(p>=k) D^(p-k) F_p, T_k = sum_(p>=k) (p-k) D^(p-k) F_p]
+    // over the planes in DESCENDING order: D once per block, H_lo once at the end -- the table used to be re-read by every image
+    // (as many bytes per step as the plane data, 45 us of this kernel and 107 us of the backward at 8 images even out of L2).
+    float2 S[PER], T[PER], D[PER];
+    const uint32_t off_out = (uint32_t)(colfft_freq_t<LOGN, INNER>(q) * W + col) * 8u;  // element e's frequency: + colfft_freq_e(e) W
+    {
+        const __amdgpu_buffer_rsrc_t dt = colfft_rsrc(htab + ((size_t)3 * P + c) * HW + c0);
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const size_t o = (size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W;
-            a[o] = sum[e];
-            zo[o] = zacc[e][threadIdx.x];
+            S[e] = T[e] = make_float2(0.0f, 0.0f);
+            D[e] = ld_f2(dt, off_out, (uint32_t)(colfft_freq_e<LOGN, INNER>(e) * W) * 8u);
         }
+    }
+    auto prev_plane = [&](int pq) {  // last plane <= pq of this group that has Gaussians (all of them when seg_off == nullptr), or p_lo - 1
+        while (seg_off && pq >= p_lo && asm_plane_empty(seg_off, (uint32_t)(b * P + pq), tiles)) --pq;
+        return __builtin_amdgcn_readfirstlane(pq);
+    };
+    auto skip_planes = [&](int m) {  // m planes with F = 0
+        for (int i = 0; i < m; ++i) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                T[e] = cmul(D[e], make_float2(T[e].x + S[e].x, T[e].y + S[e].y));
+                S[e] = cmul(D[e], S[e]);
+            }
+        }
+    };
+    int p = prev_plane(p_hi - 1);
+    const uint32_t off_tile = (uint32_t)((lane / (TC / 2)) * W + 2u * (lane % (TC / 2))) * 8u;  // lane's 16 bytes within RPI rows of the tile
+    const float2 *f0 = field + ((size_t)b * P * 3 + c) * HW + c0;                                 // + plane * 3 HW
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto request_tile = [&](float2 (*x)[TC], int plane) {  // lane i's 16 bytes land at (LDS base) + 16 i: RPI whole tile rows per load
+        const __amdgpu_buffer_rsrc_t f = colfft_rsrc(f0 + (size_t)plane * 3 * HW);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t r0 = (wave + (uint32_t)NW * k) * RPI;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(f, (lds_void *)(uintptr_t)&x[r0][0], 16, (int)off_tile, (int)(r0 * W * 8u), 0, 0);
+        }
+    };
+    // One plane in buffer x (PARITY picks it at compile time; the loop below is unrolled by two and peeled).  Barriers order LDS only
+    // (lds_only_barrier): the next tile's four loads stay in flight through the whole step.
+    auto plane_step = [&](auto has_next, auto parity, int pn) {
+        float2 (*x)[TC] = decltype(parity)::value ? xb : xa;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed ...
+        lds_only_barrier();                               // ... everybody's has, and the other buffer has been read out
+        if (decltype(has_next)::value) request_tile(decltype(parity)::value ? xa : xb, pn);
+        float2 F[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) F[e] = x[q + e * E1][col];
+        oct_dif<false>(F, tw[q], tw[2 * q], tw[4 * q]);  // block size N, points q + e N/8: w_N^q, w_N^2q, w_N^4q
+#pragma unroll
+        for (int e = 0; e < PER; ++e) x[q + e * E1][col] = F[e];
+        lds_only_barrier();
+        lds_fft_columns<LOGN, TC, NT, false, true, INNER, true>(x, tw);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) F[e] = x[out_row(e)][col];
+        if (INNER) oct_dif<true>(F, F[0], F[0], F[0]);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            T[e] = cmul(D[e], make_float2(T[e].x + S[e].x, T[e].y + S[e].y));
+            const float2 ds = cmul(D[e], S[e]);
+            S[e] = make_float2(F[e].x + ds.x, F[e].y + ds.y);
+        }
+    };
+    if (p >= p_lo) {
+        request_tile(xa, p);
+        for (int pn = prev_plane(p - 1);; ) {
+            if (pn < p_lo) { plane_step(std::false_type{}, std::false_type{}, 0); break; }
+            plane_step(std::true_type{}, std::false_type{}, pn);
+            skip_planes(p - pn - 1);
+            p = pn; pn = prev_plane(p - 1);
+            if (pn < p_lo) { plane_step(std::false_type{}, std::true_type{}, 0); break; }
+            plane_step(std::true_type{}, std::true_type{}, pn);
+            skip_planes(p - pn - 1);
+            p = pn; pn = prev_plane(p - 1);
+        }
+        skip_planes(p - p_lo);
+    }
+    const __amdgpu_buffer_rsrc_t h = colfft_rsrc(htab + ((size_t)c * P + p_lo) * HW + c0);
+    const __amdgpu_buffer_rsrc_t a = colfft_rsrc(acc + ((size_t)bz * 3 + c) * HW + c0);
+    const __amdgpu_buffer_rsrc_t zo = colfft_rsrc(zsum + ((size_t)bz * 3 + c) * HW + c0);
+    const float z_lo = focal - plane_depth(p_lo, P, near_, far_), step = P > 1 ? (far_ - near_) / (float)(P - 1) : 0.0f;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const uint32_t so = (uint32_t)(colfft_freq_e<LOGN, INNER>(e) * W) * 8u;
+        const float2 hl = ld_f2(h, off_out, so);
+        st_f2(a, off_out, so, cmul(hl, S[e]));
+        st_f2(zo, off_out, so, cmul(hl, make_float2(z_lo * S[e].x - step * T[e].x, z_lo * S[e].y - step * T[e].y)));
     }
 }
 
@@ -600,31 +711,38 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     const float *__restrict__ wavelengths, const float2 *__restrict__ gacc, const float2 *__restrict__ htab,
     const float2 *__restrict__ tw_g, float2 *__restrict__ field, float *__restrict__ pwl,
     const uint32_t *__restrict__ seg_off, uint32_t tiles, const float2 *__restrict__ zsum) {
-    constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER;
+    constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER, E1 = N / 8;
+    constexpr bool INNER = lds_fft_inner_in_registers<LOGN>();
     __shared__ float2 x[N][TC];
     __shared__ float2 tw[N / 2];
     __shared__ float wpart[NT / 64];
     load_twiddles<NT>(tw, tw_g, N / 2);
-    const int c = blockIdx.y, b = blockIdx.z / PG, grp = blockIdx.z - b * PG, c0 = blockIdx.x * TC;
+    int bx, c, b, grp;
+    colfft_block<FGS_COLFFT_ORDER_BWD>(PG, bx, c, b, grp);
+    const int bz = b * PG + grp, c0 = bx * TC;
     const int ppg = (P + PG - 1) / PG, p_lo = grp * ppg, p_hi = min(P, p_lo + ppg);
     const size_t HW = (size_t)N * W;
-    const int col = threadIdx.x % TC, r0 = threadIdx.x / TC;
-    const bool live = c0 + col < W;
+    // the mirror image of k_colfft_fwd's element assignment: IN at LDS rows in_row(e) (frequency bitrev(row)) -- for N = 8^k the eight
+    // rows of the opening block-size-8 butterfly, in registers; OUT the natural rows q + e N/8 of the closing block-size-N butterfly,
+    // in registers straight to HBM
+    const int col = threadIdx.x % TC, q = threadIdx.x / TC;  // (W is a multiple of TC: make_asm_plan)
+    auto in_row = [&](int e) { return INNER ? 8 * q + e : q + e * E1; };
     float2 g[PER];
     // dL/dlambda_c = sum_k 2 pi (sum_p z_p dL/dtheta_pk) d kz_k / d lambda, with sum_p z_p dL/dtheta_pk = -Im(conj(gAcc_k) Z_k): once per
     // (image, channel), so plane group 0 carries it -- before the plane loop, so that one float stays live across it
-    const float2 *ga = gacc + ((size_t)b * 3 + c) * HW + c0 + col;
-    const float2 *zg = zsum + ((size_t)b * 3 + c) * HW + c0 + col;
+    const __amdgpu_buffer_rsrc_t ga = colfft_rsrc(gacc + ((size_t)b * 3 + c) * HW + c0);
+    const __amdgpu_buffer_rsrc_t zg = colfft_rsrc(zsum + ((size_t)b * 3 + c) * HW + c0);
+    const uint32_t off_in = (uint32_t)(colfft_freq_t<LOGN, INNER>(q) * W + col) * 8u;  // element e's frequency row: + colfft_freq_e(e) W
+    const uint32_t off_out = (uint32_t)(q * W + col) * 8u;                             // transformed element e:    + e (N/8) W
     const float wl = wavelengths[c], il = 1.0f / wl;
     const float fx = fftfreq(c0 + col, W, inv_ndx);
     float gl = 0.0f;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
-        const int ky = bitrev<LOGN>(r0 + e * (NT / TC));
-        const size_t o = (size_t)ky * W;
-        g[e] = live ? ga[o] : make_float2(0.0f, 0.0f);
-        if (live && grp == 0) {
-            const float2 Z = zg[o];
+        const int ky = colfft_freq_t<LOGN, INNER>(q) + colfft_freq_e<LOGN, INNER>(e);  // = bitrev(in_row(e))
+        g[e] = ld_f2(ga, off_in, (uint32_t)(colfft_freq_e<LOGN, INNER>(e) * W) * 8u);
+        if (grp == 0) {
+            const float2 Z = ld_f2(zg, off_in, (uint32_t)(colfft_freq_e<LOGN, INNER>(e) * W) * 8u);
             const float fy = fftfreq(ky, N, inv_ndy);
             const float kz2 = il * il - fx * fx - fy * fy;
             const float dkz = kz2 > 0.0f ? -(il * il * il) / sqrtf(kz2) : 0.0f;
@@ -632,37 +750,50 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
         }
     }
     // a plane without Gaussians has a zero spectrum and nobody reads its gradient: skipped (block-uniform)
-    auto next_plane = [&](int q) {
-        while (seg_off && q < p_hi && asm_plane_empty(seg_off, (uint32_t)(b * P + q), tiles)) ++q;
-        return q;
+    auto next_plane = [&](int pq) {
+        while (seg_off && pq < p_hi && asm_plane_empty(seg_off, (uint32_t)(b * P + pq), tiles)) ++pq;
+        return __builtin_amdgcn_readfirstlane(pq);
     };
     int p = next_plane(p_lo);
-    float2 hh[PER];  // the plane's transfer-function values; the next plane's are in flight during the transform
+    // gF_p = gAcc conj(H_p) by recurrence, as the forward: w = gAcc conj(H) at the block's first plane, then w <- w conj(D) per plane
+    // (H_(p+1) = H_p D); no transfer-function value is read inside the plane loop
+    float2 w[PER], Dc[PER];
+    {
+        const __amdgpu_buffer_rsrc_t hp = colfft_rsrc(htab + ((size_t)c * P + min(p, P - 1)) * HW + c0);
+        const __amdgpu_buffer_rsrc_t dt = colfft_rsrc(htab + ((size_t)3 * P + c) * HW + c0);
 #pragma unroll
-    for (int e = 0; e < PER; ++e)
-        hh[e] = (live && p < p_hi) ? htab[((size_t)c * P + p) * HW + c0 + col + (size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W]
-                                   : make_float2(0.0f, 0.0f);
+        for (int e = 0; e < PER; ++e) {
+            const uint32_t so = (uint32_t)(colfft_freq_e<LOGN, INNER>(e) * W) * 8u;
+            const float2 hh = ld_f2(hp, off_in, so), d = ld_f2(dt, off_in, so);
+            w[e] = cmul(g[e], make_float2(hh.x, -hh.y));
+            Dc[e] = make_float2(d.x, -d.y);
+        }
+    }
     __syncthreads();  // twiddles
+    auto plane_step = [&](int gap) {  // gap: planes to the next one with Gaussians
+        const __amdgpu_buffer_rsrc_t f = colfft_rsrc(field + (((size_t)b * P + p) * 3 + c) * HW + c0);
+        float2 v[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) v[e] = w[e];
+        for (int i = 0; i < gap; ++i) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) w[e] = cmul(w[e], Dc[e]);
+        }
+        if (INNER) oct_dit<true>(v, v[0], v[0], v[0]);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) x[in_row(e)][col] = v[e];
+        __syncthreads();
+        lds_fft_columns<LOGN, TC, NT, true, true, INNER>(x, tw);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) v[e] = x[q + e * E1][col];
+        __syncthreads();  // the tile is read: the next plane may be written over it
+        oct_dit<false>(v, tw[q], tw[2 * q], tw[4 * q]);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) st_f2(f, off_out, (uint32_t)(e * E1 * W) * 8u, v[e]);
+    };
     while (p < p_hi) {
         const int pn = next_plane(p + 1);
-        float2 *f = field + (((size_t)b * P + p) * 3 + c) * HW + c0 + col;
-#pragma unroll
-        for (int e = 0; e < PER; ++e) x[r0 + e * (NT / TC)][col] = cmul(g[e], make_float2(hh[e].x, -hh[e].y));
-        __syncthreads();
-        if (live && pn < p_hi) {
-            const float2 *h = htab + ((size_t)c * P + pn) * HW + c0 + col;
-#pragma unroll
-            for (int e = 0; e < PER; ++e) hh[e] = h[(size_t)bitrev<LOGN>(r0 + e * (NT / TC)) * W];
-        }
-        lds_fft_columns<LOGN, TC, NT, true>(x, tw);
-        if (live) {
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                const int r = r0 + e * (NT / TC);
-                f[(size_t)r * W] = x[r][col];
-            }
-        }
-        __syncthreads();
+        plane_step(pn - p);
         p = pn;
     }
 #pragma unroll
@@ -672,7 +803,7 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     if (threadIdx.x == 0) {
         float t = 0.0f;
         for (int w = 0; w < NT / 64; ++w) t += wpart[w];
-        pwl[(size_t)c * (gridDim.x * gridDim.z) + blockIdx.z * gridDim.x + blockIdx.x] = t;
+        pwl[(size_t)c * (gridDim.x * gridDim.z) + bz * gridDim.x + bx] = t;
     }
 }
 
@@ -1087,7 +1218,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
     {
-        const size_t nh = 3 * (size_t)P * (size_t)(W / 2 + 1) * (size_t)(H / 2 + 1);  // one quadrant, mirrored
+        const size_t nh = 3 * (size_t)(P + 1) * (size_t)(W / 2 + 1) * (size_t)(H / 2 + 1);  // one quadrant, mirrored; + the step factors D
         const uint32_t nb_ph = (ngauss + 255) / 256, nb_tr = (uint32_t)((nh + 255) / 256);
         hipLaunchKernelGGL(k_asm_prep, dim3(nb_ph + nb_tr + 1), dim3(256), 0, st, nb_ph, nb_tr, ngauss, a.phase_channels,
                            color, phase, ccs, W, H, P, a.depth_near, a.depth_far, a.focal_depth, inv_ndx, inv_ndy,
@@ -1145,7 +1276,7 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
             case 6: FGS_COLFFT_FWD(6, 16); break;
             case 7: FGS_COLFFT_FWD(7, 16); break;
             case 8: FGS_COLFFT_FWD(8, 16); break;
-            case 9: FGS_COLFFT_FWD(9, 16); break;
+            case 9: FGS_COLFFT_FWD(9, FGS_COLFFT_TC9); break;
             default: FGS_COLFFT_FWD(10, 8); break;
         }
 #undef FGS_COLFFT_FWD
@@ -1228,7 +1359,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
             case 6: FGS_COLFFT_BWD(6, 16); break;
             case 7: FGS_COLFFT_BWD(7, 16); break;
             case 8: FGS_COLFFT_BWD(8, 16); break;
-            case 9: FGS_COLFFT_BWD(9, 16); break;
+            case 9: FGS_COLFFT_BWD(9, FGS_COLFFT_TC9); break;
             default: FGS_COLFFT_BWD(10, 8); break;
         }
 #undef FGS_COLFFT_BWD
