@@ -532,6 +532,29 @@ __device__ __forceinline__ constexpr int colfft_freq_e(int e) {
 template <int LOGN, bool INNER>
 __device__ __forceinline__ int colfft_freq_t(int q) { return INNER ? bitrev<LOGN - 3>(q) : 8 * bitrev<LOGN - 3>(q); }
 
+// The planes of image b that hold Gaussians, as a bit mask in scalar registers (bit p; every wave takes it with one ballot at kernel
+// start): the column kernels used to ask seg_off plane by plane -- two dependent global loads in front of every plane step.
+// More than 64 planes, or no seg_off: every plane counts as occupied (skipping is an optimisation, empty planes hold zeros).
+__device__ __forceinline__ uint64_t asm_plane_mask(const uint32_t *__restrict__ seg_off, int b, int P, uint32_t tiles) {
+    if (!seg_off || P > 64) return ~0ull;
+    const int l = (int)(threadIdx.x & 63u);
+    const bool occ = l < P && !asm_plane_empty(seg_off, (uint32_t)(b * P + l), tiles);
+    const uint64_t m = __ballot(occ);
+    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)m);
+}
+__device__ __forceinline__ int asm_plane_at_or_below(uint64_t mask, int pq, int p_lo) {  // last occupied plane in [p_lo, pq], or p_lo - 1
+    if (pq < p_lo) return p_lo - 1;
+    const uint64_t m = mask & (pq >= 63 ? ~0ull : ((2ull << pq) - 1ull)) & ~((1ull << p_lo) - 1ull);
+    return m ? 63 - __builtin_clzll(m) : p_lo - 1;
+}
+__device__ __forceinline__ int asm_plane_at_or_above(uint64_t mask, int pq, int p_hi) {  // first occupied plane in [pq, p_hi), or p_hi
+    if (pq >= p_hi) return p_hi;
+    if (pq >= 64) return pq;
+    const uint64_t m = mask & ~((1ull << pq) - 1ull);
+    const int f = m ? __builtin_ctzll(m) : 64;
+    return f < p_hi ? f : (p_hi > 64 ? 64 : p_hi);
+}
+
 // Launch order of the column kernels' blocks (grid (column tiles, 3, images x plane groups)) -> (column tile, channel, image, group).
 // ORDER 0: as dispatched (round-robin over the XCDs).  1: every XCD walks a contiguous range, column tile fastest.  2: contiguous
 // range, IMAGE fastest: the blocks of all images for one (plane group, channel, column tile) start together on one XCD and walk the
@@ -612,10 +635,8 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(in
             D[e] = ld_f2(dt, off_out, (uint32_t)(colfft_freq_e<LOGN, INNER>(e) * W) * 8u);
         }
     }
-    auto prev_plane = [&](int pq) {  // last plane <= pq of this group that has Gaussians (all of them when seg_off == nullptr), or p_lo - 1
-        while (seg_off && pq >= p_lo && asm_plane_empty(seg_off, (uint32_t)(b * P + pq), tiles)) --pq;
-        return __builtin_amdgcn_readfirstlane(pq);
-    };
+    const uint64_t occupied = asm_plane_mask(seg_off, b, P, tiles);
+    auto prev_plane = [&](int pq) { return asm_plane_at_or_below(occupied, pq, p_lo); };  // last plane <= pq of this group with Gaussians
     auto skip_planes = [&](int m) {  // m planes with F = 0
         for (int i = 0; i < m; ++i) {
 #pragma unroll
@@ -750,10 +771,8 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
         }
     }
     // a plane without Gaussians has a zero spectrum and nobody reads its gradient: skipped (block-uniform)
-    auto next_plane = [&](int pq) {
-        while (seg_off && pq < p_hi && asm_plane_empty(seg_off, (uint32_t)(b * P + pq), tiles)) ++pq;
-        return __builtin_amdgcn_readfirstlane(pq);
-    };
+    const uint64_t occupied = asm_plane_mask(seg_off, b, P, tiles);
+    auto next_plane = [&](int pq) { return asm_plane_at_or_above(occupied, pq, p_hi); };
     int p = next_plane(p_lo);
     // gF_p = gAcc conj(H_p) by recurrence, as the forward: w = gAcc conj(H) at the block's first plane, then w <- w conj(D) per plane
     // (H_(p+1) = H_p D); no transfer-function value is read inside the plane loop

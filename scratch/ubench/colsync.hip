@@ -39,6 +39,9 @@ __global__ __launch_bounds__(1024) void k(const float2 *field, float2 *out) {
     }
     if (s.x == 123.456f) out[0] = lds[threadIdx.x + 8000];
 }
+__global__ __launch_bounds__(1024) void k_fill(float2 *field, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024) { unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; field[i] = make_float2(__uint_as_float(0x3f800000u | (h >> 9)), __uint_as_float(0x3f800000u | ((h * 3266489917u) >> 9))); }
+}
 template <class F>
 void run(const char *name, F launch) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -65,5 +68,11 @@ int main() {
     run("tile, 4 ahead, neither", [&] { hipLaunchKernelGGL((k<true, 4, 0>), g, dim3(1024), 0, 0, d, o); });
     run("tile, 4 ahead, barriers only", [&] { hipLaunchKernelGGL((k<true, 4, 2>), g, dim3(1024), 0, 0, d, o); });
     run("contiguous, 4 ahead, neither", [&] { hipLaunchKernelGGL((k<false, 4, 0>), g, dim3(1024), 0, 0, d, o); });
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(1024), 0, 0, d, n); hipDeviceSynchronize();
+    run("random data: tile 1 ahead LDS + barriers", [&] { hipLaunchKernelGGL((k<true, 1, 3>), g, dim3(1024), 0, 0, d, o); });
+    run("random data: tile 2 ahead LDS + barriers", [&] { hipLaunchKernelGGL((k<true, 2, 3>), g, dim3(1024), 0, 0, d, o); });
+    run("fill only (row-FFT stand-in)", [&] { hipLaunchKernelGGL(k_fill, dim3(2048), dim3(1024), 0, 0, d, n); });
+    run("fill + tile 1 ahead LDS + barriers", [&] { hipLaunchKernelGGL(k_fill, dim3(2048), dim3(1024), 0, 0, d, n); hipLaunchKernelGGL((k<true, 1, 3>), g, dim3(1024), 0, 0, d, o); });
+    run("fill + tile 2 ahead LDS + barriers", [&] { hipLaunchKernelGGL(k_fill, dim3(2048), dim3(1024), 0, 0, d, n); hipLaunchKernelGGL((k<true, 2, 3>), g, dim3(1024), 0, 0, d, o); });
     return 0;
 }

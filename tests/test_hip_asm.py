@@ -154,12 +154,14 @@ def test_asm_batched_nonsquare_vs_oracle():
     assert rel_to_max(out["grad_wavelengths"], gw) <= 1e-3
 
 
-@pytest.mark.parametrize("W,H", [(72, 64), (96, 256), (40, 1024)])
+@pytest.mark.parametrize("W,H", [(72, 64), (80, 64), (96, 128), (96, 256), (40, 1024)])
 def test_asm_column_fused_transforms_vs_oracle(W, H):
-    """Power-of-two heights take the column-fused path (rocFFT rows + k_colfft_fwd / k_colfft_bwd: our own radix-4
-    column FFT in LDS, fused with the transfer-function multiply, the plane sum and their adjoints): widths that are
-    not a multiple of the 16-column tile, the 8-column tile of H = 1024, two images, per-channel phases; image and all
-    gradients incl. the wavelengths' against the oracle (torch.fft on the CPU)."""
+    """Power-of-two heights take the column-fused path (rocFFT rows + k_colfft_fwd / k_colfft_bwd: our own radix-8
+    column FFT in LDS and registers, fused with the transfer-function recurrence, the plane sums and their adjoints)
+    when the width is a whole number of column tiles -- every log2(H) class of the kernels (64 = 8^2 and 512 = 8^3 close
+    with a register butterfly, 128 / 256 / 1024 with a radix-2 / radix-4 pass), the 8-column tile of H = 1024 -- and
+    rocFFT's 2-D plans otherwise (72 x 64); two images, per-channel phases; image and all gradients incl. the
+    wavelengths' against the oracle (torch.fft on the CPU)."""
     from oracle import asm_oracle, fgs_oracle as orc
     from fresnel_amd.renderer import Camera
     N, Bn = 300, 2
@@ -184,6 +186,48 @@ def test_asm_column_fused_transforms_vs_oracle(W, H):
     for b in range(Bn):
         r = asm_oracle.render(*[a[b] for a in arrs], phases[b], wl, ocam, bg=bg, num_planes=6,
                               depth_range=(0.3, 2.2), focal_depth=0.9, pixel_pitch=1.0 / 200.0, grad_out=gI[b])
+        assert np.abs(out["image"][b] - r["image"]).max() <= TOL
+        for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
+            assert rel_to_max(out["grad_" + k][b], r["grad_" + k]) <= TOL, (b, k)
+        gw = gw + r["grad_wavelengths"]
+    assert rel_to_max(out["grad_wavelengths"], gw) <= 1e-3
+
+
+@pytest.mark.parametrize("H,planes", [(512, [[1, 4, 5, 11], [0, 15]]), (256, [[2, 3, 9], [7]]), (64, [[0, 1, 2, 3, 13], [5, 6]])])
+def test_asm_plane_recurrence_with_empty_planes_vs_oracle(H, planes):
+    """The column kernels walk the depth planes by the recurrence H_(p+1) = H_p D (Horner sums over descending planes forward,
+    a running product backward) and jump over the planes of an image that hold no Gaussian: scenes whose Gaussians sit in a few
+    chosen planes of 16 (gaps of 1 ... 14 planes, first / last plane empty or not, different per image), image and every
+    gradient incl. the wavelengths' against the oracle, which evaluates every plane's transfer function directly."""
+    from oracle import asm_oracle, fgs_oracle as orc
+    from fresnel_amd.renderer import Camera
+    W, N, P = 96, 240, 16
+    near, far = 0.4, 2.4
+    bg = (0.02, 0.04, 0.06)
+    rs = np.random.RandomState(H + len(planes[0]))
+    depth_of = np.linspace(near, far, P)
+    per = []
+    for b, occ in enumerate(planes):
+        pos, scale, quat, col, opa = synth_aniso(N, 310 + b, opacity_max=0.9, smin=0.03, smax=0.1)
+        pos[:, 1] *= H / W * 0.6 if H > W else 1.0
+        # depth = a chosen plane's depth +- a quarter of the plane spacing: the nearest plane is that one
+        pl = rs.choice(occ, N)
+        pos[:, 2] = -(depth_of[pl] + rs.uniform(-0.25, 0.25, N) * (far - near) / (P - 1)).astype(np.float32)
+        per.append((pos, scale, quat, col, opa))
+    arrs = [np.stack([q[i] for q in per]) for i in range(5)]
+    Bn = len(planes)
+    phases = (rs.random_sample((Bn, N, 3)) * 2 * np.pi).astype(np.float32)
+    wl = np.array([0.07, 0.052, 0.043], np.float32)
+    gI = rs.standard_normal((Bn, 3, H, W)).astype(np.float32)
+    f = 0.8 * min(W, H)
+    cam = Camera(f, f, W / 2, H / 2, W, H)
+    kw = dict(num_depth_planes=P, depth_range=(near, far), focal_depth=1.1, pixel_pitch=1.0 / 200.0)
+    out = _hip_asm(arrs, phases, wl, cam, W, H, bg, gI=gI, **kw)
+    ocam = orc.make_camera(np.eye(4, dtype=np.float32), f, f, W / 2, H / 2, W, H)
+    gw = 0.0
+    for b in range(Bn):
+        r = asm_oracle.render(*[a[b] for a in arrs], phases[b], wl, ocam, bg=bg, num_planes=P,
+                              depth_range=(near, far), focal_depth=1.1, pixel_pitch=1.0 / 200.0, grad_out=gI[b])
         assert np.abs(out["image"][b] - r["image"]).max() <= TOL
         for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
             assert rel_to_max(out["grad_" + k][b], r["grad_" + k]) <= TOL, (b, k)
