@@ -484,18 +484,21 @@ __device__ __forceinline__ float image_max(const float *__restrict__ pmax, int b
 // ---- column-fused 2-D transforms (power-of-two heights) ------------------------------------------------------------
 // rocFFT's 2-D C2C transform of the B*P*3 plane fields is a row kernel (0.30 ms for 805 MB at 8 images, 5.4 TB/s) and a
 // column kernel (0.80 ms, 2 TB/s), followed here by k_asm_accumulate, which reads the spectra once more (0.23 ms).  For
-// H = 64 ... 1024 the column direction is done by our own kernels instead, fused with what follows / precedes it:
-//   forward   rocFFT 1-D rows, then k_colfft_fwd: per (image, channel, tile of TC columns) and plane -- load the H x TC
-//             tile into LDS (rows of TC complex: 128-byte segments), radix-4 decimation-in-frequency FFT down the columns
-//             (output in bit-reversed row order, undone by the store addresses), multiply by H_pc and accumulate over the
-//             planes (acc_c in registers, Z_c -- all the backward needs for dL/dlambda -- in LDS); both written once;
-//   backward  k_colfft_bwd: gF = gAcc conj(H_pc) per plane straight into LDS in bit-reversed row order, radix-8
-//             decimation-in-time inverse FFT (natural order out), store; the dL/dlambda terms from Z; then rocFFT
+// H = 64 ... 1024 (powers of two; widths that are whole column tiles) the column direction is done by our own kernels instead, fused
+// with what follows / precedes it:
+//   forward   rocFFT 1-D rows, then k_colfft_fwd: per (image, channel, tile of TC columns) and plane -- the H x TC tile streams into
+//             LDS (rows of TC complex: 128-byte segments), radix-8 decimation-in-frequency FFT down the columns (first and, for
+//             H = 8^k, last pass in registers; output in bit-reversed row order, undone by the store addresses), and the spectrum
+//             goes into the Horner sums of the plane recurrence H_(p+1) = H_p D (no transfer-function value is read per plane);
+//             acc_c and Z_c -- all the backward needs for dL/dlambda -- are written once;
+//   backward  k_colfft_bwd: gF = gAcc conj(H_pc) per plane (the same recurrence) in bit-reversed row order, radix-8
+//             decimation-in-time inverse FFT (natural order out) straight to HBM; the dL/dlambda terms from Z; then rocFFT
 //             1-D inverse rows.
 // The column pass reads the plane data once (forward) / writes it once (backward) instead of two reads and one write plus
 // the accumulate kernel's pass.  Unnormalised, like hipFFT.  Twiddles w_N^n = exp(-2 pi i n / N) from a global table (k_asm_prep).
 // Eight tile elements per thread: NT = N * TC / 8 threads per block (1024 for a 512 x 16 tile).  (The first version ran
-// 256 threads with 32 elements each: 270 / 458 VGPRs, one wave per SIMD, 1.9 / 1.3 ms at 8 images.)
+// 256 threads with 32 elements each: 270 / 458 VGPRs, one wave per SIMD, 1.9 / 1.3 ms at 8 images.)  History and measurements:
+// DESIGN.md 10.5.
 constexpr int COLFFT_PER = 8;
 
 template <int NT>
@@ -586,8 +589,7 @@ __device__ __forceinline__ void colfft_block(int PG, int &bx, int &c, int &b, in
 // forward: acc[b][c] = sum_p F_pc H_pc and Z[b][c] = sum_p z_p F_pc H_pc.  grid (column tiles, 3, B)
 // The spectra F are NOT stored (round 3): the backward needs them only in dL/dlambda_c = sum_k 2 pi dkz_k sum_p z_p dL/dtheta_pk with
 // dL/dtheta_pk = -Im(conj(gAcc_k) H_pk F_pk), i.e. in Z_k = sum_p z_p H_pk F_pk -- linear in F, so it is summed here beside acc
-// (in registers, next to acc) and the backward reads 50 MB of Z instead of
-// 0.65 GB of spectra, which the forward no longer writes either: -1.3 GB of the 7.4 GB a config-5 step moved at 8 images.
+// and the backward reads 50 MB of Z instead of 0.8 GB of spectra, which the forward no longer writes either.
 // Planes of image b without any list entry are skipped (`seg_off`, see asm_plane_empty): their fields are zero (the row-fused build never writes them)
 template <int LOGN, int TC>
 __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(int W, int P, int PG, float2 *__restrict__ field,
