@@ -150,7 +150,7 @@ int fgs_count_pairs(const FgsDims *dims, const void *saved, uint64_t *out_pairs,
  * fgs_asm_backward writes gradients of sum(out_rgb*g_rgb) w.r.t. all Gaussian inputs, the
  * phases and the three wavelengths (dkz/dlambda is taken as 0 where 1/l^2-fx^2-fy^2 <= 0; the
  * reference's autograd returns NaN/inf when a frequency lands exactly on that boundary).
- * fgs_asm_backward CONSUMES `saved` (the stored plane spectra are overwritten by their
+ * fgs_asm_backward CONSUMES `saved` (the plane fields / spectra in it are overwritten by their
  * gradients): one backward per forward.
  * The first call for a shape builds the hipFFT plans (host work); later calls only enqueue. */
 typedef struct FgsAsmDims {
