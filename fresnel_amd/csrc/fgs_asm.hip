@@ -79,6 +79,9 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     if (rc) return rc;
     const size_t B = a->batch, P = a->num_planes, HW = (size_t)a->width * a->height;
     p->HW = HW;
+    // (The forward splat keeps its longest-lists-first order over the whole launch.  Grouping it by image, last image first, so that
+    // rocFFT's ascending row pass finds the planes it reads first in the memory-side cache, was measured at config 5, 8 images: row pass
+    // 300 -> 261 us, k_colfft_fwd -4 us, but the splat itself 249 -> 312 us and k_tile_post 9 -> 22 us: net +1 %.)
     size_t o = p->base.L.total_bytes;
     p->v_field = o; o = align256(o + B * P * 3 * HW * 8);
     p->v_htab = o; o = align256(o + 3 * (P + 1) * HW * 8);
@@ -275,9 +278,13 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
     // the grid is sized from the capacity, surplus blocks leave at once) -- balanced however uneven the lists.
     uint32_t key, seg = 0;
     if (BWD) {
-        if (blockIdx.x >= counters[2]) return;
-        key = seg_tile[blockIdx.x];
-        seg = blockIdx.x - seg_off[key];
+        const uint32_t nunits = counters[2];
+        if (blockIdx.x >= nunits) return;
+        // units in DESCENDING key order: the row transform in front of this kernel wrote the planes in ascending order, the last
+        // 256 MB of them are still in the memory-side cache (-1 %: the kernel is VALU-bound)
+        const uint32_t unit = nunits - 1u - blockIdx.x;
+        key = seg_tile[unit];
+        seg = unit - seg_off[key];
     } else {
         key = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (b*P + p)*T + t
     }
@@ -560,18 +567,25 @@ __device__ __forceinline__ int asm_plane_at_or_above(uint64_t mask, int pq, int 
 
 // Launch order of the column kernels' blocks (grid (column tiles, 3, images x plane groups)) -> (column tile, channel, image, group).
 // ORDER 0: as dispatched (round-robin over the XCDs).  1: every XCD walks a contiguous range, column tile fastest.  2: contiguous
-// range, IMAGE fastest: the blocks of all images for one (plane group, channel, column tile) start together on one XCD and walk the
-// planes side by side, so a tile of the transfer-function table is fetched into that XCD's L2 once and found there by the others.
-// Measured (config 5, profiles/r03_ab_config5_colfft.txt): at 8 images order 2 beats order 0 by 15 % on the forward kernel, at one
-// image (six plane groups) order 0 is the faster one by 20 %: the kernels take order 2 from four images up.
+// range, IMAGE fastest (from the time when every image re-read the transfer functions per plane: a table tile was then fetched into
+// one XCD's L2 once and found there by the other images' blocks).  3 / 4: orders 1 / 0 with the images in DESCENDING order -- rocFFT's row
+// pass walks the planes in ascending order, so the forward kernel starts on the planes written last and the backward kernel writes
+// last what the row pass will read first: what is still in the 256 MB memory-side cache is not fetched from HBM.
+// Measured (config 5, 8 images, profiles/r03_ab_config5_colfft.txt; k_colfft_fwd / k_colfft_bwd / the inverse row pass behind it, us):
+// order 2: 224 / 152 / 286; order 3: 228 / 147 / 281; order 4: 221 / 144 / 256.  At one image (six plane groups, everything fits the cache)
+// order 0 is 20 % faster than the XCD-contiguous orders: the kernels take ORDER_MANY from four images up.
 template <int ORDER_MANY>
 __device__ __forceinline__ void colfft_block(int PG, int &bx, int &c, int &b, int &grp) {
     const int ORDER = gridDim.z / (uint32_t)PG >= 4u ? ORDER_MANY : 0;
+    if (ORDER == 4) {  // dispatch order, images descending
+        bx = blockIdx.x; c = blockIdx.y; const int bz = (int)gridDim.z - 1 - (int)blockIdx.z; b = bz / PG; grp = bz - b * PG; return;
+    }
     if (ORDER == 0) { bx = blockIdx.x; c = blockIdx.y; b = blockIdx.z / PG; grp = blockIdx.z - b * PG; return; }
     const uint32_t lin = fgs_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + 3u * blockIdx.z), gridDim.x * 3u * gridDim.z);
-    if (ORDER == 1) {
+    if (ORDER == 1 || ORDER == 3) {  // 3: images in descending order (the planes rocFFT wrote last / reads first are handled first / last)
         bx = (int)(lin % gridDim.x); c = (int)((lin / gridDim.x) % 3u);
-        const int bz = (int)(lin / (gridDim.x * 3u));
+        int bz = (int)(lin / (gridDim.x * 3u));
+        if (ORDER == 3) bz = (int)gridDim.z - 1 - bz;
         b = bz / PG; grp = bz - b * PG;
     } else {
         const uint32_t nimg = gridDim.z / (uint32_t)PG;
@@ -580,10 +594,10 @@ __device__ __forceinline__ void colfft_block(int PG, int &bx, int &c, int &b, in
     }
 }
 #ifndef FGS_COLFFT_ORDER_FWD
-#define FGS_COLFFT_ORDER_FWD 2
+#define FGS_COLFFT_ORDER_FWD 4
 #endif
 #ifndef FGS_COLFFT_ORDER_BWD
-#define FGS_COLFFT_ORDER_BWD 2
+#define FGS_COLFFT_ORDER_BWD 4
 #endif
 
 // forward: acc[b][c] = sum_p F_pc H_pc and Z[b][c] = sum_p z_p F_pc H_pc.  grid (column tiles, 3, B)
