@@ -544,7 +544,7 @@ __device__ __forceinline__ int colfft_freq_t(int q) { return INNER ? bitrev<LOGN
 
 // The planes of image b that hold Gaussians, as a bit mask in scalar registers (bit p; every wave takes it with one ballot at kernel
 // start): the column kernels used to ask seg_off plane by plane -- two dependent global loads in front of every plane step.
-// More than 64 planes, or no seg_off: every plane counts as occupied (skipping is an optimisation, empty planes hold zeros).
+// (The interface admits at most 64 planes.)  No seg_off: every plane counts as occupied (skipping is an optimisation, empty planes hold zeros).
 __device__ __forceinline__ uint64_t asm_plane_mask(const uint32_t *__restrict__ seg_off, int b, int P, uint32_t tiles) {
     if (!seg_off || P > 64) return ~0ull;
     const int l = (int)(threadIdx.x & 63u);
@@ -554,6 +554,7 @@ __device__ __forceinline__ uint64_t asm_plane_mask(const uint32_t *__restrict__ 
 }
 __device__ __forceinline__ int asm_plane_at_or_below(uint64_t mask, int pq, int p_lo) {  // last occupied plane in [p_lo, pq], or p_lo - 1
     if (pq < p_lo) return p_lo - 1;
+    if (mask == ~0ull) return pq;  // every plane counts as occupied
     const uint64_t m = mask & (pq >= 63 ? ~0ull : ((2ull << pq) - 1ull)) & ~((1ull << p_lo) - 1ull);
     return m ? 63 - __builtin_clzll(m) : p_lo - 1;
 }

@@ -193,15 +193,17 @@ def test_asm_column_fused_transforms_vs_oracle(W, H):
     assert rel_to_max(out["grad_wavelengths"], gw) <= 1e-3
 
 
-@pytest.mark.parametrize("H,planes", [(512, [[1, 4, 5, 11], [0, 15]]), (256, [[2, 3, 9], [7]]), (64, [[0, 1, 2, 3, 13], [5, 6]])])
-def test_asm_plane_recurrence_with_empty_planes_vs_oracle(H, planes):
+@pytest.mark.parametrize("H,P,planes", [(512, 16, [[1, 4, 5, 11], [0, 15]]), (256, 16, [[2, 3, 9], [7]]),
+                                        (64, 16, [[0, 1, 2, 3, 13], [5, 6]]), (64, 64, [[3, 40, 60, 63], [0, 62]])])
+def test_asm_plane_recurrence_with_empty_planes_vs_oracle(H, P, planes):
     """The column kernels walk the depth planes by the recurrence H_(p+1) = H_p D (Horner sums over descending planes forward,
     a running product backward) and jump over the planes of an image that hold no Gaussian: scenes whose Gaussians sit in a few
     chosen planes of 16 (gaps of 1 ... 14 planes, first / last plane empty or not, different per image), image and every
-    gradient incl. the wavelengths' against the oracle, which evaluates every plane's transfer function directly."""
+    gradient incl. the wavelengths' against the oracle, which evaluates every plane's transfer function directly.  64 planes: the most
+    the interface admits (the occupancy mask's last bit, 63 recurrence steps)."""
     from oracle import asm_oracle, fgs_oracle as orc
     from fresnel_amd.renderer import Camera
-    W, N, P = 96, 240, 16
+    W, N = 96, 240
     near, far = 0.4, 2.4
     bg = (0.02, 0.04, 0.06)
     rs = np.random.RandomState(H + len(planes[0]))
