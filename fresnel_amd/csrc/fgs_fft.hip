@@ -88,13 +88,14 @@ int fgs_fft_rows_work_bytes(int W, int rows, size_t *bytes) { return fgs_fft_wor
 // ---- 2-D transforms with our own column pass ---------------------------------------------------------------------
 // rocFFT's 2-D C2C plans run a row kernel at ~5.4 TB/s and a column kernel at ~2 TB/s (config 5's 805 MB: 0.30 + 0.80 ms).
 // For heights 64 ... 1024 that are powers of two fgs_fft2_exec uses rocFFT for the rows only and k_colfft_plain for the
-// columns: per (field, tile of TC columns) the H x TC tile goes through LDS (128-byte row segments), radix-4 FFT down the
+// columns: per (field, tile of TC columns) the H x TC tile goes through LDS (128-byte row segments), radix-8 FFT down the
 // columns (fgs_colfft.h), one read and one write of the data.  Other heights: rocFFT's 2-D plan.  Unnormalised both ways.
 namespace {
 
 template <int LOGN, int TC, bool INV>
 __global__ __launch_bounds__((1 << LOGN) * TC / 8) void k_colfft_plain(int W, float2 *__restrict__ data) {
-    constexpr int N = 1 << LOGN, PER = 8, NT = N * TC / PER;
+    constexpr int N = 1 << LOGN, PER = 8, NT = N * TC / PER, E1 = N / 8;
+    constexpr bool INNER = lds_fft_inner_in_registers<LOGN>();
     __shared__ float2 x[N][TC];
     __shared__ float2 tw[N / 2];
     for (int n = threadIdx.x; n < N / 2; n += NT) {
@@ -102,23 +103,44 @@ __global__ __launch_bounds__((1 << LOGN) * TC / 8) void k_colfft_plain(int W, fl
         sincospif(-2.0f * (float)n / (float)N, &sn, &cs);
         tw[n] = make_float2(cs, sn);
     }
-    const int c0 = blockIdx.x * TC, col = threadIdx.x % TC, r0 = threadIdx.x / TC;
+    const int c0 = blockIdx.x * TC, col = threadIdx.x % TC, q = threadIdx.x / TC;
     const bool live = c0 + col < W;
     float2 *f = data + (size_t)blockIdx.y * N * W + c0 + col;
-    // forward: natural rows in, LDS row r ends up holding frequency bitrev(r); inverse: frequency k goes to LDS row
-    // bitrev(k), natural rows out
+    // As in the column kernels of the angular-spectrum renderer (fgs_asm.hip): the block-size-N pass runs in registers on the thread's
+    // own eight elements (rows q + e N/8: first forward, straight from HBM; last inverse, straight to HBM) and, for N = 8^k, so does
+    // the block-size-8 pass (rows 8 q + e, unit twiddles).  LDS row r holds frequency bitrev(r) between the two.
+    float2 v[PER];
+    if (!INV) {
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const int r = r0 + e * (NT / TC);
-        x[r][col] = live ? f[(size_t)(INV ? bitrev<LOGN>(r) : r) * W] : make_float2(0.0f, 0.0f);
-    }
-    __syncthreads();
-    lds_fft_columns<LOGN, TC, NT, INV>(x, tw);
-    if (live) {
+        for (int e = 0; e < PER; ++e) v[e] = live ? f[(size_t)(q + e * E1) * W] : make_float2(0.0f, 0.0f);
+        __syncthreads();  // twiddles
+        oct_dif<false>(v, tw[q], tw[2 * q], tw[4 * q]);
 #pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const int r = r0 + e * (NT / TC);
-            f[(size_t)(INV ? r : bitrev<LOGN>(r)) * W] = x[r][col];
+        for (int e = 0; e < PER; ++e) x[q + e * E1][col] = v[e];
+        __syncthreads();
+        lds_fft_columns<LOGN, TC, NT, false, true, INNER>(x, tw);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) v[e] = x[INNER ? 8 * q + e : q + e * E1][col];
+        if (INNER) oct_dif<true>(v, v[0], v[0], v[0]);
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) f[(size_t)bitrev<LOGN>(INNER ? 8 * q + e : q + e * E1) * W] = v[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            v[e] = live ? f[(size_t)bitrev<LOGN>(INNER ? 8 * q + e : q + e * E1) * W] : make_float2(0.0f, 0.0f);
+        if (INNER) oct_dit<true>(v, v[0], v[0], v[0]);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) x[INNER ? 8 * q + e : q + e * E1][col] = v[e];
+        __syncthreads();  // (twiddles too)
+        lds_fft_columns<LOGN, TC, NT, true, true, INNER>(x, tw);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) v[e] = x[q + e * E1][col];
+        oct_dit<false>(v, tw[q], tw[2 * q], tw[4 * q]);
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < PER; ++e) f[(size_t)(q + e * E1) * W] = v[e];
         }
     }
 }
