@@ -169,7 +169,9 @@ __device__ __forceinline__ float plane_depth(int k, int P, float near_, float fa
 // Behind the 3 P planes: D[c][ky][kx] = exp(i * ((2 pi * -step) * kz)), step = (far - near) / (P - 1) -- the planes are equally spaced
 // (torch.linspace, DR:1194), so H_(p+1) = H_p D and the column kernels walk the planes by this recurrence instead of reading H_p
 // (k_colfft_fwd / k_colfft_bwd; the table itself is still what k_asm_accumulate[_bwd] and each block's first plane read).
-__device__ __forceinline__ void asm_transfer_block(uint32_t blk, int W, int H, int P, float near_, float far_, float focal,
+// `pstride` > 1 (the column kernels' path): only the planes 0, pstride, 2 pstride, ... -- the first plane of each plane group, which is
+// all that path reads of H -- and D are evaluated (3 x 2 planes instead of 3 x 17 at config 5's 8 images: 22 -> 5 us per forward).
+__device__ __forceinline__ void asm_transfer_block(uint32_t blk, int W, int H, int P, int pstride, float near_, float far_, float focal,
                                                    float inv_ndx, float inv_ndy,
                                                    const float *__restrict__ wavelengths,
                                                    float2 *__restrict__ htab) {
@@ -177,9 +179,11 @@ __device__ __forceinline__ void asm_transfer_block(uint32_t blk, int W, int H, i
     const int QW = W / 2 + 1, QH = H / 2 + 1;
     const size_t QHW = (size_t)QW * QH;
     const size_t i = (size_t)blk * 256 + threadIdx.x;
-    if (i >= 3 * (size_t)(P + 1) * QHW) return;
+    const int np = (P + pstride - 1) / pstride;  // planes evaluated per channel (+ D)
+    if (i >= 3 * (size_t)(np + 1) * QHW) return;
     const int kx = (int)(i % QW), ky = (int)((i / QW) % QH);
-    const int p = (int)((i / QHW) % (P + 1)), c = (int)(i / (QHW * (P + 1)));
+    const int pi = (int)((i / QHW) % (np + 1)), c = (int)(i / (QHW * (np + 1)));
+    const int p = pi < np ? pi * pstride : P;
     const float fx = fftfreq(kx, W, inv_ndx), fy = fftfreq(ky, H, inv_ndy);
     const float il = 1.0f / wavelengths[c];
     float kz2 = il * il - fx * fx - fy * fy;
@@ -233,11 +237,11 @@ __global__ __launch_bounds__(256) void k_asm_prep(uint32_t nb_ph, uint32_t nb_tr
                                                   float *__restrict__ ccs, int W, int H, int P, float near_, float far_,
                                                   float focal, float inv_ndx, float inv_ndy,
                                                   const float *__restrict__ wavelengths, float2 *__restrict__ htab, int N,
-                                                  float2 *__restrict__ tw) {
+                                                  float2 *__restrict__ tw, int pstride) {
     if (blockIdx.x < nb_ph) {
         asm_phasors_block(blockIdx.x, total, phase_channels, color, phase, ccs);
     } else if (blockIdx.x < nb_ph + nb_tr) {
-        asm_transfer_block(blockIdx.x - nb_ph, W, H, P, near_, far_, focal, inv_ndx, inv_ndy, wavelengths, htab);
+        asm_transfer_block(blockIdx.x - nb_ph, W, H, P, pstride, near_, far_, focal, inv_ndx, inv_ndy, wavelengths, htab);
     } else {
         for (int n = threadIdx.x; n < N / 2; n += 256) {
             float sn, cs;
@@ -714,25 +718,30 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_fwd(in
         }
         skip_planes(p - p_lo);
     }
-    const __amdgpu_buffer_rsrc_t h = colfft_rsrc(htab + ((size_t)c * P + p_lo) * HW + c0);
+    // (a plane group beyond the last plane -- P not a multiple of the group size -- writes zeros: its H_lo is not in the table)
+    const bool any = p_lo < p_hi;
+    const __amdgpu_buffer_rsrc_t h = colfft_rsrc(htab + ((size_t)c * P + (any ? p_lo : 0)) * HW + c0);
     const __amdgpu_buffer_rsrc_t a = colfft_rsrc(acc + ((size_t)bz * 3 + c) * HW + c0);
     const __amdgpu_buffer_rsrc_t zo = colfft_rsrc(zsum + ((size_t)bz * 3 + c) * HW + c0);
     const float z_lo = focal - plane_depth(p_lo, P, near_, far_), step = P > 1 ? (far_ - near_) / (float)(P - 1) : 0.0f;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
         const uint32_t so = (uint32_t)(colfft_freq_e<LOGN, INNER>(e) * W) * 8u;
-        const float2 hl = ld_f2(h, off_out, so);
+        const float2 hl = any ? ld_f2(h, off_out, so) : make_float2(0.0f, 0.0f);
         st_f2(a, off_out, so, cmul(hl, S[e]));
         st_f2(zo, off_out, so, cmul(hl, make_float2(z_lo * S[e].x - step * T[e].x, z_lo * S[e].y - step * T[e].y)));
     }
 }
 
-// total[b][c][k] = sum over the PG plane groups of part[b][group][c][k] (fixed order)
-__global__ __launch_bounds__(256) void k_sum_groups(size_t n_per_image, int PG, const float2 *__restrict__ part,
-                                                    float2 *__restrict__ total) {
+// total[b][c][k] = sum over the PG plane groups of part[b][group][c][k] (fixed order); blockIdx.z = 0: acc, 1: Z
+__global__ __launch_bounds__(256) void k_sum_groups(size_t n_per_image, int PG, const float2 *__restrict__ part0,
+                                                    float2 *__restrict__ total0, const float2 *__restrict__ part1,
+                                                    float2 *__restrict__ total1) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= n_per_image) return;
+    const float2 *part = blockIdx.z ? part1 : part0;
+    float2 *total = blockIdx.z ? total1 : total0;
     float2 s = part[((size_t)b * PG) * n_per_image + i];
     for (int g = 1; g < PG; ++g) {
         const float2 v = part[((size_t)b * PG + g) * n_per_image + i];
@@ -791,11 +800,11 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     const uint64_t occupied = asm_plane_mask(seg_off, b, P, tiles);
     auto next_plane = [&](int pq) { return asm_plane_at_or_above(occupied, pq, p_hi); };
     int p = next_plane(p_lo);
-    // gF_p = gAcc conj(H_p) by recurrence, as the forward: w = gAcc conj(H) at the block's first plane, then w <- w conj(D) per plane
-    // (H_(p+1) = H_p D); no transfer-function value is read inside the plane loop
+    // gF_p = gAcc conj(H_p) by recurrence, as the forward: w = gAcc conj(H) at the GROUP's first plane (the only planes of H the table
+    // holds on this path), then w <- w conj(D) per plane (H_(p+1) = H_p D); no transfer-function value is read inside the plane loop
     float2 w[PER], Dc[PER];
     {
-        const __amdgpu_buffer_rsrc_t hp = colfft_rsrc(htab + ((size_t)c * P + min(p, P - 1)) * HW + c0);
+        const __amdgpu_buffer_rsrc_t hp = colfft_rsrc(htab + ((size_t)c * P + (p_lo < p_hi ? p_lo : 0)) * HW + c0);
         const __amdgpu_buffer_rsrc_t dt = colfft_rsrc(htab + ((size_t)3 * P + c) * HW + c0);
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
@@ -803,6 +812,10 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
             const float2 hh = ld_f2(hp, off_in, so), d = ld_f2(dt, off_in, so);
             w[e] = cmul(g[e], make_float2(hh.x, -hh.y));
             Dc[e] = make_float2(d.x, -d.y);
+        }
+        for (int i = p_lo; i < p && i < p_hi; ++i) {  // empty planes in front of the first occupied one
+#pragma unroll
+            for (int e = 0; e < PER; ++e) w[e] = cmul(w[e], Dc[e]);
         }
     }
     __syncthreads();  // twiddles
@@ -1254,11 +1267,13 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
     const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
     {
-        const size_t nh = 3 * (size_t)(P + 1) * (size_t)(W / 2 + 1) * (size_t)(H / 2 + 1);  // one quadrant, mirrored; + the step factors D
+        // the column kernels read H at the first plane of each plane group only (and D); the rocFFT 2-D path reads every plane
+        const int pstride = p.col_logn ? (P + p.col_pg - 1) / p.col_pg : 1, np = (P + pstride - 1) / pstride;
+        const size_t nh = 3 * (size_t)(np + 1) * (size_t)(W / 2 + 1) * (size_t)(H / 2 + 1);  // one quadrant, mirrored; + the step factors D
         const uint32_t nb_ph = (ngauss + 255) / 256, nb_tr = (uint32_t)((nh + 255) / 256);
         hipLaunchKernelGGL(k_asm_prep, dim3(nb_ph + nb_tr + 1), dim3(256), 0, st, nb_ph, nb_tr, ngauss, a.phase_channels,
                            color, phase, ccs, W, H, P, a.depth_near, a.depth_far, a.focal_depth, inv_ndx, inv_ndy,
-                           wavelengths, htab, p.col_logn ? H : 0, reinterpret_cast<float2 *>(sv + p.v_tw));
+                           wavelengths, htab, p.col_logn ? H : 0, reinterpret_cast<float2 *>(sv + p.v_tw), pstride);
         FGS_LAUNCH_CHECK("k_asm_prep");
     }
     const uint32_t *ranges_d = reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges);
@@ -1318,8 +1333,8 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
 #undef FGS_COLFFT_FWD
         FGS_LAUNCH_CHECK("k_colfft_fwd");
         if (PG > 1) {
-            hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((3 * HW + 255) / 256), B), dim3(256), 0, st, 3 * HW, PG, accp, total);
-            hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((3 * HW + 255) / 256), B), dim3(256), 0, st, 3 * HW, PG, zsump, zsum);
+            hipLaunchKernelGGL(k_sum_groups, dim3((unsigned)((3 * HW + 255) / 256), B, 2), dim3(256), 0, st, 3 * HW, PG, accp, total,
+                               zsump, zsum);
             FGS_LAUNCH_CHECK("k_sum_groups");
         }
     } else {

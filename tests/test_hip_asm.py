@@ -154,14 +154,17 @@ def test_asm_batched_nonsquare_vs_oracle():
     assert rel_to_max(out["grad_wavelengths"], gw) <= 1e-3
 
 
-@pytest.mark.parametrize("W,H", [(72, 64), (80, 64), (96, 128), (96, 256), (40, 1024)])
+@pytest.mark.parametrize("W,H", [(72, 64), (80, 64), (368, 64), (96, 128), (96, 256), (40, 1024)])
 def test_asm_column_fused_transforms_vs_oracle(W, H):
     """Power-of-two heights take the column-fused path (rocFFT rows + k_colfft_fwd / k_colfft_bwd: our own radix-8
     column FFT in LDS and registers, fused with the transfer-function recurrence, the plane sums and their adjoints)
     when the width is a whole number of column tiles -- every log2(H) class of the kernels (64 = 8^2 and 512 = 8^3 close
     with a register butterfly, 128 / 256 / 1024 with a radix-2 / radix-4 pass), the 8-column tile of H = 1024 -- and
-    rocFFT's 2-D plans otherwise (72 x 64); two images, per-channel phases; image and all gradients incl. the
-    wavelengths' against the oracle (torch.fft on the CPU)."""
+    rocFFT's 2-D plans otherwise (72 x 64); 368 x 64: 138 blocks, i.e. four plane groups of two planes for six planes -- the
+    last group is empty, and the transfer-function table holds every second plane only; two images, per-channel phases;
+    image and all gradients incl. the wavelengths' against the oracle (torch.fft on the CPU).
+    (NOT 352 x 64 with these seeds: image 0 then has a pixel whose summed amplitude is 0.9999993 / 1.0000002 depending on the
+    summation order -- the clamp of DR:1327 -- and every gradient moves by 1e-3 with the side it falls on)"""
     from oracle import asm_oracle, fgs_oracle as orc
     from fresnel_amd.renderer import Camera
     N, Bn = 300, 2
