@@ -189,10 +189,22 @@ __device__ __forceinline__ void asm_transfer_block(uint32_t blk, int W, int H, i
     float kz2 = il * il - fx * fx - fy * fy;
     kz2 = kz2 < 0.0f ? 0.0f : kz2;
     const float kz = sqrtf(kz2);
-    const float z = p < P ? focal - plane_depth(p, P, near_, far_) : (P > 1 ? -(far_ - near_) / (float)(P - 1) : 0.0f);
-    const float theta = (6.28318530717958647692f * z) * kz;
     float sn, cs;
-    sincosf(theta, &sn, &cs);
+    if (p < P) {  // H_p: the reference's own fp32 expression, rounding for rounding (DR:989-999)
+        const float z = focal - plane_depth(p, P, near_, far_);
+        const float theta = (6.28318530717958647692f * z) * kz;
+        sincosf(theta, &sn, &cs);
+    } else {
+        // D: its phase is added up to P - 1 times, so it is evaluated in double and only its two components are rounded: 4e-8 rad per
+        // step instead of the 1.5e-6 (up to 6.6e-6) of the fp32 expression -- H_lo D^k then stays within the reference's own fp32 phase
+        // rounding (5e-6 rad typical at 200 rad) of the directly evaluated H_p for every plane count the interface admits
+        const double zd = P > 1 ? -((double)far_ - (double)near_) / (double)(P - 1) : 0.0;
+        const double kz2d = (double)il * (double)il - (double)fx * (double)fx - (double)fy * (double)fy;
+        const double th = 6.283185307179586476925 * zd * (kz2d > 0.0 ? sqrt(kz2d) : 0.0);
+        double sd, cd;
+        sincos(th, &sd, &cd);
+        sn = (float)sd; cs = (float)cd;
+    }
     const float2 h = make_float2(cs, sn);
     float2 *plane = p < P ? htab + ((size_t)c * P + p) * HW : htab + ((size_t)3 * P + c) * HW;
     const int mx = (kx > 0 && W - kx != kx) ? W - kx : -1, my = (ky > 0 && H - ky != ky) ? H - ky : -1;
