@@ -381,6 +381,12 @@ class AsmRenderer(torch.autograd.Function):
     def backward(ctx, g_out):
         lib = B.load()
         pos, scl, rot, col, opa, ph, wl, cam_tensor, saved = ctx.saved_tensors
+        # fgs_asm_backward turns the plane fields in `saved` into their gradients IN PLACE (fgs.h): a second backward through this
+        # node (retain_graph=True, two losses sharing the graph) would read them as fields
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("ASMWaveFieldRenderer: backward through this node a second time -- its saved plane fields were "
+                               "consumed by the first backward; render again instead of retaining the graph")
+        ctx.consumed = True
         d = ctx.dims
         dev = pos.device
         g_out = g_out.contiguous().float()

@@ -281,6 +281,21 @@ def test_asm_layered_mask_binning_equals_radix_binning(W, H, N, spread, smin, sm
         assert np.isfinite(a).all() and np.array_equal(a, b)
 
 
+def test_asm_second_backward_through_one_render_raises():
+    """fgs_asm_backward consumes `saved` (the plane fields become their gradients in place): a second backward through the same
+    render must fail loudly, not return gradients of garbage."""
+    from fresnel_amd.renderer import ASMWaveFieldRenderer, Camera
+    dev = _cuda()
+    pos, scale, quat, col, opa = synth_aniso(50, 7, opacity_max=0.9, smin=0.03, smax=0.1)
+    ts = [torch.from_numpy(a[None]).to(dev).requires_grad_(True) for a in (pos, scale, quat, col, opa)]
+    ph = torch.zeros(1, 50, device=dev, requires_grad=True)
+    cam = Camera(50.0, 50.0, 32, 32, 64, 64)
+    img = ASMWaveFieldRenderer(64, 64, num_depth_planes=4).to(dev)(*ts, cam, phases=ph)
+    img.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        img.sum().backward()
+
+
 def test_asm_requires_phases_like_the_reference():
     from fresnel_amd.renderer import ASMWaveFieldRenderer, Camera
     dev = _cuda()
