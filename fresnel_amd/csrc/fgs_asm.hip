@@ -105,6 +105,9 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     p->col_pg = 1;
     if (p->col_logn) {
         const size_t blocks = (size_t)((a->width + p->col_tc - 1) / p->col_tc) * 3 * B;
+        // (at least 512 blocks.  Choosing PG by "rounds of 256 blocks x planes per block" instead -- 8 groups of 2 planes for one
+        // config-5 image rather than 6 of 3 -- was measured: 0.491 -> 0.518 ms at one image, 0.714 -> 0.733 at two; the blocks do not
+        // run in rounds, and every group costs a partial acc / Z pair, a table plane and a block start-up)
         if (blocks < 512) p->col_pg = (int)((512 + blocks - 1) / blocks);
         if (p->col_pg > (int)P) p->col_pg = (int)P;
     }
