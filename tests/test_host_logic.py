@@ -286,3 +286,41 @@ def test_phase_tensor_shapes_are_validated_before_any_kernel_sees_them():
     assert _phase_channels(torch.zeros(2, 5, 1)) == 1   # one float per Gaussian, NOT three
     with pytest.raises(ValueError):
         _phase_channels(torch.zeros(2, 5, 2))
+
+
+def test_plane_recurrence_identities_of_the_asm_column_kernels():
+    """The algebra k_colfft_fwd / k_colfft_bwd (fgs_asm.hip) rest on since round 3, restated in numpy: equally spaced planes give
+    H_p = H_lo D^(p - lo), hence  sum_p H_p F_p = H_lo S  and  sum_p z_p H_p F_p = H_lo (z_lo S - step T)  with the Horner sums
+    S_k = F_k + D S_(k+1), T_k = D (T_(k+1) + S_(k+1)) over the planes in descending order -- planes without Gaussians (F = 0) are
+    stepped over with the same recurrence -- and the backward's gF_p = g conj(H_p) is w <- w conj(D) from w = g conj(H_lo)."""
+    rs = np.random.RandomState(5)
+    for P, lo, hi, occupied in [(16, 0, 16, None), (16, 6, 12, [7, 8, 11]), (6, 4, 6, [4]), (64, 0, 64, [3, 40, 60, 63]), (5, 0, 5, [])]:
+        n = 37
+        near, far, focal = 0.3, 2.4, 0.9
+        step = (far - near) / (P - 1)
+        z = focal - (near + step * np.arange(P))                       # z_p, equally spaced
+        kz = rs.uniform(0.0, 23.0, n)
+        H = np.exp(1j * 2 * np.pi * z[:, None] * kz[None, :])          # H_p as the table holds it
+        D = np.exp(1j * 2 * np.pi * (-step) * kz)
+        occ = list(range(lo, hi)) if occupied is None else occupied
+        F = np.zeros((P, n), complex)
+        for p in occ:
+            F[p] = rs.standard_normal(n) + 1j * rs.standard_normal(n)
+        acc = sum(H[p] * F[p] for p in range(lo, hi))
+        Z = sum(z[p] * H[p] * F[p] for p in range(lo, hi))
+        S = np.zeros(n, complex); T = np.zeros(n, complex)
+        prev = None
+        for p in sorted(occ, reverse=True):                            # the kernel's walk: occupied planes, descending
+            for _ in range(0 if prev is None else prev - p - 1):       # skip_planes: F = 0
+                T = D * (T + S); S = D * S
+            T = D * (T + S); S = F[p] + D * S                           # plane_step's epilogue
+            prev = p
+        for _ in range(0 if prev is None else prev - lo):               # down to the group's first plane
+            T = D * (T + S); S = D * S
+        assert np.abs(H[lo] * S - acc).max() <= 1e-9 * max(1.0, np.abs(acc).max())
+        assert np.abs(H[lo] * (z[lo] * S - step * T) - Z).max() <= 1e-9 * max(1.0, np.abs(Z).max())
+        g = rs.standard_normal(n) + 1j * rs.standard_normal(n)
+        w = g * np.conj(H[lo])
+        for p in range(lo, hi):
+            assert np.abs(w - g * np.conj(H[p])).max() <= 1e-9
+            w = w * np.conj(D)
