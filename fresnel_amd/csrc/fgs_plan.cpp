@@ -141,6 +141,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
 #define FGS_ORDER_GROUPS 8
 #endif
     p->order_groups = (p->fwd_parts > 0 && layers == 1 && segment_ckpt) ? FGS_ORDER_GROUPS : 1;
+    p->depth_ordered = segment_ckpt;  // the callers without segment checkpoints are the splat renderers
     const size_t ucap = dcap / L.seg_len + B * layers * p->tiles;
     L.seg_off = o; L.seg_tile = o; L.seg_ckpt = o; L.seg_capacity = 0;
     if (!d->use_phase) {

@@ -35,6 +35,9 @@ struct FgsPlan {
     int32_t fwd_waves;        // waves per tile of the row-split forward (also the phase path)
     int32_t fwd_variant;      // the same choice in FgsDims.fwd_variant encoding (recorded in saved.counters[5])
     bool direct_binning;      // counting sort straight from the bboxes instead of emit + radix sort
+    bool depth_ordered;       // the consumer composites in depth order (blend / phase paths).  false on the splat renderers (ASM, wave:
+                              // order-independent sums, DR:1233-1283 / DR:689-926): no depth sort, the lists hold their Gaussians in
+                              // index order -- the order the reference's own loop adds them in
     int32_t order_groups;     // XCD groups of the forward's launch order (fgs_bin.hip tile_group): 8 on the blend path's
                               // depth-split forward, 1 elsewhere
     // scratch layout (bytes)
