@@ -3,7 +3,7 @@
 //
 // Pipeline (forward), all on the caller's stream:
 //   k_project (shared; also assigns the nearest depth plane) -> lists per (image, plane, tile) (layered mask binning,
-//   fgs_bin.hip) -> k_asm_prep (phasors c e^{i phi} per Gaussian, transfer functions H = exp(i 2 pi z_p sqrt(max(l_c^-2 -
+//   fgs_bin.hip; no depth sort: the sums below are order-independent, one stable pass groups the Gaussians by plane) -> k_asm_prep (phasors c e^{i phi} per Gaussian, transfer functions H = exp(i 2 pi z_p sqrt(max(l_c^-2 -
 //   fx^2 - fy^2, 0))) (DR:989-999), FFT twiddles: one launch) -> k_asm_splat (one wave per list: complex amplitudes
 //   a c e^{i phi}, order-independent sum, DR:1233-1283) -> 2-D forward transform of all B*P*3 plane fields: rocFFT 1-D rows
 //   + k_colfft_fwd, our own column FFT fused with acc_c = sum_p F_pc H_pc (heights 2^6 ... 2^10; otherwise rocFFT's 2-D plan
