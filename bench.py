@@ -194,7 +194,7 @@ def launch_ranks(args, argv):
     per GPU under torch.distributed.run, rendezvous on 127.0.0.1 -- relay their output (rank 0 prints the JSON line)
     and exit with their status.  Nothing in THIS process has imported torch or touched a GPU.  Never falls back to
     fewer ranks: too few devices is an error, not an n_gpus: 1 measurement."""
-    if args.backend == "nccl" and not args.rendezvous_only:
+    if args.backend == "nccl" and not args.rendezvous_only and not args.stub_renderer:
         have = _visible_gpus()
         if have < args.gpus:
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to measure "
@@ -226,6 +226,180 @@ def rendezvous_only(args, world, rank, result_fd):
     dist.destroy_process_group()
 
 
+class _NoStageTimers:
+    """--stub-renderer: there is no library and no GPU; the protocol's stage-timer calls become no-ops."""
+    @staticmethod
+    def stage_timing_enable(on, stages=None):
+        pass
+
+    @staticmethod
+    def stage_timing_read():
+        return {}
+
+
+def _timed_region(step, sync, dist, steps):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides (the contract of the driver)."""
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    return time.perf_counter() - t0
+
+
+def spin_up(step, sync, dist, spinup_ms, flag):
+    """Untimed steps until `spinup_ms` milliseconds of load have passed ON EVERY RANK.  Every step issues a collective
+    (the bucket all-reduce), so all ranks must run the same number of steps: after each batch of ten every rank
+    contributes "my clock says keep going" to a MAX all-reduce of `flag` (a one-element tensor on the collective's
+    device) and all of them continue while any of them wants to -- the count is agreed, never a per-rank wall-clock
+    decision (a few ms of skew at the boundary left ranks with unequal numbers of all-reduces).  Returns the
+    agreed number of steps."""
+    n = 0
+    if spinup_ms <= 0:
+        return n
+    sync()
+    t_spin = time.perf_counter()
+    while True:
+        for _ in range(10):
+            step()
+        sync()
+        n += 10
+        more = (time.perf_counter() - t_spin) * 1e3 < spinup_ms
+        if dist is not None:
+            flag.fill_(1.0 if more else 0.0)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = bool(flag.item() > 0.0)
+        if not more:
+            return n
+
+
+def run_protocol(step, sync, dist, args, timers, flag, compute_stages=(), after_warmup=None):
+    """The measurement protocol, shared by the GPU run and the CPU stub (--stub-renderer):
+      1. W warm-up steps with every stage bracketed by events (stage split at COLD clocks);
+      2. `after_warmup()`: the caller's bookkeeping (the device-side pair count);
+      3. COLD timed region: K steps straight after the warm-up -- how rounds 1 and 2 measured (ms_per_step_cold);
+      4. clock spin-up with a collectively agreed step count (spin_up), then ten bracketed steps (stage split at
+         SUSTAINED clocks);
+      5. the timed region proper: EXACTLY K steps, barrier + synchronize on both sides -> ms_per_step / value.
+    With --spinup-ms 0 steps 3 and 4 are skipped: the one timed region then IS the cold protocol.
+    During the timed regions only the dominant kernel carries an event pair (each pair costs stream time: all stages
+    together slowed the step by 2.5 %)."""
+    def avgs(raw):
+        return {k: (v[0] / v[1] if v[1] else 0.0) for k, v in raw.items()}
+
+    def dominant(avg):
+        return max(reversed(compute_stages), key=lambda k: avg.get(k, 0.0)) if compute_stages else None  # --warmup 0: the backward
+
+    def timed(dom):
+        timers.stage_timing_enable(True, stages=[dom] if dom else None)
+        timers.stage_timing_read()
+        t = _timed_region(step, sync, dist, args.steps)
+        raw = timers.stage_timing_read()
+        timers.stage_timing_enable(False)
+        ms = raw[dom][0] / raw[dom][1] if dom and raw.get(dom, (0, 0))[1] else None
+        return t, ms
+
+    timers.stage_timing_enable(True)
+    for i in range(args.warmup):
+        if i == min(1, args.warmup - 1):  # the first step carries one-time costs (allocator, plan caches): drop it
+            sync()
+            timers.stage_timing_read()
+        step()
+    sync()
+    cold_avg = avgs(timers.stage_timing_read())
+    timers.stage_timing_enable(False)
+    out = {"extra": after_warmup() if after_warmup is not None else None, "cold_avg": cold_avg, "sustained_avg": None,
+           "elapsed_cold": None, "dom_ms_cold": None, "spinup_steps": 0}
+    dom = dominant(cold_avg)
+    if args.spinup_ms > 0:
+        out["dom_stage_cold"] = dom
+        out["elapsed_cold"], out["dom_ms_cold"] = timed(dom)
+        out["spinup_steps"] = spin_up(step, sync, dist, args.spinup_ms, flag) + 10
+        timers.stage_timing_enable(True)
+        timers.stage_timing_read()
+        for _ in range(10):
+            step()
+        sync()
+        out["sustained_avg"] = avgs(timers.stage_timing_read())
+        timers.stage_timing_enable(False)
+        dom = dominant(out["sustained_avg"])
+    out["dom_stage"] = dom
+    out["elapsed"], out["dom_ms"] = timed(dom)
+    return out
+
+
+def reduce_over_ranks(dist, device, elapsed, elapsed_cold, pairs_local, steps):
+    """MAX / MIN over ranks of each rank's own clock, SUM of the pairs.  Returns (elapsed_max, elapsed_cold_max,
+    pairs_all, [rank_min_ms, rank_max_ms])."""
+    rank_ms = [elapsed / steps * 1e3] * 2
+    if dist is None:
+        return elapsed, elapsed_cold, float(pairs_local), rank_ms
+    cold = -1.0 if elapsed_cold is None else elapsed_cold
+    tmax = torch.tensor([elapsed, cold], dtype=torch.float64, device=device)
+    tmin = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    psum = torch.tensor([float(pairs_local)], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+    dist.all_reduce(psum, op=dist.ReduceOp.SUM)
+    rank_ms = [float(tmin[0].item()) / steps * 1e3, float(tmax[0].item()) / steps * 1e3]
+    cold_max = float(tmax[1].item())
+    return float(tmax[0].item()), (None if elapsed_cold is None else cold_max), float(psum.item()), rank_ms
+
+
+def stub_run(args, world, rank, result_fd):
+    """--stub-renderer: the protocol above on CPU tensors under gloo.  The step is a stand-in (no rasterizer, no GPU):
+    the line says so in `metric`, carries no roofline, and `value` is null -- it can not be mistaken for a measurement."""
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    device = torch.device("cpu")
+    bucket = torch.zeros(4096) if dist is not None else None
+    work = torch.zeros(256, 256)
+    n_collectives = [0]
+
+    def step():
+        work.add_(1.0)
+        if rank % 2:  # odd ranks are slower: the spin-up boundary falls in different batches on different ranks
+            time.sleep(0.002)
+        if bucket is not None:
+            dist.all_reduce(bucket)
+            n_collectives[0] += 1
+
+    # after_warmup: unsynchronised, rank-dependent host work (the real run's pair count + .item() calls): the ranks reach
+    # the spin-up with skewed clocks, the situation in which a per-rank wall-clock loop issued unequal collective counts
+    res = run_protocol(step, lambda: None, dist, args, _NoStageTimers, torch.zeros(1),
+                       after_warmup=lambda: time.sleep(0.013 * rank))
+    elapsed = res["elapsed"]
+    pairs_local = 1_000_000  # per rank and step: a constant, so that the SUM over ranks is checkable
+    elapsed, elapsed_cold, pairs_all, rank_ms = reduce_over_ranks(dist, device, elapsed, res["elapsed_cold"], pairs_local, args.steps)
+    ncoll = torch.tensor([float(n_collectives[0])] * 2, dtype=torch.float64)
+    if dist is not None:
+        lo, hi = ncoll[:1].clone(), ncoll[1:].clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ncoll = torch.cat([lo, hi])
+    if rank == 0:
+        line = {"metric": "STUB: bench.py timing protocol on CPU tensors (gloo), no rasterizer, no GPU -- not a measurement",
+                "value": None, "stub": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "spinup_steps": res["spinup_steps"], "ms_per_step": elapsed / args.steps * 1e3,
+                "ms_per_step_cold": None if elapsed_cold is None else elapsed_cold / args.steps * 1e3,
+                "rccl_ranks": dist.get_world_size() if dist is not None else 1, "backend": "gloo" if dist is not None else None,
+                "ms_per_step_rank_min": rank_ms[0], "ms_per_step_rank_max": rank_ms[1],
+                "step_collectives_rank_min": int(ncoll[0].item()), "step_collectives_rank_max": int(ncoll[1].item()),
+                "config": {"pairs_per_step": int(pairs_all), "pairs_per_step_per_rank": pairs_local}}
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -252,6 +426,11 @@ def main(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="form the process group, barrier and all-reduce even with ONE rank: rehearses the RCCL path "
                          "(communicator creation, collectives on the compute stream) on a one-GPU box")
+    ap.add_argument("--stub-renderer", action="store_true",
+                    help="NO GPU, NOT a measurement: the whole timing protocol of this file (warm-up, cold region, collectively "
+                         "agreed clock spin-up, timed region, MAX/MIN/SUM reductions, the one JSON line) around a stand-in step "
+                         "(a small CPU tensor op + the bucket all-reduce on gloo).  tests/test_bench_launch.py runs it with 2 and "
+                         "8 ranks: every rank must issue the same collectives in the same order")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="rehearse launcher + rendezvous + collectives on CPU tensors (gloo), no GPU work, no bench line")
     args = ap.parse_args(argv)
@@ -277,6 +456,8 @@ def main(argv=None):
     _import_compute()
     if args.rendezvous_only:
         return rendezvous_only(args, world, rank, result_fd)
+    if args.stub_renderer:
+        return stub_run(args, world, rank, result_fd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU fallback)")
     n_dev = torch.cuda.device_count()
@@ -344,90 +525,30 @@ def main(argv=None):
         if bucket is not None:
             dist.all_reduce(bucket)  # decoder-gradient bucket of the DP training step
 
-    # warm-up, with every stage bracketed by events: gives the per-stage split and tells which kernel dominates
-    B.stage_timing_enable(True)
-    for i in range(args.warmup):
-        if i == min(1, args.warmup - 1):  # the first step carries one-time costs (allocator, plan caches): drop it
-            torch.cuda.synchronize()
-            B.stage_timing_read()
-        step()
-    torch.cuda.synchronize()
-    warm_stage = B.stage_timing_read()
-    B.stage_timing_enable(False)
-
     # unit of work: composited Gaussian-pixels of this rank's batch (device-side count over the reference bboxes,
     # which are the same for every renderer: DR:594-597 / DR:1240-1247)
-    # (the blend path picks its own tile width; the phase and splat renderers of configs 4 / 5 run 16 x 16 tiles)
-    cfg0 = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, False, 0.25,
-                  tuning=dict(tile_w=16) if args.workload in ("config4", "config5") or args.saturation_skip else
-                  ({k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))} if args.tuning else None))
-    _, _, saved, dims, _ = R.forward_raw(*[t.detach() for t in leaves], None, R.pack_cameras(cam, device), cfg0)
-    pairs_dev = torch.zeros(1, dtype=torch.int64, device=device)
-    B.check(B.load().fgs_count_pairs(ctypes.byref(dims), ctypes.c_void_p(saved.data_ptr()),
-                                     ctypes.c_void_p(pairs_dev.data_ptr()),
-                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "fgs_count_pairs")
-    st = R.inspect_saved(saved, dims)
-    D_local = int(st["counters"][0].item())
-    U_local = int(st["counters"][2].item())  # backward work units = depth segments
-    tile_w = int(st["layout"].tile_w)  # 16, or 32 on the blend path from 512-pixel-wide frames on
-    pairs_local = int(pairs_dev.item())
-    del saved, st
+    def count_pairs():
+        cfg0 = R._Cfg(S, S, (0.0, 0.0, 0.0), 64, False, 0.25,
+                      tuning=dict(tile_w=16) if args.workload in ("config4", "config5") or args.saturation_skip else
+                      ({k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))} if args.tuning else None))
+        _, _, saved, dims, _ = R.forward_raw(*[t.detach() for t in leaves], None, R.pack_cameras(cam, device), cfg0)
+        pairs_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        B.check(B.load().fgs_count_pairs(ctypes.byref(dims), ctypes.c_void_p(saved.data_ptr()),
+                                         ctypes.c_void_p(pairs_dev.data_ptr()),
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "fgs_count_pairs")
+        st = R.inspect_saved(saved, dims)
+        return (int(st["counters"][0].item()), int(st["counters"][2].item()),  # D; backward work units = depth segments
+                int(st["layout"].tile_w), int(pairs_dev.item()))
 
-    # timed region: only the dominant kernel carries an event pair (each pair costs stream time: all stages
-    # together slowed the step by 2.5 %)
-    warm_avg = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in warm_stage.items()}
+    # warm-up -> pair count -> cold timed region -> collectively agreed clock spin-up -> timed region: run_protocol
     compute_stages = ("splat_fwd", "field_fwd", "field_bwd", "splat_bwd") if is_asm else ("composite_fwd", "composite_bwd")
-    dom_stage = max(reversed(compute_stages), key=lambda k: warm_avg.get(k, 0.0))  # --warmup 0: the backward
-    # clock spin-up (untimed, disclosed in the line): the GPU reaches its sustained clocks only after ~100 ms of load, and
-    # the W warm-up steps of a default run are 10 ms of it
-    spinup_steps = 0
-    if args.spinup_ms > 0:
-        torch.cuda.synchronize()
-        t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
-            spinup_steps += 10
-        # the per-stage split of the line at the same sustained clocks: ten more untimed steps with every stage bracketed
-        B.stage_timing_enable(True)
-        B.stage_timing_read()
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize()
-        spin_stage = B.stage_timing_read()
-        B.stage_timing_enable(False)
-        spinup_steps += 10
-        warm_avg = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in spin_stage.items()}
-        dom_stage = max(reversed(compute_stages), key=lambda k: warm_avg.get(k, 0.0))
-    B.stage_timing_enable(True, stages=[dom_stage])
-    B.stage_timing_read()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    stage = B.stage_timing_read()
-    B.stage_timing_enable(False)
+    res = run_protocol(step, torch.cuda.synchronize, dist, args, B, torch.zeros(1, device=device), compute_stages, count_pairs)
+    D_local, U_local, tile_w, pairs_local = res["extra"]
+    dom_stage, spinup_steps = res["dom_stage"], res["spinup_steps"]
+    warm_avg = res["sustained_avg"] if res["sustained_avg"] is not None else res["cold_avg"]
+    elapsed, elapsed_cold = res["elapsed"], res["elapsed_cold"]
 
-    tot = torch.tensor([elapsed, float(pairs_local)], dtype=torch.float64, device=device)
-    rank_ms = [elapsed / args.steps * 1e3] * 2  # [min, max] over ranks of each rank's own clock
-    if dist is not None:
-        tmax, tmin = tot[:1].clone(), tot[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        psum = tot[1:].clone()
-        dist.all_reduce(psum, op=dist.ReduceOp.SUM)
-        rank_ms = [float(tmin.item()) / args.steps * 1e3, float(tmax.item()) / args.steps * 1e3]
-        elapsed, pairs_all = float(tmax.item()), float(psum.item())
-    else:
-        pairs_all = float(pairs_local)
+    elapsed, elapsed_cold, pairs_all, rank_ms = reduce_over_ranks(dist, device, elapsed, elapsed_cold, pairs_local, args.steps)
     ms_per_step = elapsed / args.steps * 1e3
     value = pairs_all / (elapsed / args.steps)
 
@@ -450,8 +571,8 @@ def main(argv=None):
         # per-stage average launch time: the dominant kernel's comes from the timed region (`stage`); the split of
         # the other stages was taken during the warm-up steps of this same run (`warm_avg`)
         avg_ms = dict(warm_avg)
-        if stage[dom_stage][1]:
-            avg_ms[dom_stage] = stage[dom_stage][0] / stage[dom_stage][1]
+        if res["dom_ms"] is not None:
+            avg_ms[dom_stage] = res["dom_ms"]
         avg_ms["list_building"] = sum(avg_ms.get(k, 0.0) for k in ("dup_emit", "tile_sort", "tile_ranges"))
 
         def stage_roofline(name):
@@ -500,8 +621,12 @@ def main(argv=None):
                 stages[name] = r
         roofline["stages"] = stages
         roofline["stage_avg_ms"] = {k: round(v, 4) for k, v in avg_ms.items() if v > 0}
+        roofline["stage_avg_ms_cold"] = {k: round(v, 4) for k, v in res["cold_avg"].items() if v > 0}
+        if res["dom_ms_cold"] is not None:
+            roofline["stage_avg_ms_cold"][res["dom_stage_cold"]] = round(res["dom_ms_cold"], 4)
         roofline["stage_avg_ms_note"] = ("dominant kernel: timed region; other stages: ten untimed steps of this run with every stage "
-                                         "bracketed, taken after the clock spin-up (the W warm-up steps when --spinup-ms 0)")
+                                         "bracketed, taken after the clock spin-up (the W warm-up steps when --spinup-ms 0); "
+                                         "stage_avg_ms_cold: the W warm-up steps + the dominant kernel in the cold timed region")
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             cpu_baseline = cpu_baseline_leg(leaves, gI, gD, N, S)
@@ -509,7 +634,12 @@ def main(argv=None):
         line = {
             "metric": "composited Gaussian-pixels/sec + train-step ms, 512^2 render",
             "value": value, "unit": "Gaussian-pixels/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "spinup_steps": spinup_steps, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "warmup": args.warmup, "spinup_steps": spinup_steps, "ms_per_step": ms_per_step,
+            # the same K steps timed straight after the W warm-up steps, BEFORE the clock spin-up: the protocol of rounds
+            # 1 and 2, so that rounds stay comparable from the driver record alone (max over ranks, like ms_per_step)
+            "ms_per_step_cold": (elapsed_cold / args.steps * 1e3) if elapsed_cold is not None else ms_per_step,
+            "value_cold": pairs_all / ((elapsed_cold if elapsed_cold is not None else elapsed) / args.steps),
+            "higher_is_better": True,
             "rccl_ranks": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None,
             "ms_per_step_rank_min": rank_ms[0], "ms_per_step_rank_max": rank_ms[1],
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

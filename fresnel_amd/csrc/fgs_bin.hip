@@ -157,7 +157,7 @@ __device__ __forceinline__ TileRect tile_rect(const float *__restrict__ rec, uin
 // depends on the tile count fitting in LDS, and lists come out in depth order by construction.
 constexpr uint32_t MB_RANKS = FGS_BIN_G; // depth ranks per k_mask_build block (four rank words)
 static_assert(MB_RANKS == 256, "k_mask_build: one 256-thread block = four 64-bit rank words per line");
-constexpr uint32_t TO_TILES = 1024;     // tiles per block of the tile-table kernels (k_tile_pre / k_tile_post below)
+constexpr uint32_t TO_TILES = FGS_TILE_TABLE_TILES;     // tiles per block of the tile-table kernels (k_tile_pre / k_tile_post below)
 __device__ __forceinline__ uint32_t length_bucket(uint32_t len);
 constexpr uint32_t MB_MAX_LINES = FGS_MASK_MAX_LINES;  // tile columns + rows the build kernel keeps in LDS
 

@@ -79,41 +79,37 @@ __device__ __forceinline__ TileCtx tile_ctx(uint32_t tiles, uint32_t tiles_x,
 }
 
 
-// Forward.  FWD_WAVES waves per tile: 2 on the blend path (wave w owns sub-tiles 2w and 2w+1, the upper /
-// lower half of the tile: the forward has no cross-lane reduction, so the split is free and halves the serial
-// length of the longest lists), 1 when the launch has enough tiles to fill the chip several times over, 4 on the
-// phase path (latency-bound recurrence).  All waves of a block share the LDS-staged chunk of the list.
+// Row-split forward of the blend path (FgsDims.saturation_skip and fwd_variant < 0; the default is the depth-split
+// k_blend_fwd_parts below, the phase path has its own kernels, k_phase_fwd / k_phase_bwd).  FWD_WAVES waves per tile: with 2,
+// wave w owns sub-tiles 2w and 2w+1, the upper / lower half of the tile (the forward has no cross-lane reduction, so the
+// split is free and halves the serial length of the longest lists); 1 when the launch has enough tiles to fill the chip
+// several times over.  All waves of a block share the LDS-staged chunk of the list.
 //
-// Per-record work is decided once, at staging time, in parallel over the chunk.  Blend path: stage_decode
-// (fgs_wave.h) leaves a flags word (touched sub-tiles, ...) and 32 pixel bits; in the list loop a lane turns its
-// column / row bit into an all-ones / zero mask with v_bfe_i32 and and-s it onto G -- no per-pixel compare /
-// select (issue costs: DESIGN.md section 4).  Phase path: 4-bit touched-sub-tile mask (subtile_mask) and the bbox
-// re-packed as origin | extent << 16 for unsigned SDWA compares.  The scalar unit is shared by a CU's four
-// SIMDs and was the co-bottleneck of the first version (SQ_INSTS_SALU 313 M vs SQ_INSTS_VALU 587 M).
+// Per-record work is decided once, at staging time, in parallel over the chunk: stage_decode (fgs_wave.h) leaves a flags
+// word (touched sub-tiles, ...) and 32 pixel bits; in the list loop a lane turns its column / row bit into an all-ones /
+// zero mask with v_bfe_i32 and and-s it onto G -- no per-pixel compare / select (issue costs: DESIGN.md section 4).
 // SKIP: FgsDims.saturation_skip (separate instantiation).
 
-template <bool PHASE, int FWD_WAVES, bool SKIP>
+template <int FWD_WAVES, bool SKIP>
 __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
-    uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
+    uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
-    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
-    float *__restrict__ pix_state, float *__restrict__ phase_ckpt, float *__restrict__ out_rgb,
+    const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec,
+    float *__restrict__ pix_state, float *__restrict__ out_rgb,
     float *__restrict__ out_depth, const uint32_t *__restrict__ seg_off, float *__restrict__ seg_ckpt, float t_eps) {
     // records per LDS chunk: one per thread, but never more than a depth segment on the blend path
-    constexpr int FCH = (!PHASE && 64 * FWD_WAVES > FGS_SEG) ? FGS_SEG : 64 * FWD_WAVES;
-    static_assert(PHASE || FGS_SEG % FCH == 0, "segment boundaries must fall on chunk boundaries");
+    constexpr int FCH = (64 * FWD_WAVES > FGS_SEG) ? FGS_SEG : 64 * FWD_WAVES;
+    static_assert(FGS_SEG % FCH == 0, "segment boundaries must fall on chunk boundaries");
     __shared__ float4 sh0[FCH], sh1[FCH], sh2[FCH];
-    __shared__ float shp[FCH];
-    __shared__ uint32_t shm[FCH];
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = FWD_WAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     constexpr int NS = 4 / FWD_WAVES;  // sub-tiles per wave
-    // non-phase path: running transmittance T (w = alpha T; T -= w); phase path: accumulated alpha A
-    float A[NS], T[NS], Cr[NS], Cg[NS], Cb[NS], Dm[NS], Ph[NS];
+    // running transmittance T (w = alpha T; T -= w)
+    float T[NS], Cr[NS], Cg[NS], Cb[NS], Dm[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { A[s] = 0; T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; Ph[s] = 0; }
+    for (int s = 0; s < NS; ++s) { T[s] = 1.0f; Cr[s] = 0; Cg[s] = 0; Cb[s] = 0; Dm[s] = 0; }
     // sub-tile rows / columns per wave: 4 sub-tiles = 2 x 2, 2 = one row of two, 1 = a single sub-tile
     constexpr int NR = NS == 4 ? 2 : 1, NC = NS == 1 ? 1 : 2;
     const uint32_t row0 = NS == 4 ? 0u : (NS == 2 ? wave : wave >> 1), col0 = NS == 1 ? (wave & 1u) : 0u;
@@ -125,7 +121,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
     asm("" : "+v"(fx0), "+v"(fx1), "+v"(fy0));  // hoisted for good: no v_cvt in the list loop
     for (uint32_t base = c.start; base < c.end; base += FCH) {
         const uint32_t n = min((uint32_t)FCH, c.end - base);
-        if (!PHASE && base != c.start && ((base - c.start) % FGS_SEG) == 0) {
+        if (base != c.start && ((base - c.start) % FGS_SEG) == 0) {
             // state in front of this depth segment: the backward work unit (tile, segment) restarts from it
             float *ck = seg_ckpt + ((size_t)seg_off[c.tile] + (base - c.start) / FGS_SEG) * (5 * 256) + lane;
 #pragma unroll
@@ -155,76 +151,12 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
             float4 q0 = r[0], q1 = r[1], q2 = r[2];
             q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
-            const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu, by1 = bby >> 16;
-            if (PHASE) {
-                shm[threadIdx.x] = subtile_mask(c.X0, c.Y0, bx0, bx1, by0, by1);
-                q2.z = __uint_as_float(bx0 | ((bx1 - bx0) << 16));
-                q2.w = __uint_as_float(by0 | ((by1 - by0) << 16));
-            } else {
-                uint32_t flags, bits;  // flags: touched sub-tiles (none when the opacity is negative); bits: pixel masks
-                stage_decode(c.X0, c.Y0, bbx, bby, q1.y, flags, bits);
-                q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
-            }
+            uint32_t flags, bits;  // flags: touched sub-tiles (none when the opacity is negative); bits: pixel masks
+            stage_decode(c.X0, c.Y0, bbx, bby, q1.y, flags, bits);
+            q2.z = __uint_as_float(bits); q2.w = __uint_as_float(flags);
             sh0[threadIdx.x] = q0; sh1[threadIdx.x] = q1; sh2[threadIdx.x] = q2;
-            if (PHASE) shp[threadIdx.x] = phase[gid];
         }
         __syncthreads();
-        if constexpr (PHASE) {
-            // Phase path: the list walk visits only the entries whose bbox touches one of this wave's sub-tiles
-            // (64-bit scalar masks from the staged 4-bit sub-tile masks), in sub-chunks of FGS_PHASE_CKPT entries; a
-            // sub-chunk's (A, Phi) checkpoint is written when it has such an entry -- exactly the sub-chunks the
-            // backward's waves re-run (untouched entries leave the state as it is)
-            const uint32_t wmask = ((1u << NS) - 1u) << (wave * NS);
-            auto phase_entry = [&](uint32_t j) {
-                const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-                const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[j]);
-                const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);  // origin | extent << 16
-                const float ph = shp[j];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const uint32_t sg = wave * NS + s;  // sub-tile index inside the tile (scalar)
-                    if (!((msk >> sg) & 1u)) continue;  // scalar branch: sub-tile not touched
-                    const uint32_t px = c.X0 + 8u * (sg & 1) + lx, py = c.Y0 + 8u * (sg >> 1) + ly;
-                    const bool in = (px - (bbx & 0xFFFFu)) < (bbx >> 16) && (py - (bby & 0xFFFFu)) < (bby >> 16);
-                    const float dx = (float)px - q0.x, dy = (float)py - q0.y;
-                    const float m = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
-                    float alpha = __builtin_amdgcn_exp2f(m) * q1.y;
-                    if (PHASE) {
-                        float pd = fabsf(ph - Ph[s]);
-                        pd = fminf(pd, 1.0f - pd);
-                        alpha *= (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
-                    }
-                    alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
-                    alpha = in ? alpha : 0.0f;
-                    const float w = alpha * (1.0f - A[s]);
-                    Cr[s] += w * q1.z; Cg[s] += w * q1.w; Cb[s] += w * q2.x; Dm[s] += w * q2.y;
-                    A[s] += w;
-                    if (PHASE) {
-                        const float pc = w / fmaxf(A[s], 1e-6f);
-                        Ph[s] = in ? (Ph[s] * (1.0f - pc) + ph * pc) : Ph[s];
-                    }
-                }
-            };
-            for (uint32_t g0 = 0; g0 < n; g0 += 64) {
-                unsigned long long touched = __ballot(g0 + lane < n && (shm[g0 + lane] & wmask) != 0u);
-                while (touched) {
-                    const uint32_t sc = (uint32_t)(__ffsll((long long)touched) - 1) >> 3;  // sub-chunk inside the group
-                    uint32_t tsub = (uint32_t)(touched >> (8u * sc)) & 0xFFu;
-                    touched &= ~(0xFFull << (8u * sc));
-                    const uint32_t j0 = g0 + 8u * sc;
-                    static_assert(FGS_PHASE_CKPT == 8, "sub-chunk masks are bytes");
-                    const size_t slot = (size_t)(c.start / FGS_PHASE_CKPT) + (base - c.start + j0) / FGS_PHASE_CKPT + c.tile;
-                    float *ck = phase_ckpt + slot * 512 + lane;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) { ck[(wave * NS + s) * 64] = A[s]; ck[(4 + wave * NS + s) * 64] = Ph[s]; }
-                    while (tsub) {
-                        const uint32_t k = (uint32_t)__ffs((int)tsub) - 1u;
-                        tsub &= tsub - 1u;
-                        phase_entry(j0 + k);
-                    }
-                }
-            }
-        } else
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
             {
@@ -260,13 +192,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
         }
         __syncthreads();
     }
-    if constexpr (!PHASE) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) A[s] = 1.0f - T[s];
-        // live-segment count for the backward, parked in the (otherwise unused) checkpoint slot of segment 0
-        if (SKIP && threadIdx.x == 0 && c.end > c.start)
-            reinterpret_cast<uint32_t *>(seg_ckpt + (size_t)seg_off[c.tile] * (5 * 256))[0] = live_segments;
-    }
+    // live-segment count for the backward, parked in the (otherwise unused) checkpoint slot of segment 0
+    if (SKIP && threadIdx.x == 0 && c.end > c.start)
+        reinterpret_cast<uint32_t *>(seg_ckpt + (size_t)seg_off[c.tile] * (5 * 256))[0] = live_segments;
     const size_t HW = (size_t)W * H;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -275,9 +203,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_composite_fwd(
         if (px < W && py < H) {
             const size_t o = (size_t)py * W + px;
             float *ps = pix_state + (size_t)c.b * 6 * HW + o;
-            ps[0] = Cr[s]; ps[HW] = Cg[s]; ps[2 * HW] = Cb[s]; ps[3 * HW] = A[s]; ps[4 * HW] = Dm[s];
-            ps[5 * HW] = Ph[s];
-            const float T = 1.0f - A[s];
+            const float Af = 1.0f - T[s];
+            ps[0] = Cr[s]; ps[HW] = Cg[s]; ps[2 * HW] = Cb[s]; ps[3 * HW] = Af; ps[4 * HW] = Dm[s];
+            const float T = 1.0f - Af;  // (as the backward will see it)
             float *img = out_rgb + (size_t)c.b * 3 * HW + o;
             img[0] = fminf(fmaxf(Cr[s] + T * bg0, 0.0f), 1.0f);
             img[HW] = fminf(fmaxf(Cg[s] + T * bg1, 0.0f), 1.0f);
@@ -722,15 +650,136 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6
     }
 }
 
-// Phase-blending backward (the reference cannot backprop this path at
-// all, §0.6 -- the contract is the exact adjoint of the forward recurrence DR:629-667).
-// alpha_i depends on the running weighted-mean phase Phi_{i-1}, so the recurrence cannot be
-// inverted back-to-front: the forward stores (A, Phi) per pixel every FGS_PHASE_CKPT list
-// entries; this kernel walks the list in REVERSE sub-chunks, re-runs the forward inside each
-// sub-chunk from its checkpoint (parking (A_{i-1}, Phi_{i-1}) per entry in LDS), then sweeps
-// the sub-chunk back-to-front with the per-pixel adjoints Abar (init -gI.bg) and Phibar.
-// (76 VGPRs = 6 waves per SIMD; forcing 7 spills 3 registers and costs 8 %, forcing 8 spills 19 and costs 30 %)
-__global__ __launch_bounds__(256) void k_composite_bwd_phase(
+// ---------------------------------------------------------------------------------------------------------------------
+// Phase-blending path (BASELINE config 4).  alpha_i depends on the running weighted-mean phase
+// Phi_{i-1} (DR:629-667): a true recurrence per pixel, a serial cos / divide chain -- latency-bound, so the unit of work is
+// small: ONE WAVE PER 8 x 8 SUB-TILE (four per 16 x 16 tile, in one block so that they share the tile's list through the
+// CU's caches), and -- round 4 -- the four waves no longer share anything else:
+//   * every wave scans the tile's list 64 entries at a time, tests the bboxes against ITS sub-tile and parks only the
+//     records that touch it, COMPACTED and in list order, in wave-private LDS (ballot + mbcnt).  No block barrier in the list
+//     walk (round 3: one per 64 entries, the four waves of a tile waiting for the slowest), no scalar mask walk over
+//     untouched entries;
+//   * checkpoints (A, Phi) for the backward are taken every FGS_PHASE_CKPT TOUCHED entries of a scan block (round 3: every 8
+//     list positions that held at least one touched entry -- at ~40 % touched entries that was 7.9 checkpoints per 64
+//     entries for 3.2 entries each; now ceil(25 / 8) ~ 3.6): half the checkpoint traffic and twice the entries per
+//     restart.  Slot of group g of the scan block at list offset o: start / 8 + o / 8 + g + tile (g < 8: the capacity
+//     of fgs_make_plan is unchanged), plane w = A of sub-tile w, plane 4 + w = Phi.
+// bbox membership is a per-lane bit-and with masks from the staged column / row bits (v_bfe_i32), as on the blend path.
+struct PhaseRec {     // one compacted list entry in wave-private LDS
+    float4 a[64];     // u, v, conic a, conic b + c
+    float4 b[64];     // conic d, opacity, colour r, g
+    float4 c[64];     // colour b, depth, phase, pixel bits (bits 0-7: columns sx + i inside the bbox, 8-15: rows sy + i)
+};
+
+// scan step shared by the two kernels: lane j < n looks at list entry base + j; returns the ballot of the entries that touch
+// the sub-tile at (sx, sy) and parks those, compacted, in `st`.  K = factor on the conic (forward: exp2 units)
+template <bool FWD>
+__device__ __forceinline__ unsigned long long phase_scan(PhaseRec &st, uint32_t *rows, uint32_t gid, bool have, uint32_t sx,
+                                                         uint32_t sy, const TileCtx &c,
+                                                         const float *__restrict__ rec, const float *__restrict__ phase,
+                                                         const uint32_t *__restrict__ dup_off) {
+    float4 q0, q1, q2;
+    uint32_t bits = 0, e = 0;
+    if (have) {
+        const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
+        q0 = r[0]; q1 = r[1]; q2 = r[2];
+        const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
+        const int x0 = (int)(bbx & 0xFFFFu), x1 = (int)(bbx >> 16), y0 = (int)(bby & 0xFFFFu), y1 = (int)(bby >> 16);
+        const int lx0 = max(x0 - (int)sx, 0), lx1 = min(x1 - (int)sx, 8), ly0 = max(y0 - (int)sy, 0), ly1 = min(y1 - (int)sy, 8);
+        const uint32_t cm = lx1 > lx0 ? ((1u << (lx1 - lx0)) - 1u) << lx0 : 0u;
+        const uint32_t rm = ly1 > ly0 ? ((1u << (ly1 - ly0)) - 1u) << ly0 : 0u;
+        bits = (cm && rm) ? (cm | (rm << 8)) : 0u;
+        if (!FWD) {  // this duplicate's emission slot: its four gradient rows (one per sub-tile wave) are 4 e .. 4 e + 3 (k_project_bwd)
+            const uint32_t tx0 = (uint32_t)x0 / FGS_TILE, tx1 = (uint32_t)(x1 - 1) / FGS_TILE, ty0 = (uint32_t)y0 / FGS_TILE;
+            e = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
+        }
+    }
+    const unsigned long long touched = __ballot(bits != 0u);
+    if (bits) {
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(touched >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touched, 0u));
+        if (FWD) { q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E; }
+        st.a[slot] = q0; st.b[slot] = q1;
+        st.c[slot] = make_float4(q2.x, q2.y, phase[gid], __uint_as_float(bits));
+        if (!FWD) rows[slot] = e;
+    }
+    __builtin_amdgcn_wave_barrier();  // wave-private LDS: one wave's LDS instructions execute in order
+    return touched;
+}
+
+__global__ __launch_bounds__(256) void k_phase_fwd(
+    uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
+    const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ dup_ids,
+    const float *__restrict__ rec, const float *__restrict__ phase, float *__restrict__ pix_state,
+    float *__restrict__ phase_ckpt, float *__restrict__ out_rgb, float *__restrict__ out_depth) {
+    constexpr int PCK = FGS_PHASE_CKPT;
+    __shared__ PhaseRec st4[4];
+    const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PhaseRec &st = st4[wave];
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const uint32_t sx = c.X0 + 8u * (wave & 1u), sy = c.Y0 + 8u * (wave >> 1);
+    float fpx = (float)(sx + lx), fpy = (float)(sy + ly);
+    asm("" : "+v"(fpx), "+v"(fpy));  // hoisted for good: no v_cvt in the list loop
+    float A = 0.0f, Ph = 0.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, Dm = 0.0f;
+    const float base_amp = 1.0f - amp;
+    uint32_t gid_next = (c.start + lane < c.end) ? dup_ids[c.start + lane] : 0u;
+    for (uint32_t base = c.start; base < c.end; base += 64) {
+        const uint32_t gid = gid_next;
+        const bool have = base + lane < c.end;
+        if (base + 64 + lane < c.end) gid_next = dup_ids[base + 64 + lane];  // the next block's ids travel under this one's work
+        const unsigned long long touched = phase_scan<true>(st, nullptr, gid, have, sx, sy, c, rec, phase, nullptr);
+        const uint32_t nt = (uint32_t)__popcll(touched);
+        for (uint32_t j0 = 0; j0 < nt; j0 += PCK) {
+            const size_t slot = (size_t)(c.start / PCK) + (base - c.start + j0) / PCK + c.tile;
+            float *ck = phase_ckpt + slot * 512 + lane;
+            ck[wave * 64] = A; ck[(4 + wave) * 64] = Ph;
+            const uint32_t m = min((uint32_t)PCK, nt - j0);
+#pragma unroll
+            for (int k = 0; k < PCK; ++k) {
+                if (k >= (int)m) break;  // wave-uniform
+                const float4 q0 = st.a[j0 + k], q1 = st.b[j0 + k], q2 = st.c[j0 + k];
+                const uint32_t bits = __float_as_uint(q2.w);
+                const uint32_t mk = (uint32_t)__builtin_amdgcn_sbfe((int)bits, lx, 1) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, 8u + ly, 1);
+                const float dx = fpx - q0.x, dy = fpy - q0.y;
+                const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;  // conic in exp2 units
+                float alpha = __builtin_amdgcn_exp2f(mm) * q1.y;
+                float pd = fabsf(q2.z - Ph);
+                pd = fminf(pd, 1.0f - pd);
+                alpha *= base_amp + amp * phase_cos(pd * PHASE_KAPPA);
+                alpha = __builtin_amdgcn_fmed3f(alpha, 0.0f, ALPHA_MAX);
+                alpha = __uint_as_float(__float_as_uint(alpha) & mk);   // zero outside the bbox: w = pc = 0, nothing moves
+                const float w = alpha * (1.0f - A);
+                Cr += w * q1.z; Cg += w * q1.w; Cb += w * q2.x; Dm += w * q2.y;
+                A += w;
+                const float pc = w / fmaxf(A, 1e-6f);
+                Ph = Ph * (1.0f - pc) + q2.z * pc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the next scan block overwrites the parked records
+    }
+    const uint32_t px = sx + lx, py = sy + ly;
+    if (px < W && py < H) {
+        const size_t HW = (size_t)W * H, o = (size_t)py * W + px;
+        float *ps = pix_state + (size_t)c.b * 6 * HW + o;
+        ps[0] = Cr; ps[HW] = Cg; ps[2 * HW] = Cb; ps[3 * HW] = A; ps[4 * HW] = Dm; ps[5 * HW] = Ph;
+        const float T = 1.0f - A;
+        float *img = out_rgb + (size_t)c.b * 3 * HW + o;
+        img[0] = fminf(fmaxf(Cr + T * bg0, 0.0f), 1.0f);
+        img[HW] = fminf(fmaxf(Cg + T * bg1, 0.0f), 1.0f);
+        img[2 * HW] = fminf(fmaxf(Cb + T * bg2, 0.0f), 1.0f);
+        out_depth[(size_t)c.b * HW + o] = Dm;
+    }
+}
+
+// Backward of the phase recurrence (the reference cannot backprop this path at all, §0.6 -- the contract is the
+// exact adjoint of the forward recurrence DR:629-667).  The recurrence cannot be inverted back-to-front, so the wave walks
+// its sub-tile's touched entries in REVERSE checkpoint groups: re-runs the forward inside a group from the group's (A, Phi)
+// checkpoint, keeping (A_{i-1}, Phi_{i-1}) of its entries in registers (both loops over a group are fully unrolled), then
+// sweeps the group back-to-front with the per-pixel adjoints Abar (init -gI.bg) and Phibar.  Every touched (entry, sub-tile)
+// gets its OWN gradient row (row 4 e + w; k_project_bwd repeats the integer test and never reads the rows of untouched
+// sub-tiles): no cross-wave reduction.
+__global__ __launch_bounds__(256) void k_phase_bwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
     uint32_t dcap, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
@@ -738,183 +787,141 @@ __global__ __launch_bounds__(256) void k_composite_bwd_phase(
     const float *__restrict__ phase_ckpt, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
     float *__restrict__ grad_rows) {
     constexpr int PCK = FGS_PHASE_CKPT;
-    __shared__ float4 sh0[CH], sh1[CH], sh2[CH];
-    __shared__ float shp[CH];
-    __shared__ uint32_t she[CH];
-    __shared__ uint32_t shm[CH];  // touched sub-tiles of each staged record (4-bit mask)
-    // reduction scratch, one per wave (wave_sum11_addtid).  The (A, Phi) states parked by the forward re-run of a
-    // sub-chunk live in REGISTERS (both loops over a sub-chunk are fully unrolled): the block's static LDS is
-    // 16 KB instead of 37 KB, so occupancy is bounded by the 8 wave slots per SIMD, not by LDS -- this path is a
-    // serial cos / sin / divide chain per pixel and lives on latency hiding
-    __shared__ __attribute__((aligned(16))) float red4[4][11 * FGS_RED_PITCH];
+    __shared__ PhaseRec st4[4];
+    __shared__ uint32_t rows4[4][64];
+    __shared__ __attribute__((aligned(16))) float red4[4][11 * FGS_RED_PITCH];  // reduction scratch, one per wave
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
-    // FOUR waves per tile, wave w owns the 8x8 sub-tile w and writes its OWN gradient row per list entry it touches
-    // (row 4 e + w; k_project_bwd sums the rows of the touched sub-tiles of every duplicate): the recurrence is a long serial chain per
-    // pixel (cos / sin / divide per entry, forward re-run + reverse sweep), so this path is latency-bound and
-    // four independent waves per tile cut the critical path ~4x without any cross-wave reduction.
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PhaseRec &st = st4[wave];
+    uint32_t *rows = rows4[wave];
+    float *red = red4[wave];
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const size_t HW = (size_t)W * H;
     const uint32_t sx = c.X0 + 8u * (wave & 1u), sy = c.Y0 + 8u * (wave >> 1);
     const uint32_t px = sx + lx, py = sy + ly;
-    float *red = red4[wave];
-    float gr, gg, gb, gd, Abar, Pbar;
-    {
-        gr = gg = gb = gd = 0.0f;
-        Abar = 0.0f; Pbar = 0.0f;
-        if (px < W && py < H) {
-            const size_t o = (size_t)py * W + px;
-            const float *ps = pix_state + (size_t)c.b * 6 * HW + o;
-            const float Tf = 1.0f - ps[3 * HW];
-            const float pr = ps[0] + Tf * bg0, pg = ps[HW] + Tf * bg1, pb = ps[2 * HW] + Tf * bg2;
-            const float *gi = g_rgb + (size_t)c.b * 3 * HW + o;
-            gr = (pr >= 0.0f && pr <= 1.0f) ? gi[0] : 0.0f;
-            gg = (pg >= 0.0f && pg <= 1.0f) ? gi[HW] : 0.0f;
-            gb = (pb >= 0.0f && pb <= 1.0f) ? gi[2 * HW] : 0.0f;
-            gd = g_depth[(size_t)c.b * HW + o];
-            Abar = -(gr * bg0 + gg * bg1 + gb * bg2);  // d/dA of (1 - A) * bg
-        }
+    float fpx = (float)px, fpy = (float)py;
+    asm("" : "+v"(fpx), "+v"(fpy));
+    float gr = 0.0f, gg = 0.0f, gb = 0.0f, gd = 0.0f, Abar = 0.0f, Pbar = 0.0f;
+    if (px < W && py < H) {
+        const size_t o = (size_t)py * W + px;
+        const float *ps = pix_state + (size_t)c.b * 6 * HW + o;
+        const float Tf = 1.0f - ps[3 * HW];
+        const float pr = ps[0] + Tf * bg0, pg = ps[HW] + Tf * bg1, pb = ps[2 * HW] + Tf * bg2;
+        const float *gi = g_rgb + (size_t)c.b * 3 * HW + o;
+        gr = (pr >= 0.0f && pr <= 1.0f) ? gi[0] : 0.0f;  // clamp backward, closed interval
+        gg = (pg >= 0.0f && pg <= 1.0f) ? gi[HW] : 0.0f;
+        gb = (pb >= 0.0f && pb <= 1.0f) ? gi[2 * HW] : 0.0f;
+        gd = g_depth[(size_t)c.b * HW + o];
+        Abar = -(gr * bg0 + gg * bg1 + gb * bg2);  // d/dA of (1 - A) * bg
     }
+    const float base_amp = 1.0f - amp;
     const uint32_t total = c.end - c.start;
-    const uint32_t nchunks = (total + CH - 1) / CH;
-    for (uint32_t ci = nchunks; ci-- > 0;) {
-        const uint32_t base = c.start + ci * CH;
-        const uint32_t n = min((uint32_t)CH, c.end - base);
-        if (threadIdx.x < n) {
-            const uint32_t lane_s = threadIdx.x;
-            const uint32_t gid = dup_ids[base + lane_s];
-            const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
-            const float4 q2 = r[2];
-            sh0[lane_s] = r[0]; sh1[lane_s] = r[1]; sh2[lane_s] = q2;
-            shp[lane_s] = phase[gid];
-            const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
-            const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE;
-            const uint32_t ty0 = (bby & 0xFFFFu) / FGS_TILE;
-            she[lane_s] = dup_off[gid] + (c.ty - ty0) * (tx1 - tx0 + 1) + (c.tx - tx0);
-            shm[lane_s] = subtile_mask(c.X0, c.Y0, bbx & 0xFFFFu, bbx >> 16, bby & 0xFFFFu, bby >> 16);
-        }
-        __syncthreads();
-        // entries of this chunk whose bbox touches THIS wave's sub-tile, as a 64-bit scalar mask: untouched entries
-        // cost nothing below (no LDS reads, no bbox arithmetic, no gradient row -- k_project_bwd repeats the same
-        // integer test and never reads the rows of untouched sub-tiles), and a sub-chunk without touched entries
-        // is skipped with its checkpoint load
-        const unsigned long long touched = __ballot(lane < n && ((shm[lane] >> wave) & 1u));
-        const uint32_t nsub = (n + PCK - 1) / PCK;
-        for (uint32_t si = nsub; si-- > 0;) {
-            const uint32_t j0 = si * PCK;
-            const uint32_t m = min((uint32_t)PCK, n - j0);
-            const uint32_t tsub = (uint32_t)(touched >> j0) & ((1u << PCK) - 1u);
-            if (!tsub) continue;
-            const size_t slot = (size_t)(c.start / PCK) + (ci * CH + j0) / PCK + c.tile;
+    const uint32_t nblocks = (total + 63u) / 64u;
+    uint32_t gid_next = 0u;
+    if (nblocks) {
+        const uint32_t i = c.start + (nblocks - 1u) * 64u + lane;
+        if (i < c.end) gid_next = dup_ids[i];
+    }
+    for (uint32_t bi = nblocks; bi-- > 0;) {
+        const uint32_t base = c.start + bi * 64u;
+        const uint32_t gid = gid_next;
+        const bool have = base + lane < c.end;
+        if (bi) gid_next = dup_ids[base - 64u + lane];  // the block in front of this one: always full
+        const unsigned long long touched = phase_scan<false>(st, rows, gid, have, sx, sy, c, rec, phase, dup_off);
+        const uint32_t nt = (uint32_t)__popcll(touched);
+        const uint32_t ngroups = (nt + PCK - 1) / PCK;
+        for (uint32_t g = ngroups; g-- > 0;) {
+            const uint32_t j0 = g * PCK;
+            const uint32_t m = min((uint32_t)PCK, nt - j0);
+            const size_t slot = (size_t)(c.start / PCK) + (bi * 64u + j0) / PCK + c.tile;
             const float *ck = phase_ckpt + slot * 512 + lane;
             float Af = ck[wave * 64], Pf = ck[(4 + wave) * 64];
-            // ---- forward re-run of the sub-chunk: park (A_{i-1}, Phi_{i-1}) ----
+            // ---- forward re-run of the group: park (A_{i-1}, Phi_{i-1}) ----
             float sA[PCK], sP[PCK];
 #pragma unroll
             for (int k = 0; k < PCK; ++k) {
                 sA[k] = 0.0f; sP[k] = 0.0f;
-                if (k >= (int)m || !((tsub >> k) & 1u)) continue;  // wave-uniform
-                const uint32_t j = j0 + k;
-                const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-                const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
-                const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
-                const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
-                const float ph = shp[j];
-                {
-                    sA[k] = Af; sP[k] = Pf;
-                    const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
-                    const float dx = (float)px - q0.x, dy = (float)py - q0.y;
-                    const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
-                    const float Gf = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E);
-                    float alpha = Gf * q1.y;
-                    float pd = fabsf(ph - Pf);
-                    pd = fminf(pd, 1.0f - pd);
-                    const float interf = (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
-                    alpha *= interf;
-                    alpha = fminf(fmaxf(alpha, 0.0f), 0.99f);
-                    alpha = in ? alpha : 0.0f;
-                    const float w = alpha * (1.0f - Af);
-                    Af += w;
-                    const float pc = w / fmaxf(Af, 1e-6f);
-                    Pf = in ? (Pf * (1.0f - pc) + ph * pc) : Pf;
-                }
+                if (k >= (int)m) continue;  // wave-uniform
+                const float4 q0 = st.a[j0 + k], q1 = st.b[j0 + k], q2 = st.c[j0 + k];
+                const uint32_t bits = __float_as_uint(q2.w);
+                const uint32_t mk = (uint32_t)__builtin_amdgcn_sbfe((int)bits, lx, 1) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, 8u + ly, 1);
+                sA[k] = Af; sP[k] = Pf;
+                const float dx = fpx - q0.x, dy = fpy - q0.y;
+                const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
+                float alpha = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E) * q1.y;
+                float pd = fabsf(q2.z - Pf);
+                pd = fminf(pd, 1.0f - pd);
+                alpha *= base_amp + amp * phase_cos(pd * PHASE_KAPPA);
+                alpha = __builtin_amdgcn_fmed3f(alpha, 0.0f, ALPHA_MAX);
+                alpha = __uint_as_float(__float_as_uint(alpha) & mk);
+                const float w = alpha * (1.0f - Af);
+                Af += w;
+                const float pc = w / fmaxf(Af, 1e-6f);
+                Pf = Pf * (1.0f - pc) + q2.z * pc;
             }
-            // ---- reverse sweep of the sub-chunk ----
+            // ---- reverse sweep of the group ----
 #pragma unroll
             for (int k = PCK - 1; k >= 0; --k) {
-                if (k >= (int)m || !((tsub >> k) & 1u)) continue;  // wave-uniform
-                const uint32_t j = j0 + k;
-                const float4 q0 = sh0[j], q1 = sh1[j], q2 = sh2[j];
-                const uint32_t bbx = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.z));
-                const uint32_t bby = __builtin_amdgcn_readfirstlane(__float_as_uint(q2.w));
-                const uint32_t x0 = bbx & 0xFFFFu, x1 = bbx >> 16, y0 = bby & 0xFFFFu, y1 = bby >> 16;
-                const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;
-                const float ph = shp[j];
-                float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_r = 0, v_g = 0, v_b = 0, v_d = 0,
-                      v_ph = 0;
-                const uint32_t e = she[j];
-                {
-                    const float Aprev = sA[k], Pprev = sP[k];
-                    const bool in = px >= x0 && px < x1 && py >= y0 && py < y1;
-                    const float dx = (float)px - q0.x, dy = (float)py - q0.y;
-                    const float dphi = ph - Pprev;
-                    const float pd0 = fabsf(dphi);
-                    const float pd = fminf(pd0, 1.0f - pd0);
-                    const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
-                    const float G = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E);
-                    const float inter = (1.0f - amp) + amp * phase_cos(pd * PHASE_KAPPA);
-                    // (parking G and `inter` of the re-run instead of recomputing them costs 14 VGPRs = one wave per
-                    // SIMD and was 7 % slower: this kernel lives on occupancy)
-                    const float Gop = G * op, Gint = G * inter;
-                    const float raw = Gop * inter;
-                    const float alpha = in ? fminf(fmaxf(raw, 0.0f), 0.99f) : 0.0f;
-                    const float T = 1.0f - Aprev;
-                    const float w = alpha * T;
-                    const float Ai = Aprev + w;
-                    const float Aic = fmaxf(Ai, 1e-6f);
-                    const float rA = __builtin_amdgcn_rcpf(Aic);
-                    const float pc = w * rA;
-                    const float Pb = in ? Pbar : 0.0f;
-                    v_ph += Pb * pc;
-                    const float pcbar = Pb * dphi;
-                    // d pc/d w, direct (1/A_i) plus through A_i (-w/A_i^2), equals A_{i-1}/A_i^2: kept in that
-                    // cancellation-free form (the two parts cancel to ~0 for a pixel's first contribution)
-                    float Ab = Abar;
-                    float wbar = Ab + (gr * q1.z + gg * q1.w + gb * q2.x + gd * q2.y);
-                    if (Ai >= 1e-6f) {
-                        wbar += pcbar * Aprev * rA * rA;
-                        Ab -= pcbar * w * rA * rA;
-                    } else {
-                        wbar += pcbar * rA;
-                    }
-                    v_r += w * gr; v_g += w * gg; v_b += w * gb; v_d += w * gd;
-                    const float abar = wbar * T;
-                    Ab -= wbar * alpha;
-                    const float rbar = (in && raw >= 0.0f && raw <= 0.99f) ? abar : 0.0f;
-                    v_op += rbar * Gint;
-                    const float pdbar = -(rbar * Gop) * amp * PHASE_KAPPA * phase_sin(PHASE_KAPPA * pd);
-                    const float pd0bar = (pd0 < 1.0f - pd0) ? pdbar : ((pd0 > 1.0f - pd0) ? -pdbar : 0.0f);
-                    const float sg = (dphi > 0.0f) ? 1.0f : ((dphi < 0.0f) ? -1.0f : 0.0f);
-                    v_ph += pd0bar * sg;
-                    if (in) {
-                        Pbar = Pb * (1.0f - pc) - pd0bar * sg;
-                        Abar = Ab;
-                    }
-                    const float dm = -0.5f * (rbar * raw);
-                    v_ca += dm * dx * dx; v_cbc += dm * dx * dy; v_cd += dm * dy * dy;
-                    v_u -= dm * (2.0f * ca * dx + cbc * dy);
-                    v_v -= dm * (cbc * dx + 2.0f * cd * dy);
+                if (k >= (int)m) continue;  // wave-uniform
+                const float4 q0 = st.a[j0 + k], q1 = st.b[j0 + k], q2 = st.c[j0 + k];
+                const uint32_t e = rows[j0 + k];
+                const uint32_t bits = __float_as_uint(q2.w);
+                const uint32_t mk = (uint32_t)__builtin_amdgcn_sbfe((int)bits, lx, 1) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, 8u + ly, 1);
+                const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y, ph = q2.z;
+                const float Aprev = sA[k], Pprev = sP[k];
+                const float dx = fpx - q0.x, dy = fpy - q0.y;
+                const float dphi = ph - Pprev;
+                const float pd0 = fabsf(dphi);
+                const float pd = fminf(pd0, 1.0f - pd0);
+                const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
+                // G zeroed outside the bbox: raw, alpha, w, pc and every gradient term of this pixel then vanish by themselves
+                const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E)) & mk);
+                const float inter = base_amp + amp * phase_cos(pd * PHASE_KAPPA);
+                // (parking G and `inter` of the re-run instead of recomputing them costs 14 VGPRs = one wave per SIMD and
+                // was 7 % slower in round 2: this kernel lives on occupancy)
+                const float Gop = G * op, Gint = G * inter;
+                const float raw = Gop * inter;
+                const float alpha = __builtin_amdgcn_fmed3f(raw, 0.0f, ALPHA_MAX);
+                const float T = 1.0f - Aprev;
+                const float w = alpha * T;
+                const float Ai = Aprev + w;
+                const float rA = __builtin_amdgcn_rcpf(fmaxf(Ai, 1e-6f));
+                const float pc = w * rA;
+                const float Pb = __uint_as_float(__float_as_uint(Pbar) & mk);  // Phibar reaches this entry only inside its bbox
+                float v_ph = Pb * pc;
+                const float pcbar = Pb * dphi;
+                // d pc/d w, direct (1/A_i) plus through A_i (-w/A_i^2), equals A_{i-1}/A_i^2: kept in that cancellation-free
+                // form (the two parts cancel to ~0 for a pixel's first contribution)
+                float Ab = Abar;
+                float wbar = Ab + (gr * q1.z + gg * q1.w + gb * q2.x + gd * q2.y);
+                if (Ai >= 1e-6f) {
+                    wbar += pcbar * Aprev * rA * rA;
+                    Ab -= pcbar * w * rA * rA;
+                } else {
+                    wbar += pcbar * rA;
                 }
-                {
-                    const float vals[11] = {v_u, v_v, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d, v_ph};
-                    const float tot = wave_sum11_addtid(red, vals, lane);
-                    if ((lane & 3u) == 3u && lane < 44u && e < dcap)
-                        grad_rows[((size_t)e * 4 + wave) * FGS_GROW_FLOATS + (lane >> 2)] = tot;
-                }
+                const float v_r = w * gr, v_g = w * gg, v_b = w * gb, v_d = w * gd;
+                const float abar = wbar * T;
+                Abar = Ab - wbar * alpha;  // (outside the bbox: w = alpha = pcbar = 0, Abar unchanged)
+                const float rbar = (raw >= 0.0f && raw <= ALPHA_MAX) ? abar : 0.0f;  // clamp passes the gradient on the closed interval
+                const float v_op = rbar * Gint;
+                const float pdbar = -(rbar * Gop) * amp * PHASE_KAPPA * phase_sin(PHASE_KAPPA * pd);
+                const float pd0bar = (pd0 < 1.0f - pd0) ? pdbar : ((pd0 > 1.0f - pd0) ? -pdbar : 0.0f);
+                const float sg = (dphi > 0.0f) ? 1.0f : ((dphi < 0.0f) ? -1.0f : 0.0f);
+                const float t_ph = pd0bar * sg;
+                v_ph += t_ph;
+                Pbar -= Pb * pc + t_ph;  // = Pb (1 - pc) - pd0bar sg inside the bbox, unchanged outside (Pb = G = 0 there)
+                const float dm = -0.5f * (rbar * raw);
+                const float dmx = dm * dx, dmy = dm * dy;
+                const float vals[11] = {-(2.0f * ca * dmx + cbc * dmy), -(cbc * dmx + 2.0f * cd * dmy), dmx * dx, dmx * dy, dmy * dy,
+                                        v_op, v_r, v_g, v_b, v_d, v_ph};
+                const float tot = wave_sum11_addtid(red, vals, lane);
+                if ((lane & 3u) == 3u && lane < 44u && e < dcap)
+                    grad_rows[((size_t)e * 4 + wave) * FGS_GROW_FLOATS + (lane >> 2)] = tot;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();  // the next scan block overwrites the parked records
     }
 }
 
@@ -930,10 +937,17 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     const uint32_t *tile_order = reinterpret_cast<const uint32_t *>(saved + p.L.tile_order);
     const float *rec = reinterpret_cast<const float *>(saved + p.L.rec);
     float *pix = reinterpret_cast<float *>(saved + p.L.pix_state);
-    float *ckpt = p.d.use_phase ? reinterpret_cast<float *>(saved + p.L.phase_ckpt) : nullptr;
     const uint32_t *seg_off = reinterpret_cast<const uint32_t *>(saved + p.L.seg_off);
     float *seg_ckpt = reinterpret_cast<float *>(saved + p.L.seg_ckpt);
-    const float t_eps = (p.d.saturation_skip && !p.d.use_phase) ? FGS_SATURATION_EPS : 0.0f;
+    if (p.d.use_phase) {  // one wave per 8 x 8 sub-tile, four per block
+        hipLaunchKernelGGL(k_phase_fwd, dim3(grid), dim3(256), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x, (uint32_t)p.d.width,
+                           (uint32_t)p.d.height, p.d.background[0], p.d.background[1], p.d.background[2], p.d.phase_amplitude,
+                           tile_order, ranges, dup_ids, rec, phase, pix, reinterpret_cast<float *>(saved + p.L.phase_ckpt), out_rgb,
+                           out_depth);
+        FGS_LAUNCH_CHECK("k_phase_fwd");
+        return FGS_OK;
+    }
+    const float t_eps = p.d.saturation_skip ? FGS_SATURATION_EPS : 0.0f;
     const int fw = p.fwd_waves;
     if (const int np = p.fwd_parts) {
 #define FGS_PARTS_LAUNCH(NP, WD)                                                                              \
@@ -952,18 +966,15 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
         FGS_LAUNCH_CHECK("k_blend_fwd_parts");
         return FGS_OK;
     }
-#define FGS_FWD_LAUNCH(PH, FW, SK)                                                                            \
-    hipLaunchKernelGGL((k_composite_fwd<PH, FW, SK>), dim3(grid), dim3(64 * FW), 0, st, (uint32_t)p.tiles,   \
+#define FGS_FWD_LAUNCH(FW, SK)                                                                                \
+    hipLaunchKernelGGL((k_composite_fwd<FW, SK>), dim3(grid), dim3(64 * FW), 0, st, (uint32_t)p.tiles,       \
                        (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],  \
-                       p.d.background[1], p.d.background[2], p.d.phase_amplitude, tile_order, ranges, dup_ids, \
-                       rec, phase, pix, ckpt, out_rgb, out_depth, seg_off, seg_ckpt, t_eps)
-    if (p.d.use_phase) {
-        const int pw = fw;
-        if (pw == 1) FGS_FWD_LAUNCH(true, 1, false); else if (pw == 2) FGS_FWD_LAUNCH(true, 2, false); else FGS_FWD_LAUNCH(true, 4, false);
-    } else if (t_eps > 0.0f) {  // FgsDims.saturation_skip: separate instantiation, the default path carries no trace of it
-        if (fw == 1) FGS_FWD_LAUNCH(false, 1, true); else if (fw == 4) FGS_FWD_LAUNCH(false, 4, true); else FGS_FWD_LAUNCH(false, 2, true);
+                       p.d.background[1], p.d.background[2], tile_order, ranges, dup_ids, rec, pix, out_rgb,  \
+                       out_depth, seg_off, seg_ckpt, t_eps)
+    if (t_eps > 0.0f) {  // FgsDims.saturation_skip: separate instantiation, the default path carries no trace of it
+        if (fw == 1) FGS_FWD_LAUNCH(1, true); else if (fw == 4) FGS_FWD_LAUNCH(4, true); else FGS_FWD_LAUNCH(2, true);
     } else {
-        if (fw == 1) FGS_FWD_LAUNCH(false, 1, false); else if (fw == 4) FGS_FWD_LAUNCH(false, 4, false); else FGS_FWD_LAUNCH(false, 2, false);
+        if (fw == 1) FGS_FWD_LAUNCH(1, false); else if (fw == 4) FGS_FWD_LAUNCH(4, false); else FGS_FWD_LAUNCH(2, false);
     }
 #undef FGS_FWD_LAUNCH
     FGS_LAUNCH_CHECK("k_composite_fwd");
@@ -975,7 +986,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
     (void)g_phase;  // dL/dphase travels in the gradient rows and is written by k_project_bwd
     const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
     if (p.d.use_phase) {
-        hipLaunchKernelGGL(k_composite_bwd_phase, dim3(grid), dim3(256), 0, st, (uint32_t)p.tiles,
+        hipLaunchKernelGGL(k_phase_bwd, dim3(grid), dim3(256), 0, st, (uint32_t)p.tiles,
                            (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],
                            p.d.background[1], p.d.background[2], p.d.phase_amplitude, (uint32_t)p.L.dup_capacity,
                            reinterpret_cast<const uint32_t *>(saved + p.L.tile_order),
@@ -986,7 +997,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
                            reinterpret_cast<const float *>(saved + p.L.pix_state),
                            reinterpret_cast<const float *>(saved + p.L.phase_ckpt), g_rgb, g_depth,
                            reinterpret_cast<float *>(scratch + p.s_grows));
-        FGS_LAUNCH_CHECK("k_composite_bwd_phase");
+        FGS_LAUNCH_CHECK("k_phase_bwd");
         return FGS_OK;
     }
     const uint32_t ugrid = (uint32_t)p.L.seg_capacity;  // surplus blocks exit at once (measured: free)

@@ -94,16 +94,21 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     // 0.586, 4 parts 0.588; config 2 (4096 tiles): 0.169 / 0.167 / 0.134; 32 images: one wave per tile 2.215,
     // 1 part 2.173, 2 parts 2.27).  saturation_skip runs on the row-split forward; its waves per tile: two halve
     // the serial length of the longest lists, one wins with >= 24576 tiles, four for launches that cannot fill the
-    // chip once.  Phase path: the recurrence is latency-bound (serial cos / divide chain per pixel), four waves.
+    // chip once.  Phase path: the recurrence is latency-bound (serial cos / divide chain per pixel), one wave per sub-tile.
     const uint32_t grid_tiles = (uint32_t)(B * p->tiles);
     if (afv > 4 && (d->use_phase || d->saturation_skip || layers != 1 || !segment_ckpt)) {
         fgs_set_error("fwd_variant=%d: 8 / 16 list parts exist on the blend path's depth-split forward only", fv);
         return FGS_EINVAL;
     }
     if (d->use_phase) {
+        // one wave per 8 x 8 sub-tile, four per block (k_phase_fwd / k_phase_bwd): the only work split of this path
+        if (afv != 0 && afv != 4) {
+            fgs_set_error("fwd_variant=%d: the phase path has one work split (one wave per 8 x 8 sub-tile)", fv);
+            return FGS_EINVAL;
+        }
         p->fwd_parts = 0;
-        p->fwd_waves = afv ? afv : 4;
-        p->fwd_variant = -p->fwd_waves;
+        p->fwd_waves = 4;
+        p->fwd_variant = -4;
     } else if (d->saturation_skip || fv < 0) {
         p->fwd_parts = 0;
         p->fwd_waves = fv < 0 ? afv : (grid_tiles >= 24576u ? 1 : (grid_tiles <= 6144u ? 4 : 2));
@@ -162,6 +167,12 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     if (bin_words > nsort) nsort = bin_words;
     const size_t mask_words = p->direct_binning ? B * (size_t)(tx + ty) * fgs_mask_words((uint32_t)N) * 2 : 0;
     if (mask_words > nsort) nsort = mask_words;
+    // the tile tables (k_tile_pre / k_tile_post) borrow ONE sort buffer: per block of FGS_TILE_TABLE_TILES lists a 64-bit sum
+    // (two words) and 64 length buckets per launch-order group (with 8 groups a small call -- few Gaussians, or
+    // 1025 ... 1027 lists -- needs more than the B * N words the buffer used to have)
+    p->tile_table_words = ((bin_words + FGS_TILE_TABLE_TILES - 1) / FGS_TILE_TABLE_TILES) * (2 + 64 * (size_t)p->order_groups);
+    if (p->tile_table_words > nsort) nsort = p->tile_table_words;
+    p->sort_words = nsort;
     // block sums of the duplicate-offset scan: per image and block of FGS_BIN_G depth ranks (direct binning) or per
     // 256 flat elements (radix path) -- whichever is more
     const size_t nblk = B * ((N + FGS_BIN_G - 1) / FGS_BIN_G) + (B * N + 255) / 256 + 1;

@@ -19,6 +19,7 @@ enum { G_U = 0, G_V, G_CA, G_CBC, G_CD, G_OP, G_CR, G_CG, G_CB, G_DEPTH, G_PHASE
                                     the bytes each way; measured in round 3, see DESIGN.md */
 #endif
 #define FGS_BIN_G 256  /* depth ranks per block of the direct binning (fgs_bin.hip) */
+#define FGS_TILE_TABLE_TILES 1024  /* lists per block of the tile-table kernels (fgs_bin.hip k_tile_pre / k_tile_post) */
 enum { R_U = 0, R_V, R_CA, R_CBC, R_CD, R_OP, R_CR, R_CG, R_CB, R_DEPTH, R_BBX, R_BBY };
 
 struct FgsPlan {
@@ -41,6 +42,8 @@ struct FgsPlan {
     int32_t order_groups;     // XCD groups of the forward's launch order (fgs_bin.hip tile_group): 8 on the blend path's
                               // depth-split forward, 1 elsewhere
     // scratch layout (bytes)
+    size_t sort_words;        // uint32 words of EACH of the four sort buffers below
+    size_t tile_table_words;  // words the tile-table kernels need in the one sort buffer they borrow (<= sort_words)
     size_t s_total;
     size_t s_keys0, s_keys1;  // uint32 [max(B*N, Dcap)] radix ping/pong keys
     size_t s_vals0, s_vals1;  // uint32 [max(B*N, Dcap)] radix ping/pong payloads (vals of the final pass land in saved.dup_ids)

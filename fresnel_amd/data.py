@@ -36,7 +36,8 @@ class ImageDataset:
     def __len__(self) -> int:
         return len(self.image_paths)
 
-    def __getitem__(self, idx: int) -> Dict[str, torch.Tensor]:
+    def _step_tensors(self, idx: int):
+        """image, features (C,37,37), depth of item `idx` -- the three tensors a training step consumes."""
         from PIL import Image
         path = self.image_paths[idx]
         name = path.stem
@@ -45,10 +46,14 @@ class ImageDataset:
         image = (torch.from_numpy(np.array(img)).float() / 255.0).permute(2, 0, 1)
         fpath = self.feature_cache_dir / f"{name}{self.feature_suffix}"
         dpath = self.feature_cache_dir / f"{name}_depth.bin"
-        spath = self.feature_cache_dir / f"{name}_saag.bin"
         features = (fio.load_feature_cache(str(fpath), self.feature_dim) if fpath.exists()
                     else torch.zeros(self.feature_dim, fio.FEATURE_GRID, fio.FEATURE_GRID))
         depth = fio.load_depth_cache(str(dpath), S) if dpath.exists() else torch.zeros(1, S, S)
+        return name, image, features, depth
+
+    def __getitem__(self, idx: int) -> Dict[str, torch.Tensor]:
+        name, image, features, depth = self._step_tensors(idx)
+        spath = self.feature_cache_dir / f"{name}_saag.bin"
         item = {"image": image, "features": features, "depth": depth, "has_saag": spath.exists(), "name": name}
         if spath.exists():
             saag = fio.load_gaussians_from_binary(str(spath))
@@ -62,8 +67,8 @@ class ImageDataset:
     def host_item(self, idx: int):
         """(image (3,S,S), features (37,37,C) patch-major as the decoder takes them, depth (1,S,S)) on the host: what the
         training loop's prefetch threads load ahead of the step (fresnel_amd/train.py BatchPrefetcher)."""
-        it = self[idx]
-        return it["image"], it["features"].permute(1, 2, 0).contiguous(), it["depth"]
+        _, image, features, depth = self._step_tensors(idx)  # (not self[idx]: the SAAG binaries are not part of a step)
+        return image, features.permute(1, 2, 0).contiguous(), depth
 
     def batch(self, indices, device):
         """(images (B,3,S,S), features (B,37,37,C) patch-major as the decoder takes them, depth (B,1,S,S))."""

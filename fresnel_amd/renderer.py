@@ -494,7 +494,37 @@ class AngularSpectrumPropagator(nn.Module):
         return self.propagate(field, z_distance, wavelength)
 
 
-class ASMWaveFieldRenderer(nn.Module):
+class _HostBackground:
+    """The wave renderers keep `background` as a registered buffer like the reference (DR:705, DR:1103), but the kernels take
+    it as three host floats in the dims -- reading the buffer back would be a device sync per call.  So the module keeps a
+    host copy and re-reads the buffer only when it is ANOTHER tensor object or its version counter moved (an in-place edit,
+    `load_state_dict`): the reference reads the buffer on every call, and so -- observably -- does this.  Moves
+    (`.to(device)`, `.cuda()`) keep the values and are absorbed in `_apply` without a read-back."""
+
+    def _init_background(self, background):
+        self.register_buffer("background", torch.tensor(background))
+        self._bg = [float(b) for b in background]
+        self._bg_mark()
+
+    def _bg_mark(self):
+        object.__setattr__(self, "_bg_src", (self.background, self.background._version))
+
+    def _apply(self, fn, *a, **k):
+        stale = not (self.background is self._bg_src[0] and self.background._version == self._bg_src[1])
+        out = super()._apply(fn, *a, **k)
+        if not stale:
+            self._bg_mark()
+        return out
+
+    def _background_host(self):
+        b = self.background
+        if not (b is self._bg_src[0] and b._version == self._bg_src[1]):
+            self._bg = [float(v) for v in b.detach().cpu().tolist()]
+            self._bg_mark()
+        return self._bg
+
+
+class ASMWaveFieldRenderer(_HostBackground, nn.Module):
     """Drop-in for the reference's ASMWaveFieldRenderer (DR:1068-1344), HIP + hipFFT backed.
 
     forward(positions, scales, rotations, colors, opacities, camera, return_depth=False, phases=None,
@@ -514,8 +544,7 @@ class ASMWaveFieldRenderer(nn.Module):
         self.focal_depth = focal_depth
         self.pixel_pitch = pixel_pitch
         self.wavelength = wavelength
-        self._bg = [float(b) for b in background]  # host copy: reading the registered buffer back would sync every call
-        self.register_buffer("background", torch.tensor(background))
+        self._init_background(background)
         self.register_buffer("depth_planes", torch.linspace(depth_range[0], depth_range[1], num_depth_planes))
         self.propagator = AngularSpectrumPropagator(image_height, image_width, pixel_pitch, wavelength)
 
@@ -530,7 +559,7 @@ class ASMWaveFieldRenderer(nn.Module):
         if wavelengths_rgb is None:
             wavelengths_rgb = torch.full((3,), float(self.wavelength), device=positions.device)
         cfg = dict(width=self.width, height=self.height, max_radius=self.max_radius,
-                   background=self._bg,
+                   background=self._background_host(),
                    num_depth_planes=self.num_depth_planes, depth_range=self.depth_range,
                    focal_depth=self.focal_depth, pixel_pitch=self.pixel_pitch,
                    bin_mode=int(getattr(self, "bin_mode", 0)))  # tests set ren.bin_mode = 2 for the radix path
@@ -602,7 +631,7 @@ class WaveRenderer(torch.autograd.Function):
         return g_pos, g_scl, g_rot, g_col, g_opa, g_ph, None, None
 
 
-class WaveFieldRenderer(nn.Module):
+class WaveFieldRenderer(_HostBackground, nn.Module):
     """Drop-in for the reference's WaveFieldRenderer (DR:689-926), HIP backed: complex amplitude
     accumulation U = sum A_i exp(i phi_i), I = |U|^2.  phases (N,) or (N,3) radians are required
     (ValueError otherwise, DR:779-780).  Batched (B,N,.) inputs render B images per call."""
@@ -611,8 +640,7 @@ class WaveFieldRenderer(nn.Module):
         super().__init__()
         self.width, self.height = image_width, image_height
         self.max_radius = max_radius
-        self._bg = [float(b) for b in background]
-        self.register_buffer("background", torch.tensor(background))
+        self._init_background(background)
 
     def forward(self, positions, scales, rotations, colors, opacities, camera, return_depth: bool = False,
                 phases: Optional[torch.Tensor] = None):
@@ -622,7 +650,7 @@ class WaveFieldRenderer(nn.Module):
         if not batched:
             positions, scales, rotations = positions[None], scales[None], rotations[None]
             colors, opacities, phases = colors[None], opacities[None], phases[None]
-        cfg = dict(width=self.width, height=self.height, max_radius=self.max_radius, background=self._bg)
+        cfg = dict(width=self.width, height=self.height, max_radius=self.max_radius, background=self._background_host())
         img, dep = WaveRenderer.apply(positions, scales, rotations, colors, opacities, phases,
                                       pack_cameras(camera, positions.device), cfg)
         if not batched:

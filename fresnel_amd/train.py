@@ -172,31 +172,59 @@ class BatchPrefetcher:
         self.q = queue.Queue(maxsize=max(1, depth))
         self.pin = self.device.type == "cuda"
         self.workers = max(1, int(num_workers))
+        self.stop = threading.Event()
         self.thread = threading.Thread(target=self._produce, daemon=True)
         self.thread.start()
+
+    def _put(self, item):
+        """Queue `item` unless the consumer has gone away (close()): never blocks for good."""
+        while not self.stop.is_set():
+            try:
+                self.q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def _produce(self):
         from concurrent.futures import ThreadPoolExecutor
         try:
             with ThreadPoolExecutor(self.workers) as pool:
                 for idx in self.lists:
+                    if self.stop.is_set():
+                        return
                     items = list(pool.map(self.data.host_item, idx))
                     batch = tuple(torch.stack(t) for t in zip(*items))
                     if self.pin:
                         batch = tuple(t.pin_memory() for t in batch)
-                    self.q.put(batch)
-            self.q.put(None)
+                    if not self._put(batch):
+                        return
+            self._put(None)
         except BaseException as e:  # surfaces in the consumer, not in a dead thread
-            self.q.put(e)
+            self._put(e)
+
+    def close(self):
+        """Stop the producer and drop what it queued (pinned batches).  Called when the consumer leaves the loop for
+        any reason -- exhaustion, `break`, an exception in the training step -- so no thread is left blocked in `put`."""
+        self.stop.set()
+        while True:
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                break
+        self.thread.join(timeout=5.0)
 
     def __iter__(self):
-        while True:
-            b = self.q.get()
-            if b is None:
-                return
-            if isinstance(b, BaseException):
-                raise b
-            yield tuple(t.to(self.device, non_blocking=True) for t in b)
+        try:
+            while True:
+                b = self.q.get()
+                if b is None:
+                    return
+                if isinstance(b, BaseException):
+                    raise b
+                yield tuple(t.to(self.device, non_blocking=True) for t in b)
+        finally:
+            self.close()
 
 
 def _global_mean_std(x, dp):

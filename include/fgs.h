@@ -35,7 +35,7 @@ extern "C" {
 #define FGS_SEG 128        /* largest depth segment: list entries per backward work unit; a call uses
                               FgsSavedLayout.seg_len (64 for small problems, else FGS_SEG)            */
 #define FGS_TUNE_AUTO 0    /* FgsDims.seg_len / fwd_variant / bin_mode: let the library choose        */
-#define FGS_PHASE_CKPT 8   /* list entries between (A, Phi) checkpoints on the phase path */
+#define FGS_PHASE_CKPT 8   /* phase path: entries of a sub-tile's (compacted) list between (A, Phi) checkpoints */
 #define FGS_CAMERA_FLOATS 24
 
 /* Problem shape.  Mirrors TileBasedRenderer.__init__ (DR:434-450). */
@@ -61,7 +61,7 @@ typedef struct FgsDims {
     int32_t seg_len;        /* list entries per depth segment: 0 | a multiple of 64 up to 512 (saturation_skip: 128) */
     int32_t fwd_variant;    /* forward work split: 0 | 1, 2, 4, 8, 16 = depth-split forward with that many list parts
                                per tile (16 x 16 tiles; at most 8 on 32 x 16 tiles) | -1, -2, -4 = row-split forward with that many waves per tile.
-                               Phase path: |fwd_variant| = waves per tile.                                      */
+                               Phase path: one work split (0 or 4).                                             */
     int32_t bin_mode;       /* tile binning: 0 | 1 = direct (column / row rank masks) | 2 = emit + stable radix sort */
     int32_t tile_w;         /* tile width in pixels: 0 | 16 | 32 (tiles are always 16 rows high).  0 = automatic:
                                32 on the blend path with the depth-split forward for frames >= 512 pixels wide
@@ -91,8 +91,9 @@ typedef struct FgsSavedLayout {
     size_t dup_ids;    /* uint32 [Dcap]: b*N+n per duplicate, sorted by (image,tile), depth
                                          order inside a tile                              */
     size_t pix_state;  /* float  [B][6][H][W]: C_r,C_g,C_b (pre-bg, pre-clamp), A, D, Phi */
-    size_t phase_ckpt; /* float  [slots][8][64] (use_phase only): per-pixel (A, Phi) of a tile at
-                          the start of every 8th list entry; slot = start/8 + chunk + tile        */
+    size_t phase_ckpt; /* float  [slots][8][64] (use_phase only): per-pixel (A, Phi) of a tile's four 8 x 8 sub-tiles (planes w and
+                          4 + w) in front of every 8th entry THAT TOUCHES sub-tile w within a 64-entry block of the
+                          tile's list; slot = start/8 + block offset/8 + group + tile                     */
     size_t dup_capacity; /* Dcap (elements, not bytes)                                    */
     int32_t tiles_x, tiles_y;
     /* Depth segments (non-phase path): a tile's list is cut into segments of FGS_SEG entries; each

@@ -591,6 +591,94 @@ def config3_image_golden():
     save(out, "G15_config3_image_512.npz")
 
 
+def _asm_reference_run(dt, arrs, phases, wl, gI, W, H, bg, **kw):
+    """ASMWaveFieldRenderer itself with torch's default dtype set to `dt` (fp64: plane fields, FFTs, transfer functions
+    and every gradient reduction in double; the reference's own `total_field` stays complex64, DR:1288)."""
+    names = ["positions", "scales", "rotations", "colors", "opacities", "phases"]
+    torch.set_default_dtype(dt)
+    try:
+        camd = Camera(fx=0.8 * W, fy=0.8 * W, cx=W / 2, cy=H / 2, width=W, height=H)
+        camd.set_view(torch.eye(4, dtype=dt))
+        ren = ASMWaveFieldRenderer(W, H, background=bg, **kw)
+        leaves = [torch.from_numpy(a).to(dt).requires_grad_(True) for a in list(arrs) + [phases]]
+        wlt = torch.from_numpy(wl).to(dt).requires_grad_(True)
+        img = ren(*leaves[:5], camd, phases=leaves[5], wavelengths_rgb=wlt)
+        assert img.dtype == dt, img.dtype
+        (img * torch.from_numpy(gI).to(dt)).sum().backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    out = {"image": img.detach().numpy()}
+    for n, t in zip(names, leaves):
+        out["grad_" + n] = t.grad.numpy()
+    out["grad_wavelengths"] = wlt.grad.numpy()
+    return out
+
+
+def config5_image_golden():
+    """G16: ONE image of BASELINE config 5 as benchmarked (8 192 Gaussians @512x512, 16 depth planes 0.1..2.0, focal 0.5,
+    pitch 1/256, per-channel wavelengths .0635/.05/.041, scalar phases U(0, 2 pi)) through the reference's
+    ASMWaveFieldRenderer in fp32 AND in fp64, gradients incl. dL/dlambda.  Stored: image rows 0::16, the gradients of
+    every 8th Gaussian (+ each FULL tensor's max, which the tolerance is relative to), dL/dlambda of both runs; inputs
+    are regenerated by tests/helpers.synth_saag(8192, 1605) + RandomState(1606) phases.
+    Also G9f64: the fp64 run of the two G9 scenes (the committed G9 fixtures hold the fp32 run only) -- the referee for
+    dL/dlambda there."""
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    from helpers import synth_saag
+    names = ["positions", "scales", "rotations", "colors", "opacities", "phases"]
+    # ---- G9 in fp64 ----
+    for tag in ("scalar", "rgb"):
+        g9 = np.load(os.path.join(OUT, f"G9_asm256_128_{tag}.npz"))
+        R = int(g9["size"][0])
+        arrs = [g9[n] for n in names[:5]]
+        r64 = _asm_reference_run(torch.float64, arrs, g9["phases"], g9["wavelengths"], g9["gI"], R, R,
+                                 tuple(float(v) for v in g9["background"]))
+        rec = {"f64_" + k: v for k, v in r64.items()}
+        r32 = _asm_reference_run(torch.float32, arrs, g9["phases"], g9["wavelengths"], g9["gI"], R, R,
+                                 tuple(float(v) for v in g9["background"]))
+        # (a re-run of the committed fp32 fixture: equal up to the summation order of torch's threaded reductions)
+        d_img = float(np.abs(r32["image"] - g9["image"]).max())
+        fin = np.isfinite(g9["grad_wavelengths"])  # (lambda = 0.05 puts frequencies ON the evanescent boundary: the
+        assert np.array_equal(fin, np.isfinite(r32["grad_wavelengths"]))  # reference's fp32 autograd returns NaN there)
+        d_wl = float(np.abs(r32["grad_wavelengths"] - g9["grad_wavelengths"])[fin].max() / np.abs(g9["grad_wavelengths"][fin]).max())
+        print(f"G9 {tag}: fp32 re-run vs committed fixture: image {d_img:.1e} abs, dL/dlambda {d_wl:.1e} rel")
+        assert d_img <= 1e-6 and d_wl <= 1e-4, (d_img, d_wl)
+        rec["f32rerun_grad_wavelengths"] = r32["grad_wavelengths"]
+        rec["f64_image"] = rec["f64_image"].astype(np.float32)
+        rec["case"] = np.array(f"G9_asm256_128_{tag}")
+        for k, v in META.items():
+            rec["meta_" + k] = np.array(v)
+        print(f"G9f64 {tag}: reference fp32 vs fp64 (rel to max): " + ", ".join(
+            f"{k} {np.nanmax(np.abs(r32[k] - r64[k])) / np.abs(r64[k]).max():.1e}" for k in r64)
+              + f"; dL/dlambda fp32 {r32['grad_wavelengths']} fp64 {r64['grad_wavelengths']}")
+        save(rec, f"G9f64_asm256_128_{tag}.npz")
+    # ---- G16 ----
+    S, N, seed = 512, 8192, 1605
+    arrs = list(synth_saag(N, seed))
+    phases = (np.random.RandomState(seed + 1).random_sample(N) * 2 * np.pi).astype(np.float32)
+    wl = np.array([0.0635, 0.05, 0.041], np.float32)
+    gI, _ = upstream(116, S, S)
+    out = dict(name=np.array("G16"), seed=np.int32(seed), num_gaussians=np.int32(N), size=np.array([S, S], np.int32),
+               wavelengths=wl, background=np.zeros(3, np.float32), seed_up=np.int32(116), grad_stride=np.int32(8),
+               rows=np.arange(0, S, 16, dtype=np.int32), num_depth_planes=np.int32(16), depth_range=np.array([0.1, 2.0]),
+               focal_depth=np.float64(0.5), pixel_pitch=np.float64(1.0 / 256.0))
+    runs = {}
+    for dt, pre in ((torch.float32, "f32_"), (torch.float64, "f64_")):
+        import time
+        t0 = time.time()
+        r = runs[pre] = _asm_reference_run(dt, arrs, phases, wl, gI, S, S, (0.0, 0.0, 0.0))
+        print(f"G16 {pre}: {time.time() - t0:.0f} s, dL/dlambda = {r['grad_wavelengths']}")
+        out[pre + "image"] = r["image"][:, ::16].astype(np.float32).copy()
+        out[pre + "grad_wavelengths"] = r["grad_wavelengths"]
+        for n in names:
+            out[pre + "grad_" + n] = r["grad_" + n][::8].copy()
+            out[pre + "gradmax_" + n] = np.float64(np.abs(r["grad_" + n]).max())
+    print("G16 reference fp32 vs fp64 (rel to max): " + ", ".join(
+        f"{k} {np.nanmax(np.abs(runs['f32_'][k] - runs['f64_'][k])) / np.abs(runs['f64_'][k]).max():.1e}" for k in runs["f64_"]))
+    for k, v in META.items():
+        out["meta_" + k] = np.array(v)
+    save(out, "G16_config5_image_512.npz")
+
+
 def needle_goldens():
     """G14: needles (s, s/r, s/r) and discs (s, s, s/r) at ratio r, reference in fp32 and in fp64.  The fp64 run is
     the reference's own code with torch's default dtype set to float64 and double inputs / view matrix."""
@@ -717,6 +805,9 @@ def kink_goldens():
 if __name__ == "__main__":
     if "--config3-only" in sys.argv:
         config3_image_golden()
+        config5_image_golden()
+    elif "--config5-only" in sys.argv:
+        config5_image_golden()
     elif "--kinks-only" in sys.argv:
         kink_goldens()
     elif "--midsize-only" in sys.argv:
@@ -738,3 +829,4 @@ if __name__ == "__main__":
         needle_goldens()
         kink_goldens()
         config3_image_golden()
+        config5_image_golden()

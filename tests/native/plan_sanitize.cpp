@@ -51,6 +51,11 @@ static void check_plan(const FgsDims &d, int layers, bool ckpt) {
         prev = sc[i];
     }
     CHECK(p.s_keys1 - p.s_keys0 >= L.dup_capacity * 4 && p.s_keys1 - p.s_keys0 >= (size_t)d.batch * d.num_gaussians * 4, "sort buffers");
+    // the tile tables borrow one sort buffer: 2 words + 64 buckets per launch-order group for every 1024 lists
+    const size_t lists = (size_t)d.batch * layers * p.tiles, tblk = (lists + FGS_TILE_TABLE_TILES - 1) / FGS_TILE_TABLE_TILES;
+    CHECK(p.tile_table_words == tblk * (2 + 64 * (size_t)p.order_groups) && p.tile_table_words <= p.sort_words, "tile tables");
+    CHECK(p.s_keys1 - p.s_keys0 >= p.sort_words * 4 && p.s_vals0 - p.s_keys1 >= p.sort_words * 4 &&
+          p.s_vals1 - p.s_vals0 >= p.sort_words * 4 && p.s_hist - p.s_vals1 >= p.sort_words * 4, "sort buffer size");
     CHECK(p.s_total - p.s_rsum >= (size_t)d.batch * d.num_gaussians * 48, "row sums");
     if (d.use_phase) CHECK(p.fwd_parts == 0 && p.tile_w == 16, "phase path split");
     if (p.tile_w == 32) CHECK(p.fwd_parts >= 1 && p.fwd_parts <= 8, "wide tiles parts=%d", p.fwd_parts);

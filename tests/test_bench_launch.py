@@ -28,6 +28,55 @@ def test_gpus2_without_launcher_spawns_two_ranks():
     assert out["rank_sum"] == 3.0  # ranks 0 and 1 both took part in the all-reduce
 
 
+def _stub(n, extra=()):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--backend", "gloo", "--stub-renderer", "--steps", "6",
+                        "--warmup", "2", "--spinup-ms", "120"] + list(extra),
+                       capture_output=True, text=True, env=_clean_env(), timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    return json.loads(lines[0])
+
+
+def test_timing_protocol_issues_equal_collectives_on_every_rank_2_ranks():
+    """the clock spin-up ran for a per-rank wall-clock time while every step issues an all-reduce, so
+    ranks with skewed clocks issued different numbers of collectives.  `--stub-renderer` runs bench.py's REAL protocol
+    (run_protocol / spin_up / _timed_region / reduce_over_ranks -- the functions the GPU run calls) around a stand-in
+    step on gloo, with rank-dependent delays in front of the spin-up; the count of step collectives must be equal on
+    all ranks, the job must finish (a mismatch hangs or aborts), and the line must carry both timed regions."""
+    one = _stub(1)
+    out = _stub(2)
+    assert out["stub"] is True and out["value"] is None  # never mistakable for a measurement
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+    assert out["step_collectives_rank_min"] == out["step_collectives_rank_max"] > 0
+    # warm-up 2 + cold region 6 + agreed spin-up + timed region 6
+    assert out["step_collectives_rank_min"] == 2 + 6 + out["spinup_steps"] + 6
+    assert out["spinup_steps"] >= 20 and out["spinup_steps"] % 10 == 0
+    assert out["config"]["pairs_per_step"] == 2 * one["config"]["pairs_per_step"]
+    assert out["ms_per_step_rank_max"] >= out["ms_per_step_rank_min"] > 0
+    assert out["ms_per_step_cold"] > 0 and out["ms_per_step"] == out["ms_per_step_rank_max"]
+    assert one["rccl_ranks"] == 1 and one["ms_per_step_cold"] > 0
+
+
+def test_fake_8_rank_launch_prints_one_line_with_8_ranks():
+    """what the driver runs first on an 8-GPU node, rehearsed with 8 gloo ranks on the CPU: exactly
+    one JSON line, rccl_ranks 8, pairs summed over the ranks = 8 x the one-rank value, max >= min over ranks."""
+    out = _stub(8)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8
+    assert out["config"]["pairs_per_step"] == 8 * out["config"]["pairs_per_step_per_rank"]
+    assert out["ms_per_step_rank_max"] >= out["ms_per_step_rank_min"] > 0
+    assert out["step_collectives_rank_min"] == out["step_collectives_rank_max"] == 2 + 6 + out["spinup_steps"] + 6
+
+
+def test_gpu_run_and_stub_share_the_protocol_functions():
+    """The stub is only evidence for the GPU run if both go through the same code: main() must call run_protocol and
+    reduce_over_ranks, and no second spin-up loop may exist."""
+    src = open(BENCH).read()
+    main_src = src[src.index("def main("):]
+    assert "run_protocol(step, torch.cuda.synchronize, dist" in main_src and "reduce_over_ranks(dist" in main_src
+    assert src.count("perf_counter() - t_spin") == 1 and "t_spin" not in main_src
+
+
 def test_too_few_devices_is_an_error_not_a_one_gpu_run():
     """No GPU here: --gpus 2 on the RCCL backend must exit non-zero with a message and print no result line."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"],

@@ -629,7 +629,10 @@ def test_forward_variants_agree(use_phase):
     """The forward picks its work split from the launch size; FgsDims.fwd_variant / seg_len force one.  Blend path:
     the depth-split kernel with 1, 2, 4, 8 or 16 list parts per tile (partial results composed with
     (C,T)o(C',T') = (C + T C', T T'), the backward re-bases part-local checkpoints), with 64- or 128-entry depth
-    segments, or the row-split kernel with 1, 2 or 4 waves per tile.  Phase path: 1, 2 or 4 waves per tile.  All
+    segments, or the row-split kernel with 1, 2 or 4 waves per tile.  Phase path: ONE work split since round 4 (one wave
+    per 8 x 8 sub-tile, wave-private compacted lists, checkpoint groups of eight touched entries) -- the automatic choice
+    and its explicit name (fwd_variant 4) are the same kernels, other values are refused; this long-list scene (~80
+    entries per list, several scan blocks and checkpoint groups per sub-tile) is its oracle check.  All
     variants must agree on image, depth and -- through the saved state and checkpoints -- on every gradient, to
     1e-5 of max (composition order and FMA contraction differ), and with the ORACLE to the parity tolerance.
     The lists are long enough for several parts: ~3000 entries over 36 tiles."""
@@ -644,7 +647,11 @@ def test_forward_variants_agree(use_phase):
     gD = (rs.standard_normal((S, S)) * 0.1).astype(np.float32)
     phases = rs.uniform(0, 1, N).astype(np.float32) if use_phase else None
     if use_phase:
-        variants = [dict(fwd_variant=w) for w in (1, 2, 4)]
+        variants = [dict(), dict(fwd_variant=4)]
+        from fresnel_amd import _binding as B
+        for bad in (1, 2, 8):
+            with pytest.raises(B.FgsError):
+                B.saved_layout(B.make_dims(1, N, S, S, use_phase=True, tuning=dict(fwd_variant=bad)))
     else:
         variants = ([dict(fwd_variant=p, seg_len=sl) for p in (1, 2, 4) for sl in (64, 128)] +
                     [dict(fwd_variant=-w) for w in (1, 2, 4)] +

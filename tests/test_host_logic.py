@@ -217,6 +217,63 @@ def test_batch_prefetcher_yields_the_batches_in_order_and_surfaces_errors():
         list(BatchPrefetcher(Broken(4, cfg), [[0, 1]], "cpu"))
 
 
+def test_batch_prefetcher_producer_ends_when_the_consumer_leaves_early():
+    """a consumer that stops early (break / an exception in the step) must not leave the producer thread
+    blocked in `put` holding pinned batches."""
+    from fresnel_amd.train import BatchPrefetcher, SyntheticDataset, TrainingConfig
+    cfg = TrainingConfig(image_size=16, feature_size=4, feature_dim=8, device="cpu")
+    data = SyntheticDataset(64, cfg)
+    pf = BatchPrefetcher(data, [[i, i + 1] for i in range(0, 60, 2)], "cpu", num_workers=2, depth=1)
+    for k, _ in enumerate(pf):
+        if k == 1:
+            break           # generator closed -> finally: close()
+    pf.thread.join(timeout=10.0)
+    assert not pf.thread.is_alive() and pf.q.empty()
+    pf2 = BatchPrefetcher(data, [[i, i + 1] for i in range(0, 60, 2)], "cpu", num_workers=2, depth=1)
+    with pytest.raises(RuntimeError):
+        for _ in pf2:
+            raise RuntimeError("train_step failed")
+    pf2.thread.join(timeout=10.0)
+    assert not pf2.thread.is_alive()
+
+
+def test_image_dataset_host_item_does_not_decode_the_saag_binaries(tmp_path, monkeypatch):
+    """The prefetch threads load image, features and depth only (the step never uses the SAAG Gaussians)."""
+    import numpy as np
+    from PIL import Image
+    from fresnel_amd import data as D, io as fio
+    Image.fromarray((np.random.RandomState(0).rand(20, 20, 3) * 255).astype(np.uint8)).save(tmp_path / "a.png")
+    (tmp_path / "features").mkdir()
+    (tmp_path / "features" / "a_saag.bin").write_bytes(b"\0" * 64)
+    monkeypatch.setattr(fio, "load_gaussians_from_binary", lambda *_: (_ for _ in ()).throw(AssertionError("decoded SAAG")))
+    ds = D.ImageDataset(str(tmp_path), image_size=16)
+    img, feats, dep = ds.host_item(0)
+    assert img.shape == (3, 16, 16) and feats.shape == (37, 37, 384) and dep.shape == (1, 16, 16)
+
+
+def test_wave_renderers_follow_their_background_buffer():
+    """the kernels take the background as host floats; the module must notice when the registered buffer is
+    edited in place, replaced, or loaded from a state dict (the reference reads the buffer on every call), and must NOT
+    read it back when nothing changed or after a plain device / dtype move."""
+    import torch
+    from fresnel_amd.renderer import ASMWaveFieldRenderer, WaveFieldRenderer
+    for cls in (ASMWaveFieldRenderer, WaveFieldRenderer):
+        r = cls(32, 32, background=(0.1, 0.2, 0.3))
+        assert r._background_host() == pytest.approx([0.1, 0.2, 0.3])
+        marker = r._bg
+        assert r._background_host() is marker                       # unchanged buffer: no read-back
+        r = r.to(torch.float32)
+        assert r._background_host() is marker                       # a move keeps the values: no read-back
+        r.background.mul_(2.0)
+        assert r._background_host() == pytest.approx([0.2, 0.4, 0.6])
+        sd = r.state_dict()
+        sd["background"] = torch.tensor([0.5, 0.25, 0.0])
+        r.load_state_dict(sd)
+        assert r._background_host() == pytest.approx([0.5, 0.25, 0.0])
+        r.background = torch.tensor([1.0, 0.0, 0.0])
+        assert r._background_host() == [1.0, 0.0, 0.0]
+
+
 def test_training_history_json_and_device_side_nan_skip(tmp_path):
     """run_training on CPU with a stand-in renderer: history file of TGD:1317-1323 (+ step_ms), and a poisoned batch
     is skipped by the fused optimizer's found_inf path without touching weights or step count."""
