@@ -26,6 +26,14 @@
 
 namespace {
 
+// an (image, plane) pair -- or, with `tiles` = lists per image, an image -- with no list entry at all: seg_off is the
+// exclusive scan of every list's depth-segment count in key order (key = (b P + p) T + t; k_tile_post writes it on both
+// list-building paths, [lists + 1] entries), so a key range without entries is a range without units.  (NOT `ranges`: the
+// radix path leaves the ranges of empty lists zeroed.)
+__device__ __forceinline__ bool asm_plane_empty(const uint32_t *__restrict__ seg_off, uint32_t bp, uint32_t tiles) {
+    return seg_off[(size_t)(bp + 1u) * tiles] == seg_off[(size_t)bp * tiles];
+}
+
 constexpr float NEG_HALF_LOG2E = -0.72134752044448170368f;
 constexpr int ACH = 64;
 constexpr int ASM_FWD_PARTS = 4;  // list parts (waves) per (image, plane, tile) in the forward splat
@@ -47,7 +55,6 @@ struct AsmPlan {
                          //                         spectra for dL/dlambda, so the spectra themselves are never stored
     int col_logn;        // log2(H) when the column direction runs in k_colfft_* (H = 64 ... 1024, a power of two), else 0
     int col_tc, col_pg;  // its column tile width, and plane groups per image (> 1 for launches that would not fill the chip)
-    int rows_logw;       // log2(W) when the row direction runs fused with the splat (fgs_asm_rows.h), else 0
     size_t c_accp;       // float2 [B][col_pg][3][H][W] partial plane sums (col_pg > 1)
     size_t v_total_bytes;
     // scratch sections (after base.s_total)
@@ -111,21 +118,11 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
         if (blocks < 512) p->col_pg = (int)((512 + blocks - 1) / blocks);
         if (p->col_pg > (int)P) p->col_pg = (int)P;
     }
-    // Row direction fused with the splat / its adjoint: needs the column kernels (power-of-two height), a power-of-two width
-    // 64 ... 512, and a launch of many short lists (one wave walks a whole list there): (image, plane, tile) lists >= 1024
-    p->rows_logw = 0;
-    // MEASURED IN ROUND 3 AND SWITCHED OFF (FGS_ASM_ROWS=1 builds it in): config 5 at 8 images 2.63 -> 3.33 ms.  The field
-    // stages do get faster (forward 0.84 -> 0.45 ms, backward 0.85 -> 0.52: no rocFFT row passes, empty planes skipped), but
-    // the fused kernels need 133 KB of LDS for the 8-row band, i.e. ONE 16-wave block per CU, and their phases -- the
-    // latency-bound list walk, then the transforms -- run back to back with nothing to overlap them: forward 0.72 ms against
-    // 0.27 (splat) + 0.30 (rocFFT rows), backward 1.50 against 0.60 + 0.33.  The empty-plane skip in the column kernels is
-    // kept for every path (below).
-#ifndef FGS_ASM_ROWS
-#define FGS_ASM_ROWS 0
-#endif
-    if (FGS_ASM_ROWS && p->col_logn && B * P * (size_t)p->base.tiles >= 1024)
-        for (int lg = 6; lg <= 9; ++lg)
-            if (a->width == (1 << lg)) p->rows_logw = lg;
+    // (Round 3 built the row direction fused with the splat / its adjoint -- one kernel per direction keeping a band of 8 rows
+    // x 3 channels x 512 points in LDS, the plane fields never in HBM -- and measured it SLOWER: config 5 at 8 images 2.63 ->
+    // 3.33 ms.  133 KB of LDS = one 16-wave block per CU, whose phases (latency-bound list walk, then the transforms) run back
+    // to back with nothing to overlap them.  Removed in round 4; DESIGN.md 10.5, profiles/r03_ab_config5_*_rows_fused.txt,
+    // the code is in the history at 763bed2 csrc/fgs_asm_rows.h.)
     p->v_total_bytes = o;
     p->work_big = p->work_small = 0;
     if (need_fft) {
@@ -189,7 +186,7 @@ __device__ __forceinline__ void asm_transfer_block(uint32_t blk, int W, int H, i
     const int p = pi < np ? pi * pstride : P;
     const float fx = fftfreq(kx, W, inv_ndx), fy = fftfreq(ky, H, inv_ndy);
     const float il = 1.0f / wavelengths[c];
-    float kz2 = il * il - fx * fx - fy * fy;
+    float kz2 = fgs_kz2(il, fx, fy);
     kz2 = kz2 < 0.0f ? 0.0f : kz2;
     const float kz = sqrtf(kz2);
     float sn, cs;
@@ -202,8 +199,9 @@ __device__ __forceinline__ void asm_transfer_block(uint32_t blk, int W, int H, i
         // step instead of the 1.5e-6 (up to 6.6e-6) of the fp32 expression -- H_lo D^k then stays within the reference's own fp32 phase
         // rounding (5e-6 rad typical at 200 rad) of the directly evaluated H_p for every plane count the interface admits
         const double zd = P > 1 ? -((double)far_ - (double)near_) / (double)(P - 1) : 0.0;
-        const double kz2d = (double)il * (double)il - (double)fx * (double)fx - (double)fy * (double)fy;
-        const double th = 6.283185307179586476925 * zd * (kz2d > 0.0 ? sqrt(kz2d) : 0.0);
+        // (the SAME fp32 kz^2 as H: an exactly evaluated kz^2 differs from the rounded one by up to an ulp of 1/l^2, which near the
+        // evanescent boundary is a relative 1e-4 of kz -- H_lo D^k would drift from H_p by that much of its phase)
+        const double th = 6.283185307179586476925 * zd * sqrt((double)kz2);
         double sd, cd;
         sincos(th, &sd, &cd);
         sn = (float)sd; cs = (float)cd;
@@ -350,10 +348,14 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
             const float4 *r = reinterpret_cast<const float4 *>(rec + (size_t)gid * FGS_REC_FLOATS);
             const float4 q0 = r[0], q1 = r[1], q2 = r[2];
             const uint32_t bbx = __float_as_uint(q2.z), bby = __float_as_uint(q2.w);
-            const uint32_t bx0 = bbx & 0xFFFFu, bx1 = bbx >> 16, by0 = bby & 0xFFFFu, by1 = bby >> 16;
-            shm[wofs + lane] = subtile_mask(X0, Y0, bx0, bx1, by0, by1);
+            // touched sub-tiles + the pixel bits of the tile (bit i: column X0 + i inside the bbox, bit 16 + i: row Y0 + i): in the
+            // list loop a lane turns its column / row bits into all-ones / zero masks (v_bfe_i32) and and-s them onto G -- no
+            // per-pixel compare / select, as on the blend path (issue costs: DESIGN.md section 4)
+            uint32_t sflags, pbits;
+            stage_decode(X0, Y0, bbx, bby, 1.0f, sflags, pbits);
+            shm[wofs + lane] = sflags & 15u;
             if (BWD) {
-                const uint32_t tx0 = bx0 / FGS_TILE, tx1 = (bx1 - 1) / FGS_TILE, ty0 = by0 / FGS_TILE;
+                const uint32_t tx0 = (bbx & 0xFFFFu) / FGS_TILE, tx1 = ((bbx >> 16) - 1) / FGS_TILE, ty0 = (bby & 0xFFFFu) / FGS_TILE;
                 she[lane] = dup_off[gid] + (ty - ty0) * (tx1 - tx0 + 1) + (tx - tx0);
             }
             const float4 *pz = reinterpret_cast<const float4 *>(ccs + (size_t)gid * 8);
@@ -361,8 +363,7 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
             // conic pre-multiplied by K = -log2(e) / 2: G = exp2(K m) without a multiply per pixel (the backward's
             // dL/dconic = -1/2 dG/dm' ... is formed from the unscaled moments, below)
             sh0[wofs + lane] = make_float4(q0.x, q0.y, q0.z * NEG_HALF_LOG2E, q0.w * NEG_HALF_LOG2E);  // u, v, K ca, K cbc
-            sh1[wofs + lane] = make_float4(q1.x * NEG_HALF_LOG2E, q1.y, __uint_as_float(bx0 | ((bx1 - bx0) << 16)),
-                                    __uint_as_float(by0 | ((by1 - by0) << 16)));   // K cd, op, bbx', bby'
+            sh1[wofs + lane] = make_float4(q1.x * NEG_HALF_LOG2E, q1.y, __uint_as_float(pbits), 0.0f);   // K cd, op, pixel bits
             sh2[wofs + lane] = z0;
             sh3[wofs + lane] = make_float4(z1.x, z1.y, q2.y, 0.0f);  // .z = depth (WAVE)
         }
@@ -370,7 +371,9 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
         for (uint32_t j = 0; j < n; ++j) {
             const float4 q0 = sh0[wofs + j], q1 = sh1[wofs + j], q2 = sh2[wofs + j], q3 = sh3[wofs + j];
             const uint32_t msk = __builtin_amdgcn_readfirstlane(shm[wofs + j]);
-            const uint32_t bbx = __float_as_uint(q1.z), bby = __float_as_uint(q1.w);
+            const uint32_t pbits = __float_as_uint(q1.z);
+            const uint32_t mxs[2] = {(uint32_t)__builtin_amdgcn_sbfe((int)pbits, lx, 1), (uint32_t)__builtin_amdgcn_sbfe((int)pbits, lx + 8u, 1)};
+            const uint32_t mys[2] = {(uint32_t)__builtin_amdgcn_sbfe((int)pbits, 16u + ly, 1), (uint32_t)__builtin_amdgcn_sbfe((int)pbits, 24u + ly, 1)};
             const float ca = q0.z, cbc = q0.w, cd = q1.x, op = q1.y;
             const float cc[3] = {q2.x, q2.y, q2.z}, cs[3] = {q2.w, q3.x, q3.y};
             float v_u = 0, v_v = 0, v_ca = 0, v_cbc = 0, v_cd = 0, v_op = 0, v_dep = 0;
@@ -381,11 +384,9 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!((msk >> s) & 1u)) continue;
-                const uint32_t px = X0 + 8u * (s & 1) + lx, py = Y0 + 8u * (s >> 1) + ly;
-                const bool in = (px - (bbx & 0xFFFFu)) < (bbx >> 16) && (py - (bby & 0xFFFFu)) < (bby >> 16);
                 const float dx = dxs[s & 1], dy = dys[s >> 1];
                 const float m = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;  // K m
-                const float G = in ? __builtin_amdgcn_exp2f(m) : 0.0f;
+                const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(m)) & (mxs[s & 1] & mys[s >> 1]));
                 const float a = G * op;  // amplitude, DR:1270-1271 (no clamp on this path)
                 if (!BWD) {
 #pragma unroll
@@ -399,14 +400,14 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
                         da += cc[c] * re[s][c] + cs[c] * im[s][c];
                         v_cc[c] += a * re[s][c]; v_cs[c] += a * im[s][c];
                     }
-                    v_op += da * G;
-                    const float dm = -0.5f * (da * op) * G;
-                    v_ca += dm * dx * dx; v_cbc += dm * dx * dy; v_cd += dm * dy * dy;
-                    // dL/d(u, v) = -dm (2 ca dx + cbc dy, cbc dx + 2 cd dy) with the UNSCALED conic = (K-scaled) / K:
-                    // dmk = dm / K = (da op G) ln 2 ... folded into one constant
-                    const float dmk = (da * op) * G * 0.69314718055994530942f;  // -0.5 / K = ln 2
-                    v_u -= dmk * (2.0f * ca * dx + cbc * dy);
-                    v_v -= dmk * (cbc * dx + 2.0f * cd * dy);
+                    // moments of t = dL/da G about the Gaussian's mean: {1, dx, dy, dx^2, dx dy, dy^2}.  The chain through
+                    // a = G op and m (dL/dm = -1/2 t op; dL/d(u, v) = -dL/dm (2 ca dx + cbc dy, cbc dx + 2 cd dy), linear in the
+                    // first moments) is applied once per Gaussian, in double, by k_project_bwd: 7 VALU per pass instead of 13
+                    const float t = da * G;
+                    v_op += t;
+                    const float tx = t * dx, ty = t * dy;
+                    v_u += tx; v_v += ty;
+                    v_ca += tx * dx; v_cbc += tx * dy; v_cd += ty * dy;
                 }
             }
             if (BWD) {
@@ -532,7 +533,6 @@ __device__ __forceinline__ void load_twiddles(float2 *tw, const float2 *__restri
     for (int i = threadIdx.x; i < n; i += NT) tw[i] = tw_g[i];
 }
 
-#include "fgs_asm_rows.h"
 
 // Addressing of the column kernels: buffer loads / stores -- a UNIFORM base (image / plane / channel: a buffer resource in scalar
 // registers, rebuilt per plane by scalar instructions), a uniform 32-bit byte offset per tile element (scalar) and a 32-bit per-thread
@@ -806,7 +806,7 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
         if (grp == 0) {
             const float2 Z = ld_f2(zg, off_in, (uint32_t)(colfft_freq_e<LOGN, INNER>(e) * W) * 8u);
             const float fy = fftfreq(ky, N, inv_ndy);
-            const float kz2 = il * il - fx * fx - fy * fy;
+            const float kz2 = fgs_kz2(il, fx, fy);
             const float dkz = kz2 > 0.0f ? -(il * il * il) / sqrtf(kz2) : 0.0f;
             gl += 6.28318530717958647692f * (g[e].y * Z.x - g[e].x * Z.y) * dkz;
         }
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_asm_accumulate_bwd(int W, int H, int B,
         const float fx = fftfreq(kx, W, inv_ndx), fy = fftfreq(ky, H, inv_ndy);
         const float wl = wavelengths[c];
         const float il = 1.0f / wl;
-        const float kz2 = il * il - fx * fx - fy * fy;
+        const float kz2 = fgs_kz2(il, fx, fy);
         const float kz = kz2 > 0.0f ? sqrtf(kz2) : 0.0f;
         // d kz / d lambda = -1 / (lambda^3 kz) where kz2 > 0, else 0 (clamp / evanescent)
         const float dkz = kz2 > 0.0f ? -(il * il * il) / kz : 0.0f;
@@ -1291,27 +1291,10 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
                            wavelengths, htab, p.col_logn ? H : 0, reinterpret_cast<float2 *>(sv + p.v_tw), pstride);
         FGS_LAUNCH_CHECK("k_asm_prep");
     }
-    const uint32_t *ranges_d = reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges);
-    // the column kernels skip the planes of an image that hold no Gaussian (their fields are zero, or -- row-fused build --
-    // were never written), as the reference skips them (DR:1302)
+    // the column kernels skip the planes of an image that hold no Gaussian (their fields are zero), as the reference
+    // skips them (DR:1302)
     const uint32_t *seg_off_d = reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off);
     fgs_stage_begin(ST_SPLAT_FWD, st);
-    if (p.rows_logw) {
-        // splat + row transform in one kernel: the plane fields never exist in HBM (fgs_asm_rows.h)
-#define FGS_SPLAT_ROWS(LW)                                                                                            \
-    hipLaunchKernelGGL((k_asm_splat_rows<LW>), dim3((unsigned)p.base.L.tiles_y, P, B), dim3(ROWS_NT), 0, st,          \
-                       (uint32_t)p.base.tiles, (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)H, ranges_d,        \
-                       seg_off_d, reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),                          \
-                       reinterpret_cast<const float *>(sv + p.base.L.rec), ccs, field)
-        switch (p.rows_logw) {
-            case 6: FGS_SPLAT_ROWS(6); break;
-            case 7: FGS_SPLAT_ROWS(7); break;
-            case 8: FGS_SPLAT_ROWS(8); break;
-            default: FGS_SPLAT_ROWS(9); break;
-        }
-#undef FGS_SPLAT_ROWS
-        FGS_LAUNCH_CHECK("k_asm_splat_rows");
-    } else {
 #define FGS_SPLAT_FWD(WV, NPV, DW)                                                                                     \
     hipLaunchKernelGGL((k_asm_splat<false, WV, NPV>), dim3(grid), dim3(64 * NPV), 0, st, (uint32_t)p.base.tiles,       \
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,                              \
@@ -1324,12 +1307,11 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     // one wave per list once the launch has enough lists to fill the chip, else four list parts per list
     if (grid >= ASM_ONE_WAVE_LISTS) FGS_SPLAT_FWD(false, 1, (float2 *)nullptr); else FGS_SPLAT_FWD(false, ASM_FWD_PARTS, (float2 *)nullptr);
     FGS_LAUNCH_CHECK("k_asm_splat");
-    }
     fgs_stage_end(ST_SPLAT_FWD, st);
     fgs_stage_begin(ST_FIELD_FWD, st);
     if (p.col_logn) {
-        // rows by rocFFT (unless fused with the splat), columns + transfer function + plane sum in one pass of our own (k_colfft_fwd)
-        if (!p.rows_logw && (rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
+        // rows by rocFFT, columns + transfer function + plane sum in one pass of our own (k_colfft_fwd)
+        if ((rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
         float2 *tw = reinterpret_cast<float2 *>(sv + p.v_tw);
         float2 *accp = reinterpret_cast<float2 *>(sc + p.c_accp);
         const int PG = p.col_pg;
@@ -1438,9 +1420,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     hipLaunchKernelGGL(k_asm_wavelength_grad, dim3(3), dim3(256), 0, st, nwl, pwl, g_wavelengths);
     FGS_LAUNCH_CHECK("k_asm_wavelength_grad");
     // adjoint of the forward FFT is the unnormalised inverse FFT
-    if (p.rows_logw) {
-        // (the inverse row transform runs inside the splat adjoint, below)
-    } else if (p.col_logn) {
+    if (p.col_logn) {
         if ((rc = fgs_fft_rows_exec(W, B * P * 3 * H, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
     } else if ((rc = fgs_fft_exec(H, W, B * P * 3, field, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) {
         return rc;
@@ -1449,23 +1429,6 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     fgs_stage_begin(ST_SPLAT_BWD, st);
     const uint32_t grid = (uint32_t)p.base.L.seg_capacity;  // depth-segment units
     float *rows = reinterpret_cast<float *>(sc + p.base.s_grows);
-    if (p.rows_logw) {
-#define FGS_ROWS_SPLAT_BWD(LW)                                                                                        \
-    hipLaunchKernelGGL((k_asm_rows_splat_bwd<LW>), dim3((unsigned)p.base.L.tiles_y, P, B), dim3(ROWS_NT), 0, st,      \
-                       (uint32_t)p.base.tiles, (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)H,                  \
-                       (uint32_t)p.base.L.dup_capacity, reinterpret_cast<const uint32_t *>(sv + p.base.L.ranges),     \
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.seg_off),                                     \
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_ids),                                     \
-                       reinterpret_cast<const float *>(sv + p.base.L.rec), reinterpret_cast<const float *>(sv + p.v_ccs), \
-                       reinterpret_cast<const uint32_t *>(sv + p.base.L.dup_off), field, rows)
-        switch (p.rows_logw) {
-            case 6: FGS_ROWS_SPLAT_BWD(6); break;
-            case 7: FGS_ROWS_SPLAT_BWD(7); break;
-            case 8: FGS_ROWS_SPLAT_BWD(8); break;
-            default: FGS_ROWS_SPLAT_BWD(9); break;
-        }
-#undef FGS_ROWS_SPLAT_BWD
-    } else
     hipLaunchKernelGGL((k_asm_splat<true, false, 1>), dim3(grid), dim3(64), 0, st, (uint32_t)p.base.tiles,
                        (uint32_t)p.base.L.tiles_x, (uint32_t)P, (uint32_t)W, (uint32_t)H,
                        (uint32_t)p.base.L.dup_capacity,

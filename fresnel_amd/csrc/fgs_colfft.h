@@ -81,8 +81,7 @@ __device__ __forceinline__ void oct_dit(float2 (&a)[8], float2 t1, float2 t2, fl
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // In-LDS FFT of TC independent lines of N = 2^LOGN points, element (point r, line col) = X(r, col) -- an accessor, so that
-// callers choose the LDS layout (plain x[N][TC] for the column transforms; a bank-swizzled one for the row transforms of
-// fgs_asm_rows.h); all NT threads of the block; tw = w_N^n, n < N/2, in LDS.
+// callers choose the LDS layout (plain x[N][TC] for the column transforms); all NT threads of the block; tw = w_N^n, n < N/2, in LDS.
 // INV = false: forward (e^-), decimation in frequency, natural order in, bit-reversed order out.  INV = true: inverse
 // (e^+), decimation in time, bit-reversed order in, natural order out.  Two radix-2 stages per pass over the data
 // (block sizes M and M/2), one more radix-2 pass when LOGN is odd.  (Consecutive lanes = the TC columns of a row, then

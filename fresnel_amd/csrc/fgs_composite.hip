@@ -640,6 +640,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6
             // into this duplicate's gradient row: no atomics, fixed order, bitwise reproducible ----
             {
                 const float vals[10] = {v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d};
+#ifdef FGS_WHATIF_HALF_REDUCTIONS
+                // TIMING EXPERIMENT ONLY (wrong gradients): what a reduction shared by two list entries could save AT MOST --
+                // every second entry's reduction and row store cost nothing (profiles/r04_ab_whatif_half_reductions.txt)
+                if (j & 1u) { asm volatile("" :: "v"(vals[0]), "v"(vals[1]), "v"(vals[2]), "v"(vals[3]), "v"(vals[4]), "v"(vals[5]), "v"(vals[6]), "v"(vals[7]), "v"(vals[8]), "v"(vals[9])); continue; }
+#endif
                 const float tot = wave_sum10_addtid(red, vals, lane);
                 const uint32_t kk = lane >> 2, e = she[j];
                 // (16-float rows: all sixteen quads' last lanes store, lanes >= 40 a zero -- one whole 64-byte line)
@@ -665,10 +670,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6
 //     restart.  Slot of group g of the scan block at list offset o: start / 8 + o / 8 + g + tile (g < 8: the capacity
 //     of fgs_make_plan is unchanged), plane w = A of sub-tile w, plane 4 + w = Phi.
 // bbox membership is a per-lane bit-and with masks from the staged column / row bits (v_bfe_i32), as on the blend path.
-struct PhaseRec {     // one compacted list entry in wave-private LDS
-    float4 a[64];     // u, v, conic a, conic b + c
-    float4 b[64];     // conic d, opacity, colour r, g
-    float4 c[64];     // colour b, depth, phase, pixel bits (bits 0-7: columns sx + i inside the bbox, 8-15: rows sy + i)
+#ifndef FGS_PHASE_SCAN
+#define FGS_PHASE_SCAN 64  /* list entries per scan block (a multiple of FGS_PHASE_CKPT, <= 64) */
+#endif
+#ifndef FGS_PHASE_PARK
+#define FGS_PHASE_PARK 0   /* 1: the backward's re-run also parks G and the interference factor of every entry (registers) */
+#endif
+static_assert(FGS_PHASE_SCAN <= 64 && FGS_PHASE_SCAN % FGS_PHASE_CKPT == 0, "scan block");
+struct PhaseRec {                 // one compacted list entry in wave-private LDS
+    float4 a[FGS_PHASE_SCAN];     // u, v, conic a, conic b + c
+    float4 b[FGS_PHASE_SCAN];     // conic d, opacity, colour r, g
+    float4 c[FGS_PHASE_SCAN];     // colour b, depth, phase, pixel bits (bits 0-7: columns sx + i inside the bbox, 8-15: rows sy + i)
 };
 
 // scan step shared by the two kernels: lane j < n looks at list entry base + j; returns the ballot of the entries that touch
@@ -723,11 +735,12 @@ __global__ __launch_bounds__(256) void k_phase_fwd(
     asm("" : "+v"(fpx), "+v"(fpy));  // hoisted for good: no v_cvt in the list loop
     float A = 0.0f, Ph = 0.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, Dm = 0.0f;
     const float base_amp = 1.0f - amp;
-    uint32_t gid_next = (c.start + lane < c.end) ? dup_ids[c.start + lane] : 0u;
-    for (uint32_t base = c.start; base < c.end; base += 64) {
+    constexpr uint32_t SCAN = FGS_PHASE_SCAN;
+    uint32_t gid_next = (lane < SCAN && c.start + lane < c.end) ? dup_ids[c.start + lane] : 0u;
+    for (uint32_t base = c.start; base < c.end; base += SCAN) {
         const uint32_t gid = gid_next;
-        const bool have = base + lane < c.end;
-        if (base + 64 + lane < c.end) gid_next = dup_ids[base + 64 + lane];  // the next block's ids travel under this one's work
+        const bool have = lane < SCAN && base + lane < c.end;
+        if (lane < SCAN && base + SCAN + lane < c.end) gid_next = dup_ids[base + SCAN + lane];  // the next block's ids travel under this one's work
         const unsigned long long touched = phase_scan<true>(st, nullptr, gid, have, sx, sy, c, rec, phase, nullptr);
         const uint32_t nt = (uint32_t)__popcll(touched);
         for (uint32_t j0 = 0; j0 < nt; j0 += PCK) {
@@ -788,7 +801,7 @@ __global__ __launch_bounds__(256) void k_phase_bwd(
     float *__restrict__ grad_rows) {
     constexpr int PCK = FGS_PHASE_CKPT;
     __shared__ PhaseRec st4[4];
-    __shared__ uint32_t rows4[4][64];
+    __shared__ uint32_t rows4[4][FGS_PHASE_SCAN];
     __shared__ __attribute__((aligned(16))) float red4[4][11 * FGS_RED_PITCH];  // reduction scratch, one per wave
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
     const uint32_t lane = threadIdx.x & 63u;
@@ -817,31 +830,38 @@ __global__ __launch_bounds__(256) void k_phase_bwd(
     }
     const float base_amp = 1.0f - amp;
     const uint32_t total = c.end - c.start;
-    const uint32_t nblocks = (total + 63u) / 64u;
+    constexpr uint32_t SCAN = FGS_PHASE_SCAN;
+    const uint32_t nblocks = (total + SCAN - 1u) / SCAN;
     uint32_t gid_next = 0u;
     if (nblocks) {
-        const uint32_t i = c.start + (nblocks - 1u) * 64u + lane;
-        if (i < c.end) gid_next = dup_ids[i];
+        const uint32_t i = c.start + (nblocks - 1u) * SCAN + lane;
+        if (lane < SCAN && i < c.end) gid_next = dup_ids[i];
     }
     for (uint32_t bi = nblocks; bi-- > 0;) {
-        const uint32_t base = c.start + bi * 64u;
+        const uint32_t base = c.start + bi * SCAN;
         const uint32_t gid = gid_next;
-        const bool have = base + lane < c.end;
-        if (bi) gid_next = dup_ids[base - 64u + lane];  // the block in front of this one: always full
+        const bool have = lane < SCAN && base + lane < c.end;
+        if (bi && lane < SCAN) gid_next = dup_ids[base - SCAN + lane];  // the block in front of this one: always full
         const unsigned long long touched = phase_scan<false>(st, rows, gid, have, sx, sy, c, rec, phase, dup_off);
         const uint32_t nt = (uint32_t)__popcll(touched);
         const uint32_t ngroups = (nt + PCK - 1) / PCK;
         for (uint32_t g = ngroups; g-- > 0;) {
             const uint32_t j0 = g * PCK;
             const uint32_t m = min((uint32_t)PCK, nt - j0);
-            const size_t slot = (size_t)(c.start / PCK) + (bi * 64u + j0) / PCK + c.tile;
+            const size_t slot = (size_t)(c.start / PCK) + (bi * SCAN + j0) / PCK + c.tile;
             const float *ck = phase_ckpt + slot * 512 + lane;
             float Af = ck[wave * 64], Pf = ck[(4 + wave) * 64];
             // ---- forward re-run of the group: park (A_{i-1}, Phi_{i-1}) ----
             float sA[PCK], sP[PCK];
+#if FGS_PHASE_PARK
+            float sG[PCK], sI[PCK];
+#endif
 #pragma unroll
             for (int k = 0; k < PCK; ++k) {
                 sA[k] = 0.0f; sP[k] = 0.0f;
+#if FGS_PHASE_PARK
+                sG[k] = 0.0f; sI[k] = 0.0f;
+#endif
                 if (k >= (int)m) continue;  // wave-uniform
                 const float4 q0 = st.a[j0 + k], q1 = st.b[j0 + k], q2 = st.c[j0 + k];
                 const uint32_t bits = __float_as_uint(q2.w);
@@ -849,12 +869,21 @@ __global__ __launch_bounds__(256) void k_phase_bwd(
                 sA[k] = Af; sP[k] = Pf;
                 const float dx = fpx - q0.x, dy = fpy - q0.y;
                 const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
+#if FGS_PHASE_PARK
+                const float Gk = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E)) & mk);
+                float pd = fabsf(q2.z - Pf);
+                pd = fminf(pd, 1.0f - pd);
+                const float Ik = base_amp + amp * phase_cos(pd * PHASE_KAPPA);
+                sG[k] = Gk; sI[k] = Ik;
+                const float alpha = __builtin_amdgcn_fmed3f((Gk * q1.y) * Ik, 0.0f, ALPHA_MAX);
+#else
                 float alpha = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E) * q1.y;
                 float pd = fabsf(q2.z - Pf);
                 pd = fminf(pd, 1.0f - pd);
                 alpha *= base_amp + amp * phase_cos(pd * PHASE_KAPPA);
                 alpha = __builtin_amdgcn_fmed3f(alpha, 0.0f, ALPHA_MAX);
                 alpha = __uint_as_float(__float_as_uint(alpha) & mk);
+#endif
                 const float w = alpha * (1.0f - Af);
                 Af += w;
                 const float pc = w / fmaxf(Af, 1e-6f);
@@ -874,10 +903,14 @@ __global__ __launch_bounds__(256) void k_phase_bwd(
                 const float dphi = ph - Pprev;
                 const float pd0 = fabsf(dphi);
                 const float pd = fminf(pd0, 1.0f - pd0);
-                const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
                 // G zeroed outside the bbox: raw, alpha, w, pc and every gradient term of this pixel then vanish by themselves
+#if FGS_PHASE_PARK
+                const float G = sG[k], inter = sI[k];
+#else
+                const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
                 const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E)) & mk);
                 const float inter = base_amp + amp * phase_cos(pd * PHASE_KAPPA);
+#endif
                 // (parking G and `inter` of the re-run instead of recomputing them costs 14 VGPRs = one wave per SIMD and
                 // was 7 % slower in round 2: this kernel lives on occupancy)
                 const float Gop = G * op, Gint = G * inter;

@@ -342,7 +342,11 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const float4 s1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
     const float4 s2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
     const float g_mean[2] = {s0.x, s0.y};
-    const float g_conic[3] = {s0.z, s0.w, s1.x};
+    // ASM / wave rows (k_asm_splat<BWD>) hold the MOMENTS of t = dL/da G about the mean -- slots 0-1 first, 2-4 second,
+    // 5 zeroth -- and the chain through a = G op, m is applied here: dL/dconic = -1/2 op (second moments)
+    const float op_asm = ASM ? rec[(size_t)idx * FGS_REC_FLOATS + R_OP] : 0.0f;
+    const float kcon = ASM ? -0.5f * op_asm : 1.0f;
+    const float g_conic[3] = {kcon * s0.z, kcon * s0.w, kcon * s1.x};
     float g_depth = s2.y;
     g_opacity[idx] = s1.y;
     if (!ASM) {
@@ -458,7 +462,12 @@ __global__ __launch_bounds__(256) void k_project_bwd(
             for (int j = 0; j < 3; ++j)
                 GJ[i][j] = (G2[i][0] * JSt[0][j] + G2[i][1] * JSt[1][j]) + (G2[0][i] * JS[0][j] + G2[1][i] * JS[1][j]);
         double gu = g_mean[0], gv = g_mean[1];
-        if (MODE == 0 && phase_channels) {
+        if (ASM) {
+            // dL/d(u, v) = -dL/dm (2 a dx + (b + c) dy, (b + c) dx + 2 d dy) summed = 1/2 op conic_sym (first moments)
+            const double h = 0.5 * (double)op_asm, cbc = Y[0][1] + Y[1][0];
+            gu = h * (2.0 * Y[0][0] * (double)g_mean[0] + cbc * (double)g_mean[1]);
+            gv = h * (cbc * (double)g_mean[0] + 2.0 * Y[1][1] * (double)g_mean[1]);
+        } else if (MODE == 0 && phase_channels) {
             // MODE 0 reuses `phase_channels` as a flag: slots 0/1 of the rows hold the first moments
             // M = sum dm' (dx, dy) in exp2 units (k_composite_bwd); dL/d(u,v) = -K conic_sym M, K = -log2(e)/2
             const double kc = 0.72134752044448170368, cbc = Y[0][1] + Y[1][0];
@@ -577,7 +586,8 @@ int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float 
                            reinterpret_cast<const uint32_t *>(saved + p.L.order),
                            reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                            reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                           g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u, nullptr);
+                           g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u,
+                           reinterpret_cast<const float *>(saved + p.L.rec));
         FGS_LAUNCH_CHECK("k_wave_project_bwd");
         return FGS_OK;
     }
@@ -587,7 +597,8 @@ int fgs_launch_asm_project_bwd(const FgsPlan &p, const float *cams, const float 
                        reinterpret_cast<const uint32_t *>(saved + p.L.order),
                        reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                        reinterpret_cast<const uint32_t *>(saved + p.L.tile_count), grad_rows, g_pos, g_scale,
-                       g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u, nullptr);
+                       g_quat, g_color, g_opacity, g_phase, color, phase, phase_channels, 1u,
+                       reinterpret_cast<const float *>(saved + p.L.rec));
     FGS_LAUNCH_CHECK("k_asm_project_bwd");
     return FGS_OK;
 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(RT) void k_prop_apply(int W, int H, int C, float in
     if (i >= HW * C) return;
     const int c = (int)(i / HW), kx = (int)(i % W), ky = (int)((i / W) % H);
     const float fx = fftfreq(kx, W, inv_ndx), fy = fftfreq(ky, H, inv_ndy), il = 1.0f / wl[c];
-    float kz2 = il * il - fx * fx - fy * fy;
+    float kz2 = fgs_kz2(il, fx, fy);
     if (band_limit) kz2 = kz2 < 0.0f ? 0.0f : kz2;
     const float theta = (6.28318530717958647692f * zp[0]) * sqrtf(kz2);  // NaN for evanescent waves without band limit, as torch
     float sn, cs;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(RT) void k_prop_apply_bwd(int W, int H, int C, floa
     for (size_t i = (size_t)blockIdx.x * RT + threadIdx.x; i < HW; i += (size_t)gridDim.x * RT) {
         const int kx = (int)(i % W), ky = (int)(i / W);
         const float fx = fftfreq(kx, W, inv_ndx), fy = fftfreq(ky, H, inv_ndy), lam = wl[c], il = 1.0f / lam;
-        const float raw = il * il - fx * fx - fy * fy;
+        const float raw = fgs_kz2(il, fx, fy);
         const float kz2 = (band_limit && raw < 0.0f) ? 0.0f : raw;
         const float kz = sqrtf(kz2), z = zp[0];
         float sn, cs;

@@ -35,7 +35,9 @@ extern "C" {
 #define FGS_SEG 128        /* largest depth segment: list entries per backward work unit; a call uses
                               FgsSavedLayout.seg_len (64 for small problems, else FGS_SEG)            */
 #define FGS_TUNE_AUTO 0    /* FgsDims.seg_len / fwd_variant / bin_mode: let the library choose        */
+#ifndef FGS_PHASE_CKPT
 #define FGS_PHASE_CKPT 8   /* phase path: entries of a sub-tile's (compacted) list between (A, Phi) checkpoints */
+#endif
 #define FGS_CAMERA_FLOATS 24
 
 /* Problem shape.  Mirrors TileBasedRenderer.__init__ (DR:434-450). */

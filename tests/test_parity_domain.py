@@ -157,6 +157,7 @@ def test_asm_oracle_vs_asm_kink_cases(case):
         if k == "phases" and len(g["positions"]) == 1:
             continue  # one Gaussian: its phase is a global phase, the true gradient is 0 (noise / noise)
         assert_with_referee(r["grad_" + k], g["f32_grad_" + k], g["f64_grad_" + k], k)
+    assert_with_referee(r["grad_wavelengths"], g["f32_grad_wavelengths"], g["f64_grad_wavelengths"], "wavelengths")
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -242,3 +243,4 @@ def test_hip_vs_asm_kink_cases(case):
         if k == "phases" and len(g["positions"]) == 1:
             continue
         assert_with_referee(out["grad_" + k], g["f32_grad_" + k], g["f64_grad_" + k], k)
+    assert_with_referee(out["grad_wavelengths"], g["f32_grad_wavelengths"], g["f64_grad_wavelengths"], "wavelengths")
