@@ -49,7 +49,10 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
                           uint32_t **vals_sorted, uint32_t seg_len, const uint32_t *seg_len_dev,
                           uint32_t seg_capacity, uint32_t seg_stride, uint32_t num_segs, uint32_t key_bits,
                           uint32_t *hist, hipStream_t st, const uint32_t *keys_first = nullptr,
-                          uint32_t index_payload_mod = 0);
+                          uint32_t index_payload_mod = 0,
+                          const uint32_t *key_stats = nullptr /* depth sort: k_project's per-block OR / AND of the visible keys:
+                                                                 sort by the bits that vary, skip the passes nobody needs */,
+                          uint32_t key_recs = 0 /* records per segment */);
 
 int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t st);
 

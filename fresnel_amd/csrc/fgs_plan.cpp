@@ -88,6 +88,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     if (d->use_phase) o = align256(o + (dcap / FGS_PHASE_CKPT + B * p->tiles + 2) * 8 * 64 * 4);
     p->s_layer = o;
     if (layers > 1) o = align256(o + B * N * 4);
+    p->s_keybits = o; o = align256(o + B * ((N + 255) / 256) * 4 * 4);
     // ---- tuning: a pure function of the dims (no environment, so a forward and its backward always agree) ----
     // Forward work split.  Blend path: depth-split forward with 4 list parts per tile, 1 part once the launch has
     // enough tiles to fill the chip several times over (fwd ms, 8 images x 1024 tiles: row-split 0.642, 2 parts

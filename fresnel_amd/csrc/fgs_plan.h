@@ -27,6 +27,8 @@ struct FgsPlan {
     FgsSavedLayout L;
     int32_t layers;           // independent tile grids per image (ASM depth planes; 1 for TBR)
     size_t s_layer;           // saved: uint32 [B][N] layer of each Gaussian (layers > 1 only)
+    size_t s_keybits;         // saved: uint32 [B][ceil(N / 256)][4]: per projection block, OR / AND of the visible depth keys and
+                              // the visible / culled flags (k_project -> the depth sort's choice of radix passes, fgs_sort.hip)
     int32_t tile_w;           // tile width in pixels: 16, or 32 on the blend path (FgsDims.tile_w / automatic)
     int32_t tiles;            // tiles per image
     int32_t tiles_per_gauss;  // worst-case tiles touched by one Gaussian

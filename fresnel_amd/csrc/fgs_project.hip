@@ -90,10 +90,14 @@ __global__ __launch_bounds__(256) void k_project(
     const float *__restrict__ cams, const float *__restrict__ pos, const float *__restrict__ scale,
     const float *__restrict__ quat, const float *__restrict__ color, const float *__restrict__ opacity,
     float *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ tile_count,
-    uint32_t *__restrict__ layer, int32_t num_planes, float plane_near, float plane_far, int32_t tile_w) {
-    const int32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int32_t b = idx / N;
+    uint32_t *__restrict__ layer, int32_t num_planes, float plane_near, float plane_far, int32_t tile_w,
+    uint32_t *__restrict__ key_bits) {
+    // grid (blocks per image, B): a block never straddles two images, so that its share of the image's key statistics
+    // (below) is one record
+    const int32_t n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    uint32_t key = 0xFFFFFFFFu;
+    if (n < N) {
+    const int32_t idx = b * N + n;
     const float *__restrict__ cam = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
     const float p[3] = {pos[3 * idx], pos[3 * idx + 1], pos[3 * idx + 2]};
     const float s[3] = {scale[3 * idx], scale[3 * idx + 1], scale[3 * idx + 2]};
@@ -139,7 +143,8 @@ __global__ __launch_bounds__(256) void k_project(
     out[1] = make_float4(id, opacity[idx], color[3 * idx], color[3 * idx + 1]);
     out[2] = make_float4(color[3 * idx + 2], o.dep, __uint_as_float((uint32_t)x0 | ((uint32_t)x1 << 16)),
                          __uint_as_float((uint32_t)y0 | ((uint32_t)y1 << 16)));
-    depth_key[idx] = vis ? fgs_float_key(o.dep) : 0xFFFFFFFFu;
+    key = vis ? fgs_float_key(o.dep) : 0xFFFFFFFFu;
+    depth_key[idx] = key;
     tile_count[idx] = ntiles;
     if (layer) {
         // nearest depth plane, DR:1106 (torch.linspace) + DR:1147-1148 (first argmin of |depth - plane|)
@@ -153,6 +158,28 @@ __global__ __launch_bounds__(256) void k_project(
             if (dd < bd) { bd = dd; best = k; }
         }
         layer[idx] = (uint32_t)best;
+    }
+    }
+    // Which bits of the depth keys VARY over an image's visible Gaussians decides how many radix passes its depth sort needs
+    // (fgs_sort.hip: the keys are compressed to those bits -- zone-snapped depths, BASELINE config 4, differ in 3 bits and sort
+    // in one pass instead of four).  Per block: OR and AND of the visible keys and the visible / culled flags, three words;
+    // every block of the sort folds the <= N / 256 records of its image.  No atomics, no extra launch.
+    {
+        const bool visk = key != 0xFFFFFFFFu;
+        uint32_t vor = visk ? key : 0u, vand = key;  // (a culled key is all ones: neutral for the AND)
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { vor |= __shfl_xor(vor, o2, 64); vand &= __shfl_xor(vand, o2, 64); }
+        const uint32_t fl = (__ballot(visk) != 0ull ? 2u : 0u) | (__ballot(n < N && !visk) != 0ull ? 1u : 0u);
+        __shared__ uint32_t wv[4][3];
+        const uint32_t wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63u) == 0) { wv[wave][0] = vor; wv[wave][1] = vand; wv[wave][2] = fl; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t *o3 = key_bits + ((size_t)b * gridDim.x + blockIdx.x) * 4;
+            o3[0] = (wv[0][0] | wv[1][0]) | (wv[2][0] | wv[3][0]);
+            o3[1] = (wv[0][1] & wv[1][1]) & (wv[2][1] & wv[3][1]);
+            o3[2] = (wv[0][2] | wv[1][2]) | (wv[2][2] | wv[3][2]);
+        }
     }
 }
 
@@ -528,14 +555,14 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
                        const float *quat, const float *color, const float *opacity, char *saved,
                        hipStream_t st, int num_planes, float plane_near, float plane_far) {
     const int32_t total = p.d.batch * p.d.num_gaussians;
-    const int grid = (total + 255) / 256;
-    hipLaunchKernelGGL(k_project, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians, p.d.width,
+    const dim3 grid((unsigned)((p.d.num_gaussians + 255) / 256), (unsigned)p.d.batch);
+    hipLaunchKernelGGL(k_project, grid, dim3(256), 0, st, total, p.d.num_gaussians, p.d.width,
                        p.d.height, p.d.num_cameras, p.d.max_radius, cams, pos, scale, quat, color, opacity,
                        reinterpret_cast<float *>(saved + p.L.rec),
                        reinterpret_cast<uint32_t *>(saved + p.L.depth_key),
                        reinterpret_cast<uint32_t *>(saved + p.L.tile_count),
                        num_planes > 1 ? reinterpret_cast<uint32_t *>(saved + p.s_layer) : nullptr, num_planes,  // one plane: layer 0
-                       plane_near, plane_far, p.tile_w);
+                       plane_near, plane_far, p.tile_w, reinterpret_cast<uint32_t *>(saved + p.s_keybits));
     FGS_LAUNCH_CHECK("k_project");
     return FGS_OK;
 }

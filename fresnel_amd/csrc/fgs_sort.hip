@@ -15,6 +15,17 @@
 // comes from wave64 ballots: 8 ballots give the mask of lanes holding the same digit,
 // popcount below the lane gives the stable rank -- no atomics, no order dependence).
 // HBM-bound: 8 B read in upsweep+downsweep and 8 B written per element per pass.
+//
+// KEY COMPRESSION (depth sort only, round 4; BASELINE config 4's "depth-zone sort keys").  Only the key bits that VARY over a
+// segment's visible Gaussians can change their order.  k_project leaves, per block, the OR and the AND of the visible keys;
+// every block of the sort folds its segment's records into the mask m = OR ^ AND and sorts by the COMPRESSED key
+//     pext(key, m)  for a visible Gaussian,    1 << popcount(m)  for a culled one (key 0xFFFFFFFF: behind all visible ones),
+// 8 bits per pass -- order-preserving among the visible keys (the dropped bits are equal in all of them), culled ones last
+// and among themselves in index order (stable), i.e. the SAME permutation as sorting the full keys.  A segment needs
+// ceil((popcount(m) + [any culled]) / 8) passes; the blocks of the later passes leave at once, and the last LIVE pass of a
+// segment writes the payload to its final place.  Zone-snapped depths (8 zones: 3 varying bits) sort in ONE pass instead of
+// four; ordinary depths in (0.5, 4) vary in ~25 bits and keep their four.  All 8 launches still happen (how many passes a
+// segment needs is known on the device only) -- a dead pass costs a launch of blocks that read ~100 words and exit.
 #include <type_traits>
 #include "fgs_internal.h"
 
@@ -41,10 +52,77 @@ __device__ __forceinline__ SegInfo block_range(uint32_t seg_len, const uint32_t 
     return {seg0 + b, seg0 + e};
 }
 
+
+// ---- key compression (see the header) ------------------------------------------------------------------------------------
+struct KeyPlan {
+    uint32_t live;      // passes this segment needs (>= 1)
+    uint32_t sh[8];     // source bit of digit bit i of the current pass
+    uint32_t vmask;     // digit bits that exist in this pass
+    uint32_t cull;      // digit of a culled key in this pass
+};
+
+// every thread of the block returns the plan of (segment, pass); `kb` = 12 + 12 words of LDS
+__device__ __forceinline__ KeyPlan key_plan(const uint32_t *__restrict__ bits, uint32_t nrec, uint32_t seg, uint32_t pass,
+                                            uint32_t *kb) {
+    uint32_t vor = 0u, vand = 0xFFFFFFFFu, fl = 0u;
+    for (uint32_t i = threadIdx.x; i < nrec; i += RS_THREADS) {
+        const uint4 r = reinterpret_cast<const uint4 *>(bits)[(size_t)seg * nrec + i];
+        vor |= r.x; vand &= r.y; fl |= r.z;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vor |= __shfl_xor(vor, o, 64); vand &= __shfl_xor(vand, o, 64); fl |= __shfl_xor(fl, o, 64); }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) { kb[3 * wave] = vor; kb[3 * wave + 1] = vand; kb[3 * wave + 2] = fl; }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        uint32_t o = 0u, a = 0xFFFFFFFFu, f = 0u;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) { o |= kb[3 * w]; a &= kb[3 * w + 1]; f |= kb[3 * w + 2]; }
+        const uint32_t m = (f & 2u) ? (o ^ a) : 0u;  // no visible key: nothing varies
+        const uint32_t nbits = (uint32_t)__popc(m), cull = f & 1u;
+        const uint32_t idx = 8u * pass + threadIdx.x;
+        uint32_t mm = m;
+        for (uint32_t j = 0; j < idx && mm; ++j) mm &= mm - 1u;
+        kb[12 + threadIdx.x] = (idx < nbits) ? (uint32_t)__ffs((int)mm) - 1u : 32u;
+        if (threadIdx.x == 0) {
+            const uint32_t need = (nbits + cull + 7u) / 8u;
+            kb[20] = need ? need : 1u;
+            kb[21] = (cull && nbits >= 8u * pass && nbits < 8u * pass + 8u) ? 1u << (nbits - 8u * pass) : 0u;
+        }
+    }
+    __syncthreads();
+    KeyPlan kp;
+    kp.live = kb[20];
+    kp.cull = kb[21];
+    kp.vmask = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t p = kb[12 + i];
+        kp.sh[i] = p & 31u;
+        kp.vmask |= (p < 32u ? 1u : 0u) << i;
+    }
+    return kp;
+}
+
+__device__ __forceinline__ uint32_t key_digit(const KeyPlan &kp, uint32_t key) {
+    uint32_t d = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d |= ((key >> kp.sh[i]) & 1u) << i;
+    return key == 0xFFFFFFFFu ? kp.cull : (d & kp.vmask);
+}
+
+template <bool COMPRESSED>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(
     const uint32_t *__restrict__ keys, uint32_t seg_len, const uint32_t *__restrict__ seg_len_dev,
-    uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift, uint32_t dmask, uint32_t *__restrict__ hist) {
+    uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift, uint32_t dmask, uint32_t *__restrict__ hist,
+    const uint32_t *__restrict__ key_bits, uint32_t key_recs, uint32_t pass) {
     __shared__ uint32_t h[256];
+    __shared__ uint32_t kb[24];
+    KeyPlan kp;
+    if (COMPRESSED) {
+        kp = key_plan(key_bits, key_recs, blockIdx.y, pass, kb);
+        if (pass >= kp.live) return;  // this segment is sorted already
+    }
     h[threadIdx.x] = 0;
     __syncthreads();
     const SegInfo r = block_range(seg_len, seg_len_dev, seg_capacity, seg_stride);
@@ -54,7 +132,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(
         for (int u = 0; u < 4; ++u) k[u] = i + u * RS_THREADS < r.end ? keys[i + u * RS_THREADS] : 0u;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i + u * RS_THREADS < r.end) atomicAdd(&h[(k[u] >> shift) & dmask], 1u);
+            if (i + u * RS_THREADS < r.end) atomicAdd(&h[COMPRESSED ? key_digit(kp, k[u]) : (k[u] >> shift) & dmask], 1u);
     }
     __syncthreads();
     // layout: hist[(seg*256 + digit) * bps + blk]
@@ -84,11 +162,13 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *__restrict__ hist,
     if (lane == 0) dtot[row] = carry;
 }
 
+template <bool COMPRESSED>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t seg_len,
     const uint32_t *__restrict__ seg_len_dev, uint32_t seg_capacity, uint32_t seg_stride, uint32_t shift,
-    uint32_t dmask, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ dtot, uint32_t idx_mod) {
+    uint32_t dmask, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ dtot, uint32_t idx_mod,
+    const uint32_t *__restrict__ key_bits, uint32_t key_recs, uint32_t pass, uint32_t *__restrict__ vals_final) {
     // dtot == nullptr: `hist` holds the RAW per-block digit counts and this block forms its own prefix (sum over the
     // blocks before it, total over all of them) -- no k_radix_scan launch; used when a segment has few blocks (the
     // depth sort, every launch of which sits at the launch floor).
@@ -100,6 +180,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
     __shared__ uint32_t wcnt[RS_WAVES][256];
     __shared__ uint32_t wtot[RS_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint32_t kb[24];
+    KeyPlan kp;
+    if (COMPRESSED) {
+        kp = key_plan(key_bits, key_recs, blockIdx.y, pass, kb);
+        if (pass >= kp.live) return;                        // this segment is sorted already
+        if (pass + 1u == kp.live) vals_out = vals_final;    // its last live pass: the payload goes to its final place
+    }
     const SegInfo r = block_range(seg_len, seg_len_dev, seg_capacity, seg_stride);
     const uint32_t seg0 = blockIdx.y * seg_stride;
     constexpr uint32_t ROUND = RS_THREADS * 4;
@@ -180,10 +267,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
     // order, so read-count-then-bump needs no barrier); one block barrier per round then turns the four waves'
     // counts into global positions.
     for (uint32_t base = r.begin; base < r.end; base += ROUND) {
-        uint32_t lrank[4];
+        uint32_t lrank[4], dig[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const uint32_t digit = (key[it] >> shift) & dmask;
+            const uint32_t digit = COMPRESSED ? key_digit(kp, key[it]) : (key[it] >> shift) & dmask;
+            dig[it] = digit;
             unsigned long long m = __ballot(valid[it]);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
@@ -202,7 +290,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             if (valid[it]) {
-                const uint32_t digit = (key[it] >> shift) & dmask;
+                const uint32_t digit = dig[it];
                 uint32_t pre = 0;
 #pragma unroll
                 for (int w = 0; w < RS_WAVES; ++w) pre += (w < (int)wave) ? wcnt[w][digit] : 0u;
@@ -234,8 +322,15 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
                           uint32_t *vals_final, uint32_t **keys_sorted, uint32_t **vals_sorted,
                           uint32_t seg_len, const uint32_t *seg_len_dev, uint32_t seg_capacity,
                           uint32_t seg_stride, uint32_t num_segs, uint32_t key_bits, uint32_t *hist,
-                          hipStream_t st, const uint32_t *keys_first, uint32_t index_payload_mod) {
+                          hipStream_t st, const uint32_t *keys_first, uint32_t index_payload_mod,
+                          const uint32_t *key_stats, uint32_t key_recs) {
     const uint32_t bps = fgs_radix_blocks_per_seg(seg_capacity, num_segs);
+    // key compression (depth sort): full 32-bit keys read from keys_first, the index as payload, a final place for the payload
+    const bool compressed = key_stats != nullptr;
+    if (compressed && !(keys_first && index_payload_mod && vals_final && key_recs && !seg_len_dev && key_bits == 32u)) {
+        fgs_set_error("radix sort: key compression needs 32-bit keys in keys_first, an index payload and vals_final");
+        return FGS_EINVAL;
+    }
     uint32_t *dtot = hist + (size_t)num_segs * 256 * bps;
     const uint32_t passes = (key_bits + 7) / 8;
     // equal digit widths over the passes (13 key bits -> 7 + 6, not 8 + 5): fewer bins per pass means longer
@@ -263,8 +358,12 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
         uint32_t *vdst = (p == passes - 1 && vals_final) ? vals_final : (vin == vals_in ? vals_alt : vals_in);
         if (p == 0 && index_payload_mod && !(passes == 1 && vals_final)) vdst = vals_in;  // vals_in is free: nothing to read
         const dim3 grid(bps, num_segs);
-        hipLaunchKernelGGL(k_radix_upsweep, grid, dim3(RS_THREADS), 0, st, kin, seg_len, seg_len_dev,
-                           seg_capacity, seg_stride, p * width, dmask_of(p, width, key_bits), hist);
+        if (compressed)
+            hipLaunchKernelGGL(k_radix_upsweep<true>, grid, dim3(RS_THREADS), 0, st, kin, seg_len, seg_len_dev, seg_capacity,
+                               seg_stride, 0u, 0u, hist, key_stats, key_recs, p);
+        else
+            hipLaunchKernelGGL(k_radix_upsweep<false>, grid, dim3(RS_THREADS), 0, st, kin, seg_len, seg_len_dev, seg_capacity,
+                               seg_stride, p * width, dmask_of(p, width, key_bits), hist, (const uint32_t *)nullptr, 0u, p);
         FGS_LAUNCH_CHECK("k_radix_upsweep");
         const uint32_t rows = num_segs * 256;
         if (!fused_scan) {
@@ -272,9 +371,15 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
             FGS_LAUNCH_CHECK("k_radix_scan");
         }
         const uint32_t *vsrc = (p == 0 && index_payload_mod) ? nullptr : vin;
-        hipLaunchKernelGGL(k_radix_downsweep, grid, dim3(RS_THREADS), 0, st, kin, vsrc, kout, vdst, seg_len,
-                           seg_len_dev, seg_capacity, seg_stride, p * width, dmask_of(p, width, key_bits), hist,
-                           fused_scan ? (const uint32_t *)nullptr : dtot, index_payload_mod ? index_payload_mod : 1u);
+        if (compressed)
+            hipLaunchKernelGGL(k_radix_downsweep<true>, grid, dim3(RS_THREADS), 0, st, kin, vsrc, kout, vdst, seg_len, seg_len_dev,
+                               seg_capacity, seg_stride, 0u, 0u, hist, fused_scan ? (const uint32_t *)nullptr : dtot,
+                               index_payload_mod, key_stats, key_recs, p, vals_final);
+        else
+            hipLaunchKernelGGL(k_radix_downsweep<false>, grid, dim3(RS_THREADS), 0, st, kin, vsrc, kout, vdst, seg_len, seg_len_dev,
+                               seg_capacity, seg_stride, p * width, dmask_of(p, width, key_bits), hist,
+                               fused_scan ? (const uint32_t *)nullptr : dtot, index_payload_mod ? index_payload_mod : 1u,
+                               (const uint32_t *)nullptr, 0u, p, (uint32_t *)nullptr);
         FGS_LAUNCH_CHECK("k_radix_downsweep");
         // ping-pong: the buffer just read becomes the next output, except a read-only first-pass source
         uint32_t *next_out = (p == 0 && keys_first) ? kspare : const_cast<uint32_t *>(kin);

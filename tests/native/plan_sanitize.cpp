@@ -36,6 +36,9 @@ static void check_plan(const FgsDims &d, int layers, bool ckpt) {
         prev = secs[i];
     }
     CHECK(L.seg_off <= L.seg_tile && L.seg_tile <= L.seg_ckpt && L.seg_ckpt <= L.total_bytes, "segments");
+    // k_project's key statistics: 16 bytes per block of 256 Gaussians and image, between the layer ids and the segment tables
+    CHECK(p.s_keybits % 256 == 0 && p.s_keybits >= p.s_layer && p.s_keybits >= L.phase_ckpt &&
+          p.s_keybits + (size_t)d.batch * ((d.num_gaussians + 255) / 256) * 16 <= L.seg_off, "key statistics");
     CHECK(L.tile_w == 16 || L.tile_w == 32, "tile_w=%d", L.tile_w);
     CHECK(L.tiles_x == (d.width + L.tile_w - 1) / L.tile_w && L.tiles_y == (d.height + 15) / 16, "tile grid");
     CHECK(p.tiles == L.tiles_x * L.tiles_y, "tiles");

@@ -671,6 +671,57 @@ def test_forward_variants_agree(use_phase):
             assert rel_to_max(o["grad_" + k], go[k]) <= TOL, (t, k)
 
 
+@pytest.mark.parametrize("N", [1000, 8192, 33000])
+def test_depth_sort_key_compression_gives_the_full_key_order(N):
+    """Round 4 (BASELINE config 4, "depth-zone sort keys"): the depth sort keeps only the key bits that vary over an image's
+    visible Gaussians and runs as many 8-bit passes as those need.  Whatever the depths look like, `order` must be the stable
+    argsort of the FULL keys (culled keys = 0xFFFFFFFF last, in index order).  One batch, one image of each kind:
+      0  zone-snapped depths (8 values: 3 varying bits, ONE live pass), some Gaussians culled;
+      1  ordinary depths (~25 varying bits: all four passes);
+      2  every Gaussian behind the camera (all culled: nothing varies, the payload is copied by the forced pass);
+      3  one single depth, nothing culled (no varying bit, no culled bit);
+      4  two depths that differ in ONE low mantissa bit + culled ones (2 bits: one pass);
+      5  depths that differ in the exponent byte and the low byte only (16 varying bits in two separate bytes).
+    N = 1000 / 33000: segments that are not whole projection blocks (key statistics) or whole sort rounds."""
+    from fresnel_amd.renderer import Camera
+    S = 128
+    rs = np.random.RandomState(N)
+    per = []
+    for img in range(6):
+        pos, scale, quat, col, opa = [a.copy() for a in synth_saag(N, 300 + img)]
+        pos[:, :2] *= 0.3
+        if img == 0:
+            pos[:, 2] = -2.0 - 2.0 * (rs.randint(0, 8, N) + 0.5) / 8.0
+            pos[rs.rand(N) < 0.05, 0] = 50.0            # far off-screen: culled
+        elif img == 2:
+            pos[:, 2] = 3.0
+        elif img == 3:
+            pos[:, 2] = -2.5
+        elif img == 4:
+            z = np.full(N, -2.5, np.float32)
+            z[rs.rand(N) < 0.5] = np.nextafter(np.float32(-2.5), np.float32(-3.0))
+            pos[:, 2] = z
+            pos[rs.rand(N) < 0.1, 1] = -60.0
+        elif img == 5:
+            base = np.array([0.75, 1.5, 3.0, 6.0], np.float32)[rs.randint(0, 4, N)]
+            low = rs.randint(0, 256, N).astype(np.uint32)
+            pos[:, 2] = -(base.view(np.uint32) | low).view(np.float32)
+        per.append((pos, scale * 0.2, quat, col, opa))
+    arrs = [np.stack([p[i] for p in per]) for i in range(5)]
+    st = _hip_stages(arrs, Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S), S, S)
+    keys = st["depth_key"].view(np.uint32)
+    kinds = []
+    for b in range(6):
+        want = np.argsort(keys[b], kind="stable")
+        assert np.array_equal(st["order"][b], want.astype(np.int32)), f"image {b}: order is not the stable argsort of the keys"
+        vis = keys[b] != 0xFFFFFFFF
+        m = (np.bitwise_or.reduce(keys[b][vis]) ^ np.bitwise_and.reduce(keys[b][vis])) if vis.any() else 0
+        kinds.append((bin(int(m)).count("1"), int((~vis).sum())))
+    # the scenes are what the docstring says they are: (varying bits, culled) per image
+    assert kinds[0][0] == 3 and kinds[0][1] > 0 and kinds[1][0] >= 20 and kinds[2] == (0, N) and kinds[3] == (0, 0)
+    assert kinds[4][0] == 1 and kinds[4][1] > 0 and kinds[5][0] >= 9
+
+
 def test_needle_and_disc_gaussians_keep_the_alpha_clamp():
     """Needles and edge-on discs (scale ratio 300:1) make the regularised 2x2 inverse covariance ill-conditioned;
     where it comes out indefinite in fp32, G = exp(-m/2) exceeds 1 and alpha = min(G op, 0.99) binds even for small

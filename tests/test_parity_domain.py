@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (assert_with_referee, load_golden, oracle_camera, referee, rel_to_max, upstream_grads)
+from helpers import (assert_with_referee, load_golden, oracle_camera, referee, referee_tolerance, rel_to_max, upstream_grads)
 
 NAMES = ["positions", "scales", "rotations", "colors", "opacities"]
 G14 = ["G14_needles_r30_96", "G14_needles_r100_96", "G14_needles_r500_96"]
@@ -244,3 +244,76 @@ def test_hip_vs_asm_kink_cases(case):
             continue
         assert_with_referee(out["grad_" + k], g["f32_grad_" + k], g["f64_grad_" + k], k)
     assert_with_referee(out["grad_wavelengths"], g["f32_grad_wavelengths"], g["f64_grad_wavelengths"], "wavelengths")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# G16: ONE image of BASELINE config 5 AS BENCHMARKED (8 192 Gaussians @512x512, 16 planes, per-channel wavelengths) through the
+# reference's ASMWaveFieldRenderer in fp32 and fp64: image rows 0::16, the gradients of every 8th Gaussian,
+# dL/dlambda.  The reference's fp32 dL/dlambda is NaN for lambda = 0.05 (frequencies exactly on the evanescent boundary); its
+# fp64 run referees all three channels.
+# ------------------------------------------------------------------------------------------------------------------
+def _g16_scene(g):
+    from helpers import synth_saag
+    N, seed = int(g["num_gaussians"]), int(g["seed"])
+    arrs = list(synth_saag(N, seed))
+    phases = (np.random.RandomState(seed + 1).random_sample(N) * 2 * np.pi).astype(np.float32)
+    S = int(g["size"][0])
+    gI, _ = upstream_grads(int(g["seed_up"]), S, S)
+    return arrs, phases, gI, S
+
+
+def _g16_check(out_image, out_grads, g, b=None):
+    """`out_*`: the scene's image (3,H,W) and gradient dict, as rendered alone or as image b of a batch."""
+    st = int(g["grad_stride"])
+    assert_with_referee(out_image[:, ::16], g["f32_image"], g["f64_image"], "image rows")
+    for k in NAMES + ["phases"]:
+        # (tolerances are relative to the FULL tensor's max, stored next to the subsampled gradient)
+        m32, m64 = float(g["f32_gradmax_" + k]), float(g["f64_gradmax_" + k])
+        got, r32, r64 = out_grads[k][::st], g["f32_grad_" + k], g["f64_grad_" + k]
+        if m64 == 0.0:  # rotations: isotropic scales make the covariance independent of the quaternion -- exactly zero gradients
+            assert m32 == 0.0 and float(np.abs(out_grads[k]).max()) <= 1e-12, k
+            continue
+        spread = float(np.abs(r32 - r64).max() / m64)
+        use64, tol = referee_tolerance(spread)
+        err = float(np.abs(got - r64).max() / m64) if use64 else float(np.abs(got - r32).max() / m32)
+        assert err <= tol, f"G16 {k}: {err:.2e} > {tol:.2e} (reference fp32-vs-fp64 spread {spread:.1e})"
+
+
+def test_oracle_forward_vs_g16_config5_image():
+    """CPU: the oracle's forward on the G16 scene (no autograd: its per-Gaussian graph at this size is tens of GB) against the
+    reference's image rows."""
+    from oracle import asm_oracle, fgs_oracle as orc
+    g = load_golden("G16_config5_image_512")
+    arrs, phases, _, S = _g16_scene(g)
+    cam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+    r = asm_oracle.render(*arrs, phases, g["wavelengths"], cam)
+    assert np.abs(r["image"][:, ::16] - g["f32_image"]).max() <= 1e-5
+    assert len(np.unique(r["plane_idx"])) >= 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 8])
+def test_hip_vs_g16_config5_image(batch):
+    """The benchmark's own config-5 launches (bench.py --workload config5: one image; --images-per-gpu 8: eight) with the G16
+    scene as image 0 of 1 / image 3 of 8: image and every gradient against the reference itself, dL/dlambda (one image: the
+    wavelengths are shared by a batch) against its fp64 run."""
+    from helpers import synth_saag
+    from test_hip_asm import _assert_wavelength_grad, _hip_asm
+    from fresnel_amd.renderer import Camera
+    g = load_golden("G16_config5_image_512")
+    arrs, phases, gI, S = _g16_scene(g)
+    slot = 0 if batch == 1 else 3
+    rs = np.random.RandomState(1616)
+    per = [list(synth_saag(len(phases), 1700 + b)) for b in range(batch)]
+    per[slot] = arrs
+    barrs = [np.stack([p[i] for p in per]) for i in range(5)]
+    bph = (rs.random_sample((batch, len(phases))) * 2 * np.pi).astype(np.float32)
+    bph[slot] = phases
+    bgI = rs.standard_normal((batch, 3, S, S)).astype(np.float32)
+    bgI[slot] = gI
+    cam = Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
+    out = _hip_asm(barrs, bph, g["wavelengths"], cam, S, S, (0.0, 0.0, 0.0), gI=bgI)
+    _g16_check(out["image"][slot], {k: out["grad_" + k][slot] for k in NAMES + ["phases"]}, g)
+    if batch == 1:
+        _assert_wavelength_grad(out["grad_wavelengths"], g["f64_grad_wavelengths"], "G16 vs the reference in fp64")
+        _assert_wavelength_grad(out["grad_wavelengths"], g["f32_grad_wavelengths"], "G16 vs the reference in fp32 (finite channels)")
