@@ -507,6 +507,8 @@ def main(argv=None):
                                   saturation_skip=args.saturation_skip).to(device)
         if args.tuning:
             ren.tuning = {k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))}
+        elif args.workload == "config4":
+            ren.tuning = dict(sort_mode=1)  # --use_fresnel_zones 8: depths snapped to zone centres -> zone-key depth sort (fgs_sort.hip)
     g = torch.Generator().manual_seed(4242 + rank)
     gI = torch.randn(per_gpu, 3, S, S, generator=g).to(device)
     gD = (torch.randn(per_gpu, S, S, generator=g) * 0.1).to(device)

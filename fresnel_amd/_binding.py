@@ -35,7 +35,7 @@ class FgsDims(ctypes.Structure):
                 ("use_phase", ctypes.c_int32), ("phase_amplitude", ctypes.c_float),
                 ("num_cameras", ctypes.c_int32), ("saturation_skip", ctypes.c_int32),
                 ("seg_len", ctypes.c_int32), ("fwd_variant", ctypes.c_int32), ("bin_mode", ctypes.c_int32),
-                ("tile_w", ctypes.c_int32)]
+                ("tile_w", ctypes.c_int32), ("sort_mode", ctypes.c_int32)]
 
 
 class FgsSavedLayout(ctypes.Structure):
@@ -147,7 +147,7 @@ def check(rc, what):
 
 def make_dims(batch, num_gaussians, width, height, max_radius=64.0, background=(0.0, 0.0, 0.0),
               use_phase=False, phase_amplitude=0.25, num_cameras=1, saturation_skip=False, tuning=None):
-    """`tuning`: optional dict of FgsDims overrides {seg_len, fwd_variant, bin_mode} (0 / absent = automatic)."""
+    """`tuning`: optional dict of FgsDims overrides {seg_len, fwd_variant, bin_mode, tile_w, sort_mode} (0 / absent = automatic)."""
     d = FgsDims()
     d.batch, d.num_gaussians, d.width, d.height = int(batch), int(num_gaussians), int(width), int(height)
     d.max_radius = float(max_radius)
@@ -158,7 +158,7 @@ def make_dims(batch, num_gaussians, width, height, max_radius=64.0, background=(
     d.num_cameras = int(num_cameras)
     d.saturation_skip = 1 if saturation_skip else 0
     for k, v in (tuning or {}).items():
-        if k not in ("seg_len", "fwd_variant", "bin_mode", "tile_w"):
+        if k not in ("seg_len", "fwd_variant", "bin_mode", "tile_w", "sort_mode"):
             raise FgsError(f"unknown tuning field {k!r}")
         setattr(d, k, int(v))
     return d

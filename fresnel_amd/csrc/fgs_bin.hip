@@ -960,7 +960,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         }
     } else if ((rc = fgs_launch_radix_sort(keys0, vals0, keys1, vals1, layered_direct ? nullptr : order, &ks, &vs, N, nullptr, N, N,
                                            B, 32, hist, st, depth_key, N,
-                                           layered_direct ? nullptr : reinterpret_cast<const uint32_t *>(saved + p.s_keybits),
+                                           (layered_direct || p.d.sort_mode != 1) ? nullptr : reinterpret_cast<const uint32_t *>(saved + p.s_keybits),
                                            (N + 255u) / 256u))) {
         return rc;
     }

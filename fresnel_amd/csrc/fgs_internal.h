@@ -94,12 +94,11 @@ __device__ __forceinline__ uint32_t fgs_float_key(float f) {
 }
 
 // kz^2 = (1/l)^2 - FX^2 - FY^2 exactly as the reference's fp32 expression evaluates it (DR:993): every product and every
-// difference rounded on its own -- NO fused multiply-add.  Near the evanescent boundary the difference cancels to a few ulps of
-// 1/l^2, and dkz/dlambda = -1 / (l^3 kz) weights exactly those frequencies most: with the compiler free to contract
-// il * il - fx * fx into an FMA (differently in the kernel that builds H and in the ones that form dL/dlambda) the wavelength
-// gradient of K5 came out 2e-4 from the reference's, with this 4e-6 (round 4, profiles/r04_dlambda_probe.txt).  ONE function
-// for the forward table, the recurrence factor D, both dL/dlambda kernels and the standalone propagator (fgs_spectral.hip):
-// forward and adjoint must agree on kz to the bit.
+// difference rounded on its own, whatever the translation unit's contraction setting.  Near the evanescent boundary the
+// difference cancels to a few ulps of 1/l^2 and dkz/dlambda = -1 / (l^3 kz) weights exactly those frequencies most, so the
+// forward table, the recurrence factor D, both dL/dlambda kernels and the standalone propagator (fgs_spectral.hip) take kz^2
+// from this ONE function: forward and adjoint agree on kz to the bit.  (fgs_asm.hip as a whole is compiled with
+// -ffp-contract=off since round 4 -- build.py has the measurement that decided it.)
 __device__ __forceinline__ float fgs_kz2(float il, float fx, float fy) {
     return __fsub_rn(__fsub_rn(__fmul_rn(il, il), __fmul_rn(fx, fx)), __fmul_rn(fy, fy));
 }

@@ -16,7 +16,7 @@
 // popcount below the lane gives the stable rank -- no atomics, no order dependence).
 // HBM-bound: 8 B read in upsweep+downsweep and 8 B written per element per pass.
 //
-// KEY COMPRESSION (depth sort only, round 4; BASELINE config 4's "depth-zone sort keys").  Only the key bits that VARY over a
+// KEY COMPRESSION (depth sort only, round 4; BASELINE config 4's "depth-zone sort keys"; selected by FgsDims.sort_mode = 1).  Only the key bits that VARY over a
 // segment's visible Gaussians can change their order.  k_project leaves, per block, the OR and the AND of the visible keys;
 // every block of the sort folds its segment's records into the mask m = OR ^ AND and sorts by the COMPRESSED key
 //     pext(key, m)  for a visible Gaussian,    1 << popcount(m)  for a culled one (key 0xFFFFFFFF: behind all visible ones),
@@ -25,7 +25,11 @@
 // ceil((popcount(m) + [any culled]) / 8) passes; the blocks of the later passes leave at once, and the last LIVE pass of a
 // segment writes the payload to its final place.  Zone-snapped depths (8 zones: 3 varying bits) sort in ONE pass instead of
 // four; ordinary depths in (0.5, 4) vary in ~25 bits and keep their four.  All 8 launches still happen (how many passes a
-// segment needs is known on the device only) -- a dead pass costs a launch of blocks that read ~100 words and exit.
+// segment needs is known on the device only) -- a dead pass costs a launch of blocks that read ~100 words and exit -- and
+// every live kernel pays ~1-1.7 us for folding the records.  Measured (profiles/r04_ab_sort_key_compression.txt): config 4
+// depth sort 38 -> 27 us, but config 2 39 -> 52 and config 3 53 -> 68 (with the record loads overlapped with the key loads:
+// 37 -> 33, 39 -> 47, 53 -> 60).  Hence a MODE the caller selects when it knows its depths are quantised (the training
+// harness with --use_fresnel_zones, bench.py --workload config4), never a default: any data sorts correctly in either mode.
 #include <type_traits>
 #include "fgs_internal.h"
 
@@ -86,7 +90,7 @@ __device__ __forceinline__ KeyPlan key_plan(const uint32_t *__restrict__ bits, u
         kb[12 + threadIdx.x] = (idx < nbits) ? (uint32_t)__ffs((int)mm) - 1u : 32u;
         if (threadIdx.x == 0) {
             const uint32_t need = (nbits + cull + 7u) / 8u;
-            kb[20] = need ? need : 1u;
+            kb[20] = need < 1u ? 1u : (need > 4u ? 4u : need);  // (33 bits -- every key bit varies and some keys are culled -- is the full key: key_digit)
             kb[21] = (cull && nbits >= 8u * pass && nbits < 8u * pass + 8u) ? 1u << (nbits - 8u * pass) : 0u;
         }
     }
@@ -104,7 +108,9 @@ __device__ __forceinline__ KeyPlan key_plan(const uint32_t *__restrict__ bits, u
     return kp;
 }
 
-__device__ __forceinline__ uint32_t key_digit(const KeyPlan &kp, uint32_t key) {
+// (a segment whose keys vary in more than 24 bits needs four passes either way: the key's own bytes then, same permutation)
+__device__ __forceinline__ uint32_t key_digit(const KeyPlan &kp, uint32_t key, uint32_t pass) {
+    if (kp.live >= 4u) return (key >> (8u * pass)) & 0xFFu;  // block-uniform
     uint32_t d = 0u;
 #pragma unroll
     for (int i = 0; i < 8; ++i) d |= ((key >> kp.sh[i]) & 1u) << i;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(
         for (int u = 0; u < 4; ++u) k[u] = i + u * RS_THREADS < r.end ? keys[i + u * RS_THREADS] : 0u;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i + u * RS_THREADS < r.end) atomicAdd(&h[COMPRESSED ? key_digit(kp, k[u]) : (k[u] >> shift) & dmask], 1u);
+            if (i + u * RS_THREADS < r.end) atomicAdd(&h[COMPRESSED ? key_digit(kp, k[u], pass) : (k[u] >> shift) & dmask], 1u);
     }
     __syncthreads();
     // layout: hist[(seg*256 + digit) * bps + blk]
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
         uint32_t lrank[4], dig[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const uint32_t digit = COMPRESSED ? key_digit(kp, key[it]) : (key[it] >> shift) & dmask;
+            const uint32_t digit = COMPRESSED ? key_digit(kp, key[it], pass) : (key[it] >> shift) & dmask;
             dig[it] = digit;
             unsigned long long m = __ballot(valid[it]);
 #pragma unroll

@@ -302,6 +302,10 @@ def default_renderer_factory(cfg: TrainingConfig, device, res: Optional[int] = N
     else:                       # TGD:1898-1906
         renderer = TileBasedRenderer(res, res, use_phase_blending=cfg.use_phase_blending,
                                      phase_amplitude=cfg.phase_amplitude).to(device)
+        if cfg.use_fresnel_zones:
+            # the decoder snaps depths to `num_fresnel_zones` values (GDM:834-841): the zone-key depth sort then needs one
+            # radix pass instead of four (FgsDims.sort_mode, fgs_sort.hip); a work-split choice, the order is the same
+            renderer.tuning = dict(sort_mode=1)
     camera = Camera(fx=res * 0.8, fy=res * 0.8, cx=res / 2, cy=res / 2, width=res, height=res)
     return renderer, camera
 

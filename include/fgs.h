@@ -68,6 +68,11 @@ typedef struct FgsDims {
     int32_t tile_w;         /* tile width in pixels: 0 | 16 | 32 (tiles are always 16 rows high).  0 = automatic:
                                32 on the blend path with the depth-split forward for frames >= 512 pixels wide
                                in calls of >= 3072 16 x 16 tiles, 16 elsewhere (FgsSavedLayout.tile_w tells)    */
+    int32_t sort_mode;      /* depth sort: 0 = four 8-bit radix passes over the 32 key bits | 1 = "zone keys" (BASELINE config 4,
+                               --use_fresnel_zones: depths snapped to a few values): the keys are compressed to the bits that
+                               vary over an image's visible Gaussians and only the passes those need do any work -- the same
+                               order for ANY depths, faster when they vary in <= 24 bits, ~20 % slower otherwise.  NOT chosen
+                               automatically: what the depths look like is known on the device only (fgs_sort.hip)      */
 } FgsDims;
 
 /* Camera record on the DEVICE: FGS_CAMERA_FLOATS floats per camera (Camera, DR:27-52):

@@ -26,6 +26,9 @@ Cases:
   G15 ONE image of the headline configuration (BASELINE config 3: 32 768 Gaussians @512x512, create_dummy_saag distribution)
       through the reference itself: image / depth rows 0::16 and the gradients of every 8th Gaussian; inputs are regenerated
       from the seed by tests/helpers.synth_saag
+  G16 ONE image of BASELINE config 5 AS BENCHMARKED (8 192 Gaussians @512x512, 16 depth planes, per-channel wavelengths, scalar
+      phases) through ASMWaveFieldRenderer in fp32 and fp64 (16 + 29 minutes here): image rows 0::16, gradients of every 8th
+      Gaussian, dL/dlambda; G9f64: the fp64 run of the two G9 scenes (referee of dL/dlambda, which is NaN in fp32 for lambda = .05)
   K1-K5 the randomized sweeps' known kink / conditioning cases (tests/fuzz_cases.py replays the sweep's draws): two
       phase-path scenes and two ASM scenes, each through the reference-derived referee in fp32 and in fp64
   G14 needles / discs at scale ratios 30:1, 100:1, 500:1 through the reference in fp32 AND in fp64 (default dtype

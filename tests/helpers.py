@@ -83,26 +83,32 @@ def upstream_grads(seed, H, W):
     return gI, gD
 
 
-REFEREE_FACTOR = 3.0  # see referee(); the per-tensor numbers behind it: profiles/r04_referee_table.txt
+# Referee rule of the fixtures that hold the reference in fp32 AND fp64 (G14, K1-K5, G9f64, G16) and of the oracle-based
+# dL/dlambda checks.  profiles/r04_referee_table.txt lists, per fixture and tensor, the distance from the fp64 reference of the
+# reference's own fp32 run, of the CPU oracle and of the HIP path.  Over all tensors whose fp32 reference is further than 5e-5
+# from its fp64 run, the largest ratio (distance of ours) / (distance of the reference's fp32 run) is 1.62 for the HIP path
+# (G14 100:1 image) and 1.33 for the oracle (G14 500:1 opacities): REFEREE_FACTOR = 2 covers both with a margin.  (Round 3 needed
+# 3: the ASM unit's FMA contraction put the HIP path 2.8x further out than the reference on K5; compiled without, it tracks the
+# reference's fp32 run to within a few per cent on K3-K5.)
+REFEREE_FACTOR = 2.0
+REFEREE_CEILING = 2e-2  # nothing passes further out than this, whatever the spread (G14 500:1 rotations: reference fp32 2e+4, HIP 1.5e-2)
 
 
 def referee_tolerance(spread):
-    """(use the fp64 run?, tolerance) for a tensor whose reference fp32 run is `spread` (relative to max) from its fp64 run."""
+    """(use the fp64 run?, tolerance) for a tensor whose reference fp32 run is `spread` (relative to max) from its fp64 run:
+      * spread <= 5e-5: fp32 arithmetic is adequate -> the usual statement, 1e-4 of max against the fp32 reference;
+      * else the fp64 run referees, tolerance REFEREE_FACTOR x spread -- but beyond 1e-3 no more than 1.25 x spread (a
+        regression must not hide behind a large spread), never more than REFEREE_CEILING, at least 1e-4."""
     if spread <= 5e-5:
         return False, 1e-4
-    return True, max(1e-4, REFEREE_FACTOR * spread)
+    tol = min(REFEREE_FACTOR * spread, max(1e-3, 1.25 * spread), REFEREE_CEILING)
+    return True, max(1e-4, tol)
 
 
 def referee(ref32, ref64):
-    """Which reference run referees a tensor, and with what tolerance (fixtures G14 / K1-K4 hold the reference's result
-    in fp32 AND in fp64).  spread = distance of the reference's own fp32 result from its fp64 one, relative to max.
-      * spread <= 5e-5: fp32 arithmetic is adequate here -> the usual statement, 1e-4 of max against the fp32 reference;
-      * otherwise the reference's fp32 result is itself not a 1e-4 answer (needles, kinks of the phase recurrence,
-        strongly interfering ASM scenes) -> the fp64 run is the referee and the result must be no further from it than
-        THREE times the reference's own fp32 run is (independent fp32 evaluations of an ill-conditioned quantity scatter
-        by such factors: in K5 the rotation gradients are 500x smaller than the position gradients, merely rounding the
-        PROJECTED means / conics to fp32 -- everything else in double -- already moves them 2.1e-4, the reference's fp32
-        autograd is 1.7e-4 off, this repo's torch restatement 1.7e-4, the HIP path 4.7e-4); at least 1e-4."""
+    """Which reference run referees a tensor, and with what tolerance (referee_tolerance).  spread = distance of the
+    reference's own fp32 result from its fp64 one, relative to max: where it exceeds 5e-5 the reference's fp32 result is itself
+    not a 1e-4 answer (needles, kinks of the phase recurrence, strongly interfering ASM scenes)."""
     spread = rel_to_max(ref32, ref64)
     use64, tol = referee_tolerance(spread)
     return (np.asarray(ref64) if use64 else np.asarray(ref32)), tol, spread

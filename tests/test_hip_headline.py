@@ -178,7 +178,8 @@ def test_more_than_65536_gaussians_per_image_vs_oracle():
 def test_config4_phase_launch_vs_oracle():
     """BASELINE config 4 as the bench launches it: 16 images x 8 192 Gaussians @256x256, depths snapped to 8 zone
     centres (massive depth ties -> canonical stable order), edge-aware scale factors U(.5,1), scalar phases U(0,1),
-    phase blending with amplitude 0.25 -- forward, all gradients incl. dL/dphase of images 0 and 11 vs the oracle."""
+    phase blending with amplitude 0.25 -- forward, all gradients incl. dL/dphase of images 0 and 11 vs the oracle.  As the
+    bench (and the training harness with --use_fresnel_zones) launches it: FgsDims.sort_mode = 1, the zone-key depth sort."""
     from oracle import fgs_oracle as orc
     from fresnel_amd.renderer import Camera
     from helpers import synth_saag
@@ -196,7 +197,8 @@ def test_config4_phase_launch_vs_oracle():
     ocam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * S, 0.8 * S, S / 2, S / 2, S, S)
     gI = rs.standard_normal((Bn, 3, S, S)).astype(np.float32)
     gD = (rs.standard_normal((Bn, S, S)) * 0.1).astype(np.float32)
-    out = _hip_render(arrs, cam, S, S, (0.0, 0.0, 0.0), phases=phases, use_phase=True, amp=0.25, grads=(gI, gD))
+    out = _hip_render(arrs, cam, S, S, (0.0, 0.0, 0.0), phases=phases, use_phase=True, amp=0.25, grads=(gI, gD),
+                      tuning=dict(sort_mode=1))
     for b in (0, 11):
         r = orc.render(*[a[b] for a in arrs], ocam, phases=phases[b], phase_amp=0.25)
         assert len(np.unique(r.proj["depth"][r.proj["visible"].astype(bool)])) <= 8

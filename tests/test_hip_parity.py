@@ -671,11 +671,13 @@ def test_forward_variants_agree(use_phase):
             assert rel_to_max(o["grad_" + k], go[k]) <= TOL, (t, k)
 
 
+@pytest.mark.parametrize("sort_mode", [1, 0])
 @pytest.mark.parametrize("N", [1000, 8192, 33000])
-def test_depth_sort_key_compression_gives_the_full_key_order(N):
-    """Round 4 (BASELINE config 4, "depth-zone sort keys"): the depth sort keeps only the key bits that vary over an image's
-    visible Gaussians and runs as many 8-bit passes as those need.  Whatever the depths look like, `order` must be the stable
-    argsort of the FULL keys (culled keys = 0xFFFFFFFF last, in index order).  One batch, one image of each kind:
+def test_depth_sort_key_compression_gives_the_full_key_order(N, sort_mode):
+    """Round 4 (BASELINE config 4, "depth-zone sort keys"): with FgsDims.sort_mode = 1 the depth sort keeps only the key bits that
+    vary over an image's visible Gaussians and runs as many 8-bit passes as those need.  Whatever the depths look like, and in
+    either mode, `order` must be the stable argsort of the FULL keys (culled keys = 0xFFFFFFFF last, in index order).  One batch,
+    one image of each kind:
       0  zone-snapped depths (8 values: 3 varying bits, ONE live pass), some Gaussians culled;
       1  ordinary depths (~25 varying bits: all four passes);
       2  every Gaussian behind the camera (all culled: nothing varies, the payload is copied by the forced pass);
@@ -708,7 +710,7 @@ def test_depth_sort_key_compression_gives_the_full_key_order(N):
             pos[:, 2] = -(base.view(np.uint32) | low).view(np.float32)
         per.append((pos, scale * 0.2, quat, col, opa))
     arrs = [np.stack([p[i] for p in per]) for i in range(5)]
-    st = _hip_stages(arrs, Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S), S, S)
+    st = _hip_stages(arrs, Camera(0.8 * S, 0.8 * S, S / 2, S / 2, S, S), S, S, tuning=dict(sort_mode=sort_mode))
     keys = st["depth_key"].view(np.uint32)
     kinds = []
     for b in range(6):
