@@ -45,7 +45,7 @@ def _import_compute():
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (packed / dual-issue rate)
 DECODER_GRAD_FLOATS = 673_537  # DirectPatchDecoder gradient bucket (measured)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
 
 WORKLOADS = {
     # name: (N gaussians, resolution, images per GPU)   -- BASELINE.json configs[1..4]
@@ -105,7 +105,7 @@ def pmc_field_traffic(run_key):
 
 def pmc_traffic(run_key, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r03_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per the gfx950
+    (profiles/r04_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per the gfx950
     correction of MI355X_MICROARCH.md).  None when that run was not profiled."""
     if not os.path.exists(PMC_SUMMARY):
         return None
@@ -592,8 +592,8 @@ def main(argv=None):
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "avg_launch_ms": round(avg_ms[name], 4),
                     "algorithmic_bytes_per_launch": int(alg_bytes[name])}
 
-        kernel_names = {"composite_fwd": "k_blend_fwd_parts" if args.workload != "config4" and not args.saturation_skip else "k_composite_fwd",
-                        "composite_bwd": "k_composite_bwd_phase" if args.workload == "config4" else "k_composite_bwd",
+        kernel_names = {"composite_fwd": "k_phase_fwd" if args.workload == "config4" else ("k_composite_fwd" if args.saturation_skip else "k_blend_fwd_parts"),
+                        "composite_bwd": "k_phase_bwd" if args.workload == "config4" else "k_composite_bwd",
                         "splat_fwd": "k_asm_splat<false>", "splat_bwd": "k_asm_splat<true>",
                         "field_fwd": "rocFFT rows + k_colfft_fwd (column FFT x transfer function, plane sum) + k_asm_transfer/max/output",
                         "field_bwd": "k_asm_output_bwd + k_colfft_bwd (gAcc conj(H), inverse column FFT) + rocFFT rows"}
@@ -602,14 +602,14 @@ def main(argv=None):
         roofline.update(stage_roofline(dom_stage))
         traffic = pmc_traffic(run_key, kernel_names[dom_stage].split("<")[0]) if not args.saturation_skip else None
         roofline["traffic"] = traffic
-        roofline["traffic_source"] = (f"profiles/r03_pmc_summary.json run {run_key}: separate rocprofv3 --pmc FETCH_SIZE / "
+        roofline["traffic_source"] = (f"profiles/r04_pmc_summary.json run {run_key}: separate rocprofv3 --pmc FETCH_SIZE / "
                                       "WRITE_SIZE passes of this command, 2*FETCH_SIZE + WRITE_SIZE per launch"
                                       if traffic is not None else None)
         if dom_stage in ("field_fwd", "field_bwd") and pmc_field_traffic(run_key) is not None:
             # a stage of many kernels (rocFFT's + ours): the counters are summed over BOTH field stages of a step, to
             # be compared with the algorithmic bytes of both (2 x 0.36 GB per image)
             roofline["traffic"] = pmc_field_traffic(run_key)
-            roofline["traffic_source"] = (f"profiles/r03_pmc_summary.json run {run_key}: 2*FETCH_SIZE + WRITE_SIZE summed over all "
+            roofline["traffic_source"] = (f"profiles/r04_pmc_summary.json run {run_key}: 2*FETCH_SIZE + WRITE_SIZE summed over all "
                                           "kernels of field_fwd AND field_bwd per step; algorithmic counterpart = "
                                           f"{int(2 * ASM_BYTES_PER_IMAGE * per_gpu)} bytes")
         roofline["flop_model"] = ("SURVEY 8d: 23 flop per Gaussian-pixel forward, 60 backward (phase path: same count, its extra "

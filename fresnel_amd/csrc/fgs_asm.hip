@@ -59,7 +59,7 @@ struct AsmPlan {
     size_t v_total_bytes;
     // scratch sections (after base.s_total)
     size_t c_acc;        // float2 [B][3][H][W]
-    size_t c_part;       // float2 [B][RED_BLOCKS] block partials of the per-image scalars | float [3][B*HW/256] of dL/dlambda
+    size_t c_part;       // float2 [B][RED_BLOCKS] block partials of the per-image scalars | double [3][B*HW/256] of dL/dlambda
     size_t c_fftwork;
     size_t c_total_bytes;
     size_t work_big, work_small;
@@ -121,7 +121,7 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     // (Round 3 built the row direction fused with the splat / its adjoint -- one kernel per direction keeping a band of 8 rows
     // x 3 channels x 512 points in LDS, the plane fields never in HBM -- and measured it SLOWER: config 5 at 8 images 2.63 ->
     // 3.33 ms.  133 KB of LDS = one 16-wave block per CU, whose phases (latency-bound list walk, then the transforms) run back
-    // to back with nothing to overlap them.  Removed in round 4; DESIGN.md 10.5, profiles/r03_ab_config5_*_rows_fused.txt,
+    // to back with nothing to overlap them.  Removed in round 4; DESIGN_LOG.md 10.5, profiles/r03_ab_config5_*_rows_fused.txt,
     // the code is in the history at 763bed2 csrc/fgs_asm_rows.h.)
     p->v_total_bytes = o;
     p->work_big = p->work_small = 0;
@@ -138,7 +138,7 @@ int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
         size_t nwl = (B * HW + 255) / 256;  // dL/dlambda partials: per block of k_asm_accumulate_bwd / k_colfft_bwd
         const size_t nwl2 = (size_t)((a->width + p->col_tc - 1) / p->col_tc) * B * p->col_pg;
         if (nwl2 > nwl) nwl = nwl2;
-        p->c_part = o; o = align256(o + B * RED_BLOCKS * 8 + 3 * nwl * 4);
+        p->c_part = o; o = align256(o + B * RED_BLOCKS * 8 + 3 * nwl * 8);  // (the dL/dlambda partials are doubles)
     }
     p->c_accp = o;
     if (p->col_pg > 1) o = align256(o + 2 * B * p->col_pg * 3 * HW * 8);  // partial plane sums of acc and of Z
@@ -525,7 +525,7 @@ __device__ __forceinline__ float image_max(const float *__restrict__ pmax, int b
 // the accumulate kernel's pass.  Unnormalised, like hipFFT.  Twiddles w_N^n = exp(-2 pi i n / N) from a global table (k_asm_prep).
 // Eight tile elements per thread: NT = N * TC / 8 threads per block (1024 for a 512 x 16 tile).  (The first version ran
 // 256 threads with 32 elements each: 270 / 458 VGPRs, one wave per SIMD, 1.9 / 1.3 ms at 8 images.)  History and measurements:
-// DESIGN.md 10.5.
+// DESIGN_LOG.md 10.5.
 constexpr int COLFFT_PER = 8;
 
 template <int NT>
@@ -771,13 +771,13 @@ template <int LOGN, int TC>
 __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
     int W, int P, int PG, float near_, float far_, float focal, float inv_ndx, float inv_ndy,
     const float *__restrict__ wavelengths, const float2 *__restrict__ gacc, const float2 *__restrict__ htab,
-    const float2 *__restrict__ tw_g, float2 *__restrict__ field, float *__restrict__ pwl,
+    const float2 *__restrict__ tw_g, float2 *__restrict__ field, double *__restrict__ pwl,
     const uint32_t *__restrict__ seg_off, uint32_t tiles, const float2 *__restrict__ zsum) {
     constexpr int N = 1 << LOGN, PER = COLFFT_PER, NT = N * TC / PER, E1 = N / 8;
     constexpr bool INNER = lds_fft_inner_in_registers<LOGN>();
     __shared__ float2 x[N][TC];
     __shared__ float2 tw[N / 2];
-    __shared__ float wpart[NT / 64];
+    __shared__ double wpart[NT / 64];
     load_twiddles<NT>(tw, tw_g, N / 2);
     int bx, c, b, grp;
     colfft_block<FGS_COLFFT_ORDER_BWD>(PG, bx, c, b, grp);
@@ -860,12 +860,15 @@ __global__ __launch_bounds__((1 << LOGN) * TC / COLFFT_PER) void k_colfft_bwd(
         plane_step(pn - p);
         p = pn;
     }
+    // the block's 8 192 terms (eight per thread, added in fp32 above) are summed in DOUBLE from here on: dL/dlambda cancels to a
+    // fraction of its terms, and an fp32 tree over 1 024 partials alone put it 1.3e-4 from the fp64 oracle on a 512-row scene
+    double gld = (double)gl;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) gl += __shfl_xor(gl, o, 64);
-    if ((threadIdx.x & 63u) == 0) wpart[threadIdx.x >> 6] = gl;
+    for (int o = 32; o > 0; o >>= 1) gld += __shfl_xor(gld, o, 64);
+    if ((threadIdx.x & 63u) == 0) wpart[threadIdx.x >> 6] = gld;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float t = 0.0f;
+        double t = 0.0;
         for (int w = 0; w < NT / 64; ++w) t += wpart[w];
         pwl[(size_t)c * (gridDim.x * gridDim.z) + bz * gridDim.x + bx] = t;
     }
@@ -1017,11 +1020,11 @@ __global__ __launch_bounds__(256) void k_asm_accumulate_bwd(int W, int H, int B,
                                                             const float2 *__restrict__ gacc,
                                                             const float2 *__restrict__ htab,
                                                             float2 *__restrict__ field,
-                                                            float *__restrict__ pwl /* [3][gridDim.x] block partials */) {
+                                                            double *__restrict__ pwl /* [3][gridDim.x] block partials */) {
     const size_t HW = (size_t)W * H;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y;
-    float gl = 0.0f;
+    double gl = 0.0;  // (summed in double from the first term on: see k_colfft_bwd)
     if (i < (size_t)B * HW) {
         const size_t k = i % HW;
         const int b = (int)(i / HW);
@@ -1041,23 +1044,23 @@ __global__ __launch_bounds__(256) void k_asm_accumulate_bwd(int W, int H, int B,
             const float2 gH = cmul(make_float2(f.x, -f.y), g);          // conj(F) * gAcc
             const float gtheta = -(h.y * gH.x - h.x * gH.y);             // -Im(H * conj(gH))
             const float z = focal - plane_depth(p, P, near_, far_);
-            gl += gtheta * (6.28318530717958647692f * z) * dkz;
+            gl += (double)(gtheta * (6.28318530717958647692f * z) * dkz);
             field[fi] = cmul(g, make_float2(h.x, -h.y));
         }
     }
 #pragma unroll
     for (int of = 32; of > 0; of >>= 1) gl += __shfl_xor(gl, of, 64);
-    __shared__ float part[4];
+    __shared__ double part[4];
     if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = gl;
     __syncthreads();
     if (threadIdx.x == 0) pwl[(size_t)c * gridDim.x + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // dL/dlambda_c = the sum of k_asm_accumulate_bwd's block partials, in a fixed order, in double (one block per channel)
-__global__ __launch_bounds__(256) void k_asm_wavelength_grad(uint32_t n, const float *__restrict__ pwl,
+__global__ __launch_bounds__(256) void k_asm_wavelength_grad(uint32_t n, const double *__restrict__ pwl,
                                                              float *__restrict__ g_wavelengths) {
     double s = 0.0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) s += (double)pwl[(size_t)blockIdx.x * n + i];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s += pwl[(size_t)blockIdx.x * n + i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     __shared__ double part[4];
@@ -1379,7 +1382,7 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     fgs_stage_begin(ST_FIELD_BWD, st);
     const dim3 gpix((unsigned)((HW + 255) / 256), B);
     float2 *psum = reinterpret_cast<float2 *>(sc + p.c_part);
-    float *pwl = reinterpret_cast<float *>(sc + p.c_part + (size_t)B * RED_BLOCKS * 8);
+    double *pwl = reinterpret_cast<double *>(sc + p.c_part + (size_t)B * RED_BLOCKS * 8);
     hipLaunchKernelGGL(k_asm_output_bwd1, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, inv_hw, a.background[0],
                        a.background[1], a.background[2], total, scal, g_rgb, psum);
     FGS_LAUNCH_CHECK("k_asm_output_bwd1");

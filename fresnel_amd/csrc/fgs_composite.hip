@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64 * NP * (1 + WIDE)) __attribute__((amdgpu_waves_p
 // NSX = sub-tile columns of the tile: 2 (16 x 16 tiles) or 4 (32 x 16 tiles: eight sub-tiles per lane, ~0.6x as many list
 // entries, reductions and gradient rows; 5 waves per SIMD instead of 6 -- the loop is issue-bound, not latency-bound).
 #ifndef FGS_BWD_WIDE_WAVES
-#define FGS_BWD_WIDE_WAVES 5  /* waves per SIMD of k_composite_bwd<4>; re-measured in round 3 under the clause scheduler: see DESIGN.md 10.3 */
+#define FGS_BWD_WIDE_WAVES 5  /* waves per SIMD of k_composite_bwd<4>; re-measured in round 3 under the clause scheduler: see DESIGN_LOG.md 10.3 */
 #endif
 template <int NSX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6 : FGS_BWD_WIDE_WAVES, NSX == 2 ? 6 : FGS_BWD_WIDE_WAVES))) void k_composite_bwd(

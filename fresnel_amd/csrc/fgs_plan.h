@@ -16,7 +16,7 @@ enum { G_U = 0, G_V, G_CA, G_CBC, G_CD, G_OP, G_CR, G_CG, G_CB, G_DEPTH, G_PHASE
 #ifndef FGS_BLEND_ROW_FLOATS
 #define FGS_BLEND_ROW_FLOATS 10  /* gradient rows of the (non-phase) blend backward: exactly its ten sums.  16 (build experiment):
                                     one 64-byte line per row, written whole by sixteen lanes -- no partial-sector writes, but 1.6x
-                                    the bytes each way; measured in round 3, see DESIGN.md */
+                                    the bytes each way; measured in round 3, see DESIGN_LOG.md 10.3 */
 #endif
 #define FGS_BIN_G 256  /* depth ranks per block of the direct binning (fgs_bin.hip) */
 #define FGS_TILE_TABLE_TILES 1024  /* lists per block of the tile-table kernels (fgs_bin.hip k_tile_pre / k_tile_post) */

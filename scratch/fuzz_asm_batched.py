@@ -41,7 +41,7 @@ for it in range(ncase):
         for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
             errs["%s%d" % (k[:3], b)] = rel_to_max(out["grad_" + k][b], r["grad_" + k])
         gw = gw + r["grad_wavelengths"]
-    errs["wavelengths/10"] = rel_to_max(out["grad_wavelengths"], gw) / 10.0  # (its tolerance is 1e-3)
+    errs["wavelengths"] = rel_to_max(out["grad_wavelengths"], gw)  # (1e-4 like the others since round 4)
     m = max(errs.values()); worst = max(worst, m)
     if only >= 0: print({k: '%.1e' % v for k, v in errs.items()})
     print(f"seed {seed} it {it:2d} W{W} H{H} P{P} B{Bn} N{N} max err {m:.2e} ({max(errs, key=errs.get)})" + ('' if m <= 1e-4 else '  <-- ABOVE 1e-4'), flush=True)

@@ -2,7 +2,7 @@
 by scratch/profile_merge.py)."""
 import sys, glob, csv, collections, json
 root, key = sys.argv[1], sys.argv[2]
-KEYS = ('k_colfft_fwd', 'k_colfft_bwd', 'k_composite_bwd_phase', 'k_composite_bwd', 'k_blend_fwd_parts', 'k_composite_fwd', 'k_asm_splat', 'k_asm_accumulate_bwd',
+KEYS = ('k_colfft_fwd', 'k_colfft_bwd', 'k_phase_fwd', 'k_phase_bwd', 'k_composite_bwd_phase', 'k_composite_bwd', 'k_blend_fwd_parts', 'k_composite_fwd', 'k_asm_splat', 'k_asm_accumulate_bwd',
         'k_asm_accumulate', 'k_asm_transfer', 'k_project_bwd', 'k_project', 'k_sort_image', 'k_radix_downsweep', 'k_radix_upsweep',
         'k_mask_build', 'k_mask_count', 'k_mask_emit', 'k_row_sum', 'k_tile_pre', 'k_tile_post', 'k_dup_emit')
 
