@@ -1,6 +1,6 @@
 """N2 profile: the library's fused spectral / stencil losses against the stock-torch formulation on a rendered batch
 (8 x 3 x 512 x 512, forward + backward).  Run plain for wall-clock numbers, or under
-`rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 scratch/profile_losses.py` for per-kernel
+`rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 scratch/profile/profile_losses.py` for per-kernel
 times.  Prints one JSON line with ms per call and the HBM fraction of each library kernel class (algorithmic bytes)."""
 import json, sys, time
 import torch

@@ -1,5 +1,5 @@
-"""Collect one run of scratch/profile_run.sh into <out>/pmc_run.json (merged into profiles/<tag>_pmc_summary.json
-by scratch/profile_merge.py)."""
+"""Collect one run of scratch/profile/profile_run.sh into <out>/pmc_run.json (merged into profiles/<tag>_pmc_summary.json
+by scratch/profile/profile_merge.py)."""
 import sys, glob, csv, collections, json
 root, key = sys.argv[1], sys.argv[2]
 KEYS = ('k_colfft_fwd', 'k_colfft_bwd', 'k_phase_fwd', 'k_phase_bwd', 'k_composite_bwd_phase', 'k_composite_bwd', 'k_blend_fwd_parts', 'k_composite_fwd', 'k_asm_splat', 'k_asm_accumulate_bwd',

@@ -19,7 +19,7 @@ for grp in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" 
   timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 bench.py $ARGS --steps 3 --warmup 1 --spinup-ms 0 --no-cpu-baseline > $OUT/g$i.log 2>&1 || { echo "$KEY pmc group $i failed"; tail -5 $OUT/g$i.log; exit 1; }
   echo "$KEY pmc group $i done"
 done
-python3 scratch/profile_parse.py $OUT $KEY
+python3 scratch/profile/profile_parse.py $OUT $KEY
 # keep only the small artefacts (the raw counter CSVs are tens of MB)
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/stats $OUT/g1 $OUT/g2 $OUT/g3 $OUT/g4 $OUT/g5

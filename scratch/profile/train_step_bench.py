@@ -3,7 +3,7 @@ clip -> fused AdamW, fresnel_amd.train.train_step at BASELINE config 2 / config 
 stand-in decoder: K = 6 -> 8214 @ 256^2 x 16 images, K = 24 -> 32856 @ 512^2 x 8 images).  Reports step ms (host clock
 over `steps` steps, one sync at the end), the rasterizer's share from the library's stage timers (a second pass with
 every stage bracketed), pairs/s, and the number of host syncs per step (torch sync debug mode).
-usage: python scratch/train_step_bench.py [steps] > gpurun_out/train_step.json"""
+usage: python scratch/profile/train_step_bench.py [steps] > gpurun_out/train_step.json"""
 import json, sys, time, warnings
 import numpy as np, torch
 sys.path.insert(0, '.')

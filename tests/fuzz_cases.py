@@ -1,4 +1,4 @@
-"""Seeded case generators of the randomized parity sweeps (scratch/fuzz_phase.py, scratch/fuzz_asm.py).  Kept in one
+"""Seeded case generators of the randomized parity sweeps (scratch/fuzz/fuzz_phase.py, scratch/fuzz/fuzz_asm.py).  Kept in one
 place so that a sweep's failing case (seed, iteration) can be turned into a committed fixture: tests/golden/
 make_goldens.py --kinks-only replays the same draws, runs the reference (fp32 and fp64) on them and stores the result.
 The draw ORDER is part of the contract -- do not reorder statements."""
