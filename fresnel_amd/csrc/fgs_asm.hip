@@ -385,20 +385,23 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
             for (int s = 0; s < 4; ++s) {
                 if (!((msk >> s) & 1u)) continue;
                 const float dx = dxs[s & 1], dy = dys[s >> 1];
-                const float m = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;  // K m
+                // (this unit is compiled with -ffp-contract=off -- build.py -- so the FMAs of the two VALU-bound loops, this one and
+                // the column butterflies of fgs_colfft.h, are written out: sums of same-signed or well-separated terms, where
+                // fusing is harmless; measured: dL/dlambda of K5 / G9 / G16 unchanged, config 5 back from 1.99 to 1.89 ms)
+                const float m = fmaf(ca * dx, dx, fmaf(cbc * dx, dy, (cd * dy) * dy));  // K m
                 const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(m)) & (mxs[s & 1] & mys[s >> 1]));
                 const float a = G * op;  // amplitude, DR:1270-1271 (no clamp on this path)
                 if (!BWD) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { re[s][c] += a * cc[c]; im[s][c] += a * cs[c]; }
-                    if (WAVE) { wd[s] += a * dz; ww[s] += a; }  // DR:890-891
+                    for (int c = 0; c < 3; ++c) { re[s][c] = fmaf(a, cc[c], re[s][c]); im[s][c] = fmaf(a, cs[c], im[s][c]); }
+                    if (WAVE) { wd[s] = fmaf(a, dz, wd[s]); ww[s] += a; }  // DR:890-891
                 } else {
                     float da = 0.0f;
-                    if (WAVE) { da = wd[s] * dz + ww[s]; v_dep += a * wd[s]; }
+                    if (WAVE) { da = fmaf(wd[s], dz, ww[s]); v_dep = fmaf(a, wd[s], v_dep); }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        da += cc[c] * re[s][c] + cs[c] * im[s][c];
-                        v_cc[c] += a * re[s][c]; v_cs[c] += a * im[s][c];
+                        da = fmaf(cc[c], re[s][c], fmaf(cs[c], im[s][c], da));
+                        v_cc[c] = fmaf(a, re[s][c], v_cc[c]); v_cs[c] = fmaf(a, im[s][c], v_cs[c]);
                     }
                     // moments of t = dL/da G about the Gaussian's mean: {1, dx, dy, dx^2, dx dy, dy^2}.  The chain through
                     // a = G op and m (dL/dm = -1/2 t op; dL/d(u, v) = -dL/dm (2 ca dx + cbc dy, cbc dx + 2 cd dy), linear in the
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
                     v_op += t;
                     const float tx = t * dx, ty = t * dy;
                     v_u += tx; v_v += ty;
-                    v_ca += tx * dx; v_cbc += tx * dy; v_cd += ty * dy;
+                    v_ca = fmaf(tx, dx, v_ca); v_cbc = fmaf(tx, dy, v_cbc); v_cd = fmaf(ty, dy, v_cd);
                 }
             }
             if (BWD) {

@@ -3,10 +3,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-__device__ __forceinline__ float2 fgs_cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// (FMAs written out: the butterflies must cost the same whatever the including unit's -ffp-contract setting -- fgs_asm.hip has it off)
+__device__ __forceinline__ float2 fgs_cmul(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a conj(b)
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y))); }  // a conj(b)
 
 // 8-point butterflies in registers = three radix-2 stages (block sizes M, M/2, M/4) on the points i + k M/8, k = 0 ... 7, in place
 // (a[k] <- the value of point i + k M/8 after the pass).  t1 = w_M^i, t2 = w_M^(2i), t4 = w_M^(4i); UNIT: i = 0, all three are 1
