@@ -303,7 +303,11 @@ __global__ __launch_bounds__(64 * NP) void k_asm_splat(
         key = seg_tile[unit];
         seg = unit - seg_off[key];
     } else {
+#ifdef FGS_SPLAT_ORDER_GROUPS
+        key = tile_order ? tile_order[NP == 1 ? fgs_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x] : blockIdx.x;  // (b*P + p)*T + t
+#else
         key = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (b*P + p)*T + t
+#endif
     }
     const uint32_t bp = key / tiles, t = key - bp * tiles;
     const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;

@@ -787,21 +787,26 @@ __global__ __launch_bounds__(256) void k_tile_post(uint32_t ntiles, uint32_t *__
             // columns tid, tid + 256 and walks the rows, all of a round's loads in flight together
             for (uint32_t col = threadIdx.x; col < ncols; col += 256) { pb[1][col] = pb[2][col] = pb[3][col] = 0; pa[1][col] = pa[2][col] = pa[3][col] = 0; }
             uint32_t before[2] = {0, 0}, all[2] = {0, 0};
-            for (uint32_t k0 = 0; k0 < nblk; k0 += 4) {
+            // many blocks (the layered lists of the splat renderers): when a group is a whole number of blocks, column (g, bucket) is
+            // non-zero in group g's rows only -- an eighth of the rows to walk
+            const bool aligned = ngroups == 8u && (ntiles & 7u) == 0u && ((ntiles >> 3) % TO_TILES) == 0u && ncols == 512u;
+            const uint32_t rpg = aligned ? nblk / 8u : nblk;  // rows per group
+            const uint32_t r0[2] = {aligned ? (threadIdx.x >> 6) * rpg : 0u, aligned ? ((threadIdx.x >> 6) + 4u) * rpg : 0u};
+            for (uint32_t k0 = 0; k0 < rpg; k0 += 4) {
                 uint32_t h[2][4];
 #pragma unroll
                 for (uint32_t c = 0; c < 2; ++c)
 #pragma unroll
                     for (uint32_t u = 0; u < 4; ++u) {
                         const uint32_t col = threadIdx.x + 256u * c;
-                        h[c][u] = (k0 + u < nblk && col < ncols) ? bhist[(size_t)(k0 + u) * ncols + col] : 0u;
+                        h[c][u] = (k0 + u < rpg && col < ncols) ? bhist[(size_t)(r0[c] + k0 + u) * ncols + col] : 0u;
                     }
 #pragma unroll
                 for (uint32_t c = 0; c < 2; ++c)
 #pragma unroll
                     for (uint32_t u = 0; u < 4; ++u) {
                         all[c] += h[c][u];
-                        if (k0 + u < blk) before[c] += h[c][u];
+                        if (r0[c] + k0 + u < blk) before[c] += h[c][u];
                     }
             }
 #pragma unroll

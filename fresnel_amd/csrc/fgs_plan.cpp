@@ -147,6 +147,11 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
 #define FGS_ORDER_GROUPS 8
 #endif
     p->order_groups = (p->fwd_parts > 0 && layers == 1 && segment_ckpt) ? FGS_ORDER_GROUPS : 1;
+#ifdef FGS_SPLAT_ORDER_GROUPS
+    // build experiment (round 4): the splat renderers' forward launch order grouped per XCD as well -- XCD g walks the g-th
+    // eighth of the (image, plane, tile) keys longest-first (eight images: one image per XCD, all eight concurrently)
+    if (!segment_ckpt && B * (size_t)layers * p->tiles >= 24576) p->order_groups = FGS_ORDER_GROUPS;
+#endif
     p->depth_ordered = segment_ckpt;  // the callers without segment checkpoints are the splat renderers
     const size_t ucap = dcap / L.seg_len + B * layers * p->tiles;
     L.seg_off = o; L.seg_tile = o; L.seg_ckpt = o; L.seg_capacity = 0;
