@@ -513,10 +513,11 @@ def main(argv=None):
     gI = torch.randn(per_gpu, 3, S, S, generator=g).to(device)
     gD = (torch.randn(per_gpu, S, S, generator=g) * 0.1).to(device)
     bucket = torch.zeros(DECODER_GRAD_FLOATS, device=device) if dist is not None else None
+    grad_leaves = leaves + ([phases] if phases is not None else []) + ([wl] if is_asm else [])
 
     def step():
         # the nn.Module call the training harness makes (fresnel_amd/train.py train_step): batched tensors, one Camera
-        for t in leaves:
+        for t in grad_leaves:  # (every leaf: a gradient left in place makes autograd launch an accumulation kernel per step)
             t.grad = None
         if is_asm:
             img = ren(*leaves, cam, phases=phases, wavelengths_rgb=wl)

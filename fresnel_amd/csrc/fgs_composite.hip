@@ -947,7 +947,10 @@ __global__ __launch_bounds__(256) void k_phase_bwd(
                 Pbar -= Pb * pc + t_ph;  // = Pb (1 - pc) - pd0bar sg inside the bbox, unchanged outside (Pb = G = 0 there)
                 const float dm = -0.5f * (rbar * raw);
                 const float dmx = dm * dx, dmy = dm * dy;
-                const float vals[11] = {-(2.0f * ca * dmx + cbc * dmy), -(cbc * dmx + 2.0f * cd * dmy), dmx * dx, dmx * dy, dmy * dy,
+                // slots 0 / 1: the FIRST MOMENTS of dL/dm' (m' = K m, the blend path's convention: dm / K = -2 ln2 dm) -- dL/d(u, v) =
+                // -K conic_sym (moments) is formed once per Gaussian, in double, by k_project_bwd (two multiplies here instead of the
+                // conic products; the same chain as the blend backward's rows)
+                const float vals[11] = {dmx * -1.38629436111989061883f, dmy * -1.38629436111989061883f, dmx * dx, dmx * dy, dmy * dy,
                                         v_op, v_r, v_g, v_b, v_d, v_ph};
                 const float tot = wave_sum11_addtid(red, vals, lane);
                 if ((lane & 3u) == 3u && lane < 44u && e < dcap)

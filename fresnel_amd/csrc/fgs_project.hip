@@ -594,7 +594,7 @@ int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos
     hipLaunchKernelGGL(k_project_bwd<0>, dim3(grid), dim3(256), 0, st, total, p.d.num_gaussians,
                        p.d.num_cameras, (uint32_t)p.L.dup_capacity, cams, pos, scale, quat, depth_key, order, dup_off,
                        tile_count, grad_rows, g_pos, g_scale, g_quat, g_color, g_opacity, g_phase, nullptr, nullptr,
-                       0, 4u, rec);  // phase path: four rows per duplicate; rec: row geometry
+                       1, 4u, rec);  // phase path: four rows per duplicate (rec: row geometry); slots 0 / 1 = first moments
     FGS_LAUNCH_CHECK("k_project_bwd");
     return FGS_OK;
 }
