@@ -926,17 +926,15 @@ __global__ __launch_bounds__(256) void k_phase_bwd(
                 const float pcbar = Pb * dphi;
                 // d pc/d w, direct (1/A_i) plus through A_i (-w/A_i^2), equals A_{i-1}/A_i^2: kept in that cancellation-free
                 // form (the two parts cancel to ~0 for a pixel's first contribution)
-                float Ab = Abar;
-                float wbar = Ab + (gr * q1.z + gg * q1.w + gb * q2.x + gd * q2.y);
-                if (Ai >= 1e-6f) {
-                    wbar += pcbar * Aprev * rA * rA;
-                    Ab -= pcbar * w * rA * rA;
-                } else {
-                    wbar += pcbar * rA;
-                }
+                // (below the 1e-6 clamp of A_i, pc = w / 1e-6: d pc/d w = 1 / 1e-6 = rA and no dependence on A_{i-1}; selected per lane
+                // -- a divergent branch cost a save / restore of the exec mask per entry)
+                const float rA2 = rA * rA;
+                const bool big = Ai >= 1e-6f;
+                const float dpc_dw = big ? Aprev * rA2 : rA, dpc_dA = big ? w * rA2 : 0.0f;
+                const float wbar = Abar + (gr * q1.z + gg * q1.w + gb * q2.x + gd * q2.y) + pcbar * dpc_dw;
                 const float v_r = w * gr, v_g = w * gg, v_b = w * gb, v_d = w * gd;
                 const float abar = wbar * T;
-                Abar = Ab - wbar * alpha;  // (outside the bbox: w = alpha = pcbar = 0, Abar unchanged)
+                Abar = (Abar - pcbar * dpc_dA) - wbar * alpha;  // (outside the bbox: w = alpha = pcbar = 0, Abar unchanged)
                 const float rbar = (raw >= 0.0f && raw <= ALPHA_MAX) ? abar : 0.0f;  // clamp passes the gradient on the closed interval
                 const float v_op = rbar * Gint;
                 const float pdbar = -(rbar * Gop) * amp * PHASE_KAPPA * phase_sin(PHASE_KAPPA * pd);

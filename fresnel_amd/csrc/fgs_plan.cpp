@@ -22,7 +22,7 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     if (!d || !p) { fgs_set_error("null dims"); return FGS_EINVAL; }
-    if (d->batch < 1 || d->num_gaussians < 1 || d->width < 1 || d->height < 1 || d->width > 32768 ||
+    if (d->batch < 1 || d->batch > 65535 /* images are a grid dimension of the projection and the depth sort */ || d->num_gaussians < 1 || d->width < 1 || d->height < 1 || d->width > 32768 ||
         d->height > 32768 || !(d->max_radius > 0.0f) || !(d->max_radius <= 65536.0f) /* also rejects NaN / inf: the tile span
         below converts 2 * max_radius to int */ || (d->num_cameras != 1 && d->num_cameras != d->batch)) {
         fgs_set_error("invalid dims: B=%d N=%d W=%d H=%d max_radius=%g num_cameras=%d", d->batch,
