@@ -86,7 +86,7 @@ __device__ __forceinline__ void project_one(const float *__restrict__ V, float f
 }
 
 __global__ __launch_bounds__(256) void k_project(
-    int32_t total, int32_t N, int32_t W, int32_t H, int32_t num_cameras, float max_radius,
+    int32_t N, int32_t W, int32_t H, int32_t num_cameras, float max_radius,
     const float *__restrict__ cams, const float *__restrict__ pos, const float *__restrict__ scale,
     const float *__restrict__ quat, const float *__restrict__ color, const float *__restrict__ opacity,
     float *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ tile_count,
@@ -97,68 +97,68 @@ __global__ __launch_bounds__(256) void k_project(
     const int32_t n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     uint32_t key = 0xFFFFFFFFu;
     if (n < N) {
-    const int32_t idx = b * N + n;
-    const float *__restrict__ cam = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
-    const float p[3] = {pos[3 * idx], pos[3 * idx + 1], pos[3 * idx + 2]};
-    const float s[3] = {scale[3 * idx], scale[3 * idx + 1], scale[3 * idx + 2]};
-    const float4 q4 = reinterpret_cast<const float4 *>(quat)[idx];
-    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    const float fx = cam[16], fy = cam[17], cx = cam[18], cy = cam[19], nearp = cam[20], farp = cam[21];
-    Proj o;
-    project_one(cam, fx, fy, cx, cy, p, s, q, o);
+        const int32_t idx = b * N + n;
+        const float *__restrict__ cam = cams + (num_cameras > 1 ? b : 0) * FGS_CAMERA_FLOATS;
+        const float p[3] = {pos[3 * idx], pos[3 * idx + 1], pos[3 * idx + 2]};
+        const float s[3] = {scale[3 * idx], scale[3 * idx + 1], scale[3 * idx + 2]};
+        const float4 q4 = reinterpret_cast<const float4 *>(quat)[idx];
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float fx = cam[16], fy = cam[17], cx = cam[18], cy = cam[19], nearp = cam[20], farp = cam[21];
+        Proj o;
+        project_one(cam, fx, fy, cx, cy, p, s, q, o);
 
-    // radius, DR:471-485
-    const float tr = o.a + o.d;
-    float det = o.a * o.d - o.b * o.c;
-    det = clamp_min(det, 1e-6f);
-    const float disc = clamp_min(tr * tr - 4.0f * det, 0.0f);
-    const float lam = __fdiv_rn(tr + __fsqrt_rn(disc), 2.0f);
-    float r = 3.0f * __fsqrt_rn(clamp_min(lam, 1e-6f));
-    r = clamp_max(r, max_radius);
-    // visibility, DR:541-543
-    const bool vis = (o.dep > nearp) && (o.dep < farp) && (o.u + r > 0.0f) && (o.u - r < (float)W) &&
-                     (o.v + r > 0.0f) && (o.v - r < (float)H);
-    // bbox in fp64, DR:594-597
-    int32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-    if (vis) {
-        const double ud = (double)o.u, vd = (double)o.v, rd = (double)r;
-        double e;
-        e = trunc(ud - rd); x0 = e < 0.0 ? 0 : (e > (double)W ? W : (int32_t)e);
-        e = trunc(ud + rd) + 1.0; x1 = e > (double)W ? W : (e < 0.0 ? 0 : (int32_t)e);
-        e = trunc(vd - rd); y0 = e < 0.0 ? 0 : (e > (double)H ? H : (int32_t)e);
-        e = trunc(vd + rd) + 1.0; y1 = e > (double)H ? H : (e < 0.0 ? 0 : (int32_t)e);
-    }
-    uint32_t ntiles = 0;
-    if (vis && x0 < x1 && y0 < y1)
-        ntiles = (uint32_t)(((x1 - 1) / tile_w - x0 / tile_w + 1) * ((y1 - 1) / FGS_TILE - y0 / FGS_TILE + 1));
-    // inverse of cov + 1e-4 I, DR:578-579 (closed form)
-    const float ar = o.a + 1e-4f, dr = o.d + 1e-4f;
-    const float detr = ar * dr - o.b * o.c;
-    const float ia = __fdiv_rn(dr, detr);
-    const float ibc = __fdiv_rn(-o.b, detr) + __fdiv_rn(-o.c, detr);
-    const float id = __fdiv_rn(ar, detr);
-
-    float4 *out = reinterpret_cast<float4 *>(rec + (size_t)idx * FGS_REC_FLOATS);
-    out[0] = make_float4(o.u, o.v, ia, ibc);
-    out[1] = make_float4(id, opacity[idx], color[3 * idx], color[3 * idx + 1]);
-    out[2] = make_float4(color[3 * idx + 2], o.dep, __uint_as_float((uint32_t)x0 | ((uint32_t)x1 << 16)),
-                         __uint_as_float((uint32_t)y0 | ((uint32_t)y1 << 16)));
-    key = vis ? fgs_float_key(o.dep) : 0xFFFFFFFFu;
-    depth_key[idx] = key;
-    tile_count[idx] = ntiles;
-    if (layer) {
-        // nearest depth plane, DR:1106 (torch.linspace) + DR:1147-1148 (first argmin of |depth - plane|)
-        const float step = (plane_far - plane_near) / (float)(num_planes - 1);
-        int32_t best = 0;
-        float bd = 3.4e38f;
-        for (int32_t k = 0; k < num_planes; ++k) {
-            const float pk = (k < num_planes / 2) ? plane_near + step * (float)k
-                                                  : plane_far - step * (float)(num_planes - 1 - k);
-            const float dd = fabsf(o.dep - pk);
-            if (dd < bd) { bd = dd; best = k; }
+        // radius, DR:471-485
+        const float tr = o.a + o.d;
+        float det = o.a * o.d - o.b * o.c;
+        det = clamp_min(det, 1e-6f);
+        const float disc = clamp_min(tr * tr - 4.0f * det, 0.0f);
+        const float lam = __fdiv_rn(tr + __fsqrt_rn(disc), 2.0f);
+        float r = 3.0f * __fsqrt_rn(clamp_min(lam, 1e-6f));
+        r = clamp_max(r, max_radius);
+        // visibility, DR:541-543
+        const bool vis = (o.dep > nearp) && (o.dep < farp) && (o.u + r > 0.0f) && (o.u - r < (float)W) &&
+                         (o.v + r > 0.0f) && (o.v - r < (float)H);
+        // bbox in fp64, DR:594-597
+        int32_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        if (vis) {
+            const double ud = (double)o.u, vd = (double)o.v, rd = (double)r;
+            double e;
+            e = trunc(ud - rd); x0 = e < 0.0 ? 0 : (e > (double)W ? W : (int32_t)e);
+            e = trunc(ud + rd) + 1.0; x1 = e > (double)W ? W : (e < 0.0 ? 0 : (int32_t)e);
+            e = trunc(vd - rd); y0 = e < 0.0 ? 0 : (e > (double)H ? H : (int32_t)e);
+            e = trunc(vd + rd) + 1.0; y1 = e > (double)H ? H : (e < 0.0 ? 0 : (int32_t)e);
         }
-        layer[idx] = (uint32_t)best;
-    }
+        uint32_t ntiles = 0;
+        if (vis && x0 < x1 && y0 < y1)
+            ntiles = (uint32_t)(((x1 - 1) / tile_w - x0 / tile_w + 1) * ((y1 - 1) / FGS_TILE - y0 / FGS_TILE + 1));
+        // inverse of cov + 1e-4 I, DR:578-579 (closed form)
+        const float ar = o.a + 1e-4f, dr = o.d + 1e-4f;
+        const float detr = ar * dr - o.b * o.c;
+        const float ia = __fdiv_rn(dr, detr);
+        const float ibc = __fdiv_rn(-o.b, detr) + __fdiv_rn(-o.c, detr);
+        const float id = __fdiv_rn(ar, detr);
+
+        float4 *out = reinterpret_cast<float4 *>(rec + (size_t)idx * FGS_REC_FLOATS);
+        out[0] = make_float4(o.u, o.v, ia, ibc);
+        out[1] = make_float4(id, opacity[idx], color[3 * idx], color[3 * idx + 1]);
+        out[2] = make_float4(color[3 * idx + 2], o.dep, __uint_as_float((uint32_t)x0 | ((uint32_t)x1 << 16)),
+                             __uint_as_float((uint32_t)y0 | ((uint32_t)y1 << 16)));
+        key = vis ? fgs_float_key(o.dep) : 0xFFFFFFFFu;
+        depth_key[idx] = key;
+        tile_count[idx] = ntiles;
+        if (layer) {
+            // nearest depth plane, DR:1106 (torch.linspace) + DR:1147-1148 (first argmin of |depth - plane|)
+            const float step = (plane_far - plane_near) / (float)(num_planes - 1);
+            int32_t best = 0;
+            float bd = 3.4e38f;
+            for (int32_t k = 0; k < num_planes; ++k) {
+                const float pk = (k < num_planes / 2) ? plane_near + step * (float)k
+                                                      : plane_far - step * (float)(num_planes - 1 - k);
+                const float dd = fabsf(o.dep - pk);
+                if (dd < bd) { bd = dd; best = k; }
+            }
+            layer[idx] = (uint32_t)best;
+        }
     }
     // Which bits of the depth keys VARY over an image's visible Gaussians decides how many radix passes its depth sort needs
     // (fgs_sort.hip: the keys are compressed to those bits -- zone-snapped depths, BASELINE config 4, differ in 3 bits and sort
@@ -554,9 +554,8 @@ __global__ __launch_bounds__(256) void k_project_bwd(
 int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                        const float *quat, const float *color, const float *opacity, char *saved,
                        hipStream_t st, int num_planes, float plane_near, float plane_far) {
-    const int32_t total = p.d.batch * p.d.num_gaussians;
     const dim3 grid((unsigned)((p.d.num_gaussians + 255) / 256), (unsigned)p.d.batch);
-    hipLaunchKernelGGL(k_project, grid, dim3(256), 0, st, total, p.d.num_gaussians, p.d.width,
+    hipLaunchKernelGGL(k_project, grid, dim3(256), 0, st, p.d.num_gaussians, p.d.width,
                        p.d.height, p.d.num_cameras, p.d.max_radius, cams, pos, scale, quat, color, opacity,
                        reinterpret_cast<float *>(saved + p.L.rec),
                        reinterpret_cast<uint32_t *>(saved + p.L.depth_key),
