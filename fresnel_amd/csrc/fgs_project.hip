@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
         // rows_per_dup gradient rows per duplicate (4 on the phase path: one per sub-tile wave), contiguous
         const uint32_t cnt = tile_count[idx] * rows_per_dup, off = dup_off[idx] * rows_per_dup;
         if (MODE == 0) {  // (the blend path's rows are summed by k_row_sum: PRESUM)
-            // phase path: FOUR rows per duplicate, one per 8x8 sub-tile wave of k_composite_bwd_phase, which writes
+            // phase path: FOUR rows per duplicate, one per 8x8 sub-tile wave of k_phase_bwd, which writes
             // only the rows of sub-tiles the bbox touches -- the same integer test decides here which rows exist
             // (lane `sub` of the quad owns sub-tile `sub` of every duplicate)
             const uint32_t bbx = __float_as_uint(rec[(size_t)idx * FGS_REC_FLOATS + R_BBX]);
