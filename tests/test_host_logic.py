@@ -251,6 +251,23 @@ def test_image_dataset_host_item_does_not_decode_the_saag_binaries(tmp_path, mon
     assert img.shape == (3, 16, 16) and feats.shape == (37, 37, 384) and dep.shape == (1, 16, 16)
 
 
+def test_harness_selects_the_zone_key_depth_sort_with_fresnel_zones():
+    """--use_fresnel_zones snaps the decoder's depths to a few values (GDM:834-841): the harness then asks the renderer for the
+    zone-key depth sort (FgsDims.sort_mode = 1, one radix pass instead of four); without the flag nothing is overridden."""
+    from fresnel_amd.train import TrainingConfig, default_renderer_factory
+    ren, cam = default_renderer_factory(TrainingConfig(image_size=64, device="cpu", use_fresnel_zones=True), "cpu")
+    assert ren.tuning == dict(sort_mode=1) and cam.width == 64
+    ren, _ = default_renderer_factory(TrainingConfig(image_size=64, device="cpu"), "cpu")
+    assert ren.tuning is None
+    from fresnel_amd import _binding as B
+    d = B.make_dims(2, 100, 64, 64, tuning=dict(sort_mode=1))
+    assert d.sort_mode == 1 and B.make_dims(2, 100, 64, 64).sort_mode == 0
+    with pytest.raises(B.FgsError):
+        B.saved_layout(B.make_dims(2, 100, 64, 64, tuning=dict(sort_mode=2)))
+    with pytest.raises(B.FgsError):
+        B.saved_layout(B.make_dims(70000, 4, 16, 16))   # images are a grid dimension: <= 65535
+
+
 def test_wave_renderers_follow_their_background_buffer():
     """the kernels take the background as host floats; the module must notice when the registered buffer is
     edited in place, replaced, or loaded from a state dict (the reference reads the buffer on every call), and must NOT
