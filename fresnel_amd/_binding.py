@@ -56,7 +56,7 @@ class FgsAsmDims(ctypes.Structure):
                 ("max_radius", ctypes.c_float), ("background", ctypes.c_float * 3),
                 ("num_planes", ctypes.c_int32), ("depth_near", ctypes.c_float),
                 ("depth_far", ctypes.c_float), ("focal_depth", ctypes.c_float),
-                ("pixel_pitch", ctypes.c_float), ("phase_channels", ctypes.c_int32),
+                ("pixel_pitch", ctypes.c_double), ("phase_channels", ctypes.c_int32),
                 ("num_cameras", ctypes.c_int32), ("bin_mode", ctypes.c_int32)]
 
 
@@ -117,8 +117,8 @@ def load():
     lib.fgs_gather_forward.restype = lib.fgs_gather_backward.restype = ctypes.c_int
     f32 = ctypes.c_float
     lib.fgs_asm_propagate_workspace_bytes.argtypes = [i32, i32, i32, cp(ctypes.c_size_t)]
-    lib.fgs_asm_propagate_forward.argtypes = [i32, i32, i32, f32, i32] + [vp] * 7
-    lib.fgs_asm_propagate_backward.argtypes = [i32, i32, i32, f32, i32] + [vp] * 9
+    lib.fgs_asm_propagate_forward.argtypes = [i32, i32, i32, ctypes.c_double, i32] + [vp] * 7   # (the pitch is a double: fgs.h)
+    lib.fgs_asm_propagate_backward.argtypes = [i32, i32, i32, ctypes.c_double, i32] + [vp] * 9
     lib.fgs_spectral_workspace_bytes.argtypes = [cp(FgsSpectralDims), cp(ctypes.c_size_t), cp(ctypes.c_size_t)]
     lib.fgs_spectral_loss_forward.argtypes = [cp(FgsSpectralDims)] + [vp] * 8
     lib.fgs_spectral_loss_backward.argtypes = [cp(FgsSpectralDims)] + [vp] * 12

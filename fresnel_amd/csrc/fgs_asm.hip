@@ -70,7 +70,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int make_asm_plan(const FgsAsmDims *a, AsmPlan *p, bool need_fft) {
     if (!a) { fgs_set_error("null dims"); return FGS_EINVAL; }
     if (a->num_planes < 1 || a->num_planes > 64 || (a->phase_channels != 1 && a->phase_channels != 3) ||
-        !(a->pixel_pitch > 0.0f)) {
+        !(a->pixel_pitch > 0.0)) {
         fgs_set_error("invalid ASM dims: planes=%d phase_channels=%d pitch=%g", a->num_planes, a->phase_channels,
                       (double)a->pixel_pitch);
         return FGS_EINVAL;
@@ -1289,8 +1289,9 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
     const uint32_t grid = (uint32_t)B * P * p.base.tiles;
     float *ccs = reinterpret_cast<float *>(sv + p.v_ccs);
     const uint32_t ngauss = (uint32_t)B * (uint32_t)a.num_gaussians;
-    const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
-    const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
+    // torch.fft.fftfreq(n, d) = arange * (float)(1.0 / (n * d)) with d the reference's Python float (a double): DR:959-961
+    const float inv_ndx = (float)(1.0 / ((double)W * a.pixel_pitch));
+    const float inv_ndy = (float)(1.0 / ((double)H * a.pixel_pitch));
     {
         // the column kernels read H at the first plane of each plane group only (and D); the rocFFT 2-D path reads every plane
         const int pstride = p.col_logn ? (P + p.col_pg - 1) / p.col_pg : 1, np = (P + pstride - 1) / pstride;
@@ -1398,8 +1399,9 @@ int fgs_asm_backward(const FgsAsmDims *dims, const float *cameras, const float *
     FGS_LAUNCH_CHECK("k_asm_output_bwd2");
     // adjoint of the unnormalised inverse FFT is the unnormalised forward FFT
     if ((rc = fgs_fft2_exec(H, W, B * 3, gtot, HIPFFT_FORWARD, sc + p.c_fftwork, st))) return rc;
-    const float inv_ndx = (float)(1.0 / ((double)W * (double)a.pixel_pitch));
-    const float inv_ndy = (float)(1.0 / ((double)H * (double)a.pixel_pitch));
+    // torch.fft.fftfreq(n, d) = arange * (float)(1.0 / (n * d)) with d the reference's Python float (a double): DR:959-961
+    const float inv_ndx = (float)(1.0 / ((double)W * a.pixel_pitch));
+    const float inv_ndy = (float)(1.0 / ((double)H * a.pixel_pitch));
     unsigned nwl = (unsigned)(((size_t)B * HW + 255) / 256);
     if (p.col_logn) {
         // gF = gAcc conj(H) and the inverse transform down the columns in one pass (k_colfft_bwd), then rocFFT rows

@@ -291,13 +291,13 @@ int fgs_asm_propagate_workspace_bytes(int32_t height, int32_t width, int32_t cha
     return FGS_OK;
 }
 
-int fgs_asm_propagate_forward(int32_t height, int32_t width, int32_t channels, float pixel_pitch, int32_t band_limit,
+int fgs_asm_propagate_forward(int32_t height, int32_t width, int32_t channels, double pixel_pitch, int32_t band_limit,
                               const float *field, const float *z, const float *wavelengths, float *out,
                               float *spectrum, void *scratch, void *stream) {
     size_t sb;
     int rc = fgs_asm_propagate_workspace_bytes(height, width, channels, &sb);
     if (rc) return rc;
-    if (!field || !z || !wavelengths || !out || !spectrum || !scratch || !(pixel_pitch > 0.0f)) {
+    if (!field || !z || !wavelengths || !out || !spectrum || !scratch || !(pixel_pitch > 0.0)) {
         fgs_set_error("fgs_asm_propagate_forward: null pointer / bad pitch");
         return FGS_EINVAL;
     }
@@ -308,15 +308,15 @@ int fgs_asm_propagate_forward(int32_t height, int32_t width, int32_t channels, f
     if (e != hipSuccess) { fgs_set_error("propagate copy: %s", hipGetErrorString(e)); return FGS_ELAUNCH; }
     float2 *spec = reinterpret_cast<float2 *>(spectrum), *o = reinterpret_cast<float2 *>(out);
     if ((rc = fgs_fft2_exec(height, width, channels, spec, HIPFFT_FORWARD, work, st))) return rc;
-    const float inv_ndx = (float)(1.0 / ((double)width * (double)pixel_pitch));
-    const float inv_ndy = (float)(1.0 / ((double)height * (double)pixel_pitch));
+    const float inv_ndx = (float)(1.0 / ((double)width * pixel_pitch));
+    const float inv_ndy = (float)(1.0 / ((double)height * pixel_pitch));
     hipLaunchKernelGGL(k_prop_apply, dim3((unsigned)((n + RT - 1) / RT)), dim3(RT), 0, st, width, height, channels, inv_ndx,
                        inv_ndy, band_limit, z, wavelengths, spec, o);
     FGS_LAUNCH_CHECK("k_prop_apply");
     return fgs_fft2_exec(height, width, channels, o, HIPFFT_BACKWARD, work, st);
 }
 
-int fgs_asm_propagate_backward(int32_t height, int32_t width, int32_t channels, float pixel_pitch, int32_t band_limit,
+int fgs_asm_propagate_backward(int32_t height, int32_t width, int32_t channels, double pixel_pitch, int32_t band_limit,
                                const float *spectrum, const float *z, const float *wavelengths, const float *g_out,
                                float *g_field, float *g_z, float *g_wavelengths, void *scratch, void *stream) {
     size_t sb;
@@ -337,8 +337,8 @@ int fgs_asm_propagate_backward(int32_t height, int32_t width, int32_t channels, 
     if ((rc = fgs_fft2_exec(height, width, channels, g, HIPFFT_FORWARD, work, st))) return rc;
     unsigned gx = part_blocks(HW);
     if ((size_t)gx * channels > MAX_PART) gx = MAX_PART / channels ? MAX_PART / channels : 1;
-    const float inv_ndx = (float)(1.0 / ((double)width * (double)pixel_pitch));
-    const float inv_ndy = (float)(1.0 / ((double)height * (double)pixel_pitch));
+    const float inv_ndx = (float)(1.0 / ((double)width * pixel_pitch));
+    const float inv_ndy = (float)(1.0 / ((double)height * pixel_pitch));
     hipLaunchKernelGGL(k_prop_apply_bwd, dim3(gx, channels), dim3(RT), 0, st, width, height, channels, inv_ndx, inv_ndy,
                        band_limit, z, wavelengths, reinterpret_cast<const float2 *>(spectrum), g, part);
     FGS_LAUNCH_CHECK("k_prop_apply_bwd");

@@ -168,7 +168,9 @@ typedef struct FgsAsmDims {
     int32_t num_planes;      /* num_depth_planes, DR:1088 */
     float depth_near, depth_far; /* depth_range, DR:1089 */
     float focal_depth;       /* DR:1090 */
-    float pixel_pitch;       /* DR:1091 */
+    double pixel_pitch;      /* DR:1091.  DOUBLE, like the Python float the reference hands to torch.fft.fftfreq(n, d): the frequency
+                                grid is k * (float)(1.0 / (n * d)), and a pitch rounded to fp32 first moves that factor by an ulp
+                                for some (n, d) -- 96 samples at 1/200 -- which the near-evanescent terms of dL/dlambda feel */
     int32_t phase_channels;  /* 1: phases (B,N); 3: phases (B,N,3) */
     int32_t num_cameras;     /* 1 or B */
     int32_t bin_mode;        /* list building, as FgsDims.bin_mode: 0 = automatic | 1 = direct (rank masks; the depth order is
@@ -217,10 +219,10 @@ int fgs_wave_backward(const FgsWaveDims *dims, const float *cameras, const float
  * fft2(field) and is what the backward needs; scratch from fgs_asm_propagate_workspace_bytes.  band_limit: clamp
  * 1/l^2 - fx^2 - fy^2 at 0 (DR:993-994).  dL/dwavelength is taken as 0 where the clamp binds (see fgs_asm_backward). */
 int fgs_asm_propagate_workspace_bytes(int32_t height, int32_t width, int32_t channels, size_t *scratch_bytes);
-int fgs_asm_propagate_forward(int32_t height, int32_t width, int32_t channels, float pixel_pitch, int32_t band_limit,
+int fgs_asm_propagate_forward(int32_t height, int32_t width, int32_t channels, double pixel_pitch, int32_t band_limit,
                               const float *field, const float *z, const float *wavelengths, float *out,
                               float *spectrum, void *scratch, void *stream);
-int fgs_asm_propagate_backward(int32_t height, int32_t width, int32_t channels, float pixel_pitch, int32_t band_limit,
+int fgs_asm_propagate_backward(int32_t height, int32_t width, int32_t channels, double pixel_pitch, int32_t band_limit,
                                const float *spectrum, const float *z, const float *wavelengths, const float *g_out,
                                float *g_field, float *g_z, float *g_wavelengths, void *scratch, void *stream);
 
