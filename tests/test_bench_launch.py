@@ -102,3 +102,31 @@ def test_parent_imports_nothing_gpu_related_before_launching():
     assert "import torch" not in head.replace("import torch as _torch", "") and "fresnel_amd" not in head.split('"""')[2]
     main_src = src[src.index("def main("):]
     assert main_src.index("launch_ranks(args, argv)") < main_src.index("_import_compute()")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["config3", "config4", "config5"])
+def test_bench_line_on_the_gpu(workload):
+    """The line the driver records, from a short real run: one JSON object on stdout with the contract's fields, both timed
+    regions, the roofline object of the dominant kernel (hipEvent-timed in the library) and the workload's name."""
+    r = subprocess.run([sys.executable, BENCH, "--workload", workload, "--steps", "3", "--warmup", "2", "--spinup-ms", "60",
+                        "--no-cpu-baseline"] + (["--images-per-gpu", "2"] if workload == "config3" else []),
+                       capture_output=True, text=True, env=_clean_env(), timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_cold", "value_cold", "spinup_steps",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] > 1e8 and d["ms_per_step"] > 0 and d["ms_per_step_cold"] > 0 and d["spinup_steps"] >= 20
+    assert workload in d["config"]["workload"] and d["config"]["pairs_per_step"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] in ("valu", "hbm") and rf["unit"] in ("TFLOP/s", "GB/s") and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
+    assert set(rf["stage_avg_ms"]) >= {"project", "project_bwd"} and rf["stage_avg_ms_cold"]
+    assert rf["kernel"].startswith({"config3": "k_composite_bwd", "config4": "k_phase_bwd", "config5": ""}[workload])
