@@ -35,16 +35,15 @@ SOURCES = {
     "fgs_sort.hip": [],
     "fgs_bin.hip": [],
     "fgs_composite.hip": ["-ffast-math", "-fno-finite-math-only"] + NO_SLP + SCHED,
-    # no fast-math here: the transfer function needs the accurate sincosf.  No FMA contraction either (round 4): with the compiler
-    # free to fuse a * b + c across the field chain, dL/dlambda -- a sum over all frequencies that cancels to a fraction of its
-    # terms and weights the near-evanescent ones by 1 / kz -- came out 2e-4 from the reference on the K5 fixture (96 x 32 frame,
-    # rocFFT 2-D path) where the reference's own fp32 run is 4e-6 from its fp64 run, and every other K5 tensor 2-3x further out
-    # than the reference's fp32 run; with -ffp-contract=off: 4.7e-6, and the HIP path tracks the reference's fp32 run on K3-K5
-    # (profiles/r04_dlambda_probe.txt, r04_referee_table.txt).  Which fusion does it could not be isolated per kernel
-    # (`#pragma clang fp contract(off)` changes nothing: the AMDGPU backend fuses under the global setting); it is in neither
-    # of the two VALU-bound loops, so those have their FMAs WRITTEN OUT (k_asm_splat's pass, fgs_colfft.h's butterflies) and the
-    # flag costs nothing: config 5 at 8 images 1.845 ms contracted / 1.958 with the flag alone (splat kernels +10 %) / 1.852
-    # with the explicit FMAs; 0.437 / 0.462 / 0.438 at one image (profiles/r04_ab_config5_contract_off.txt).
+    # no fast-math here: the transfer function needs the accurate sincosf.  No FMA contraction either (round 4): with kz^2 =
+    # 1/l^2 - fx^2 - fy^2 contracted, dL/dlambda -- which weights the near-evanescent frequencies by 1 / kz -- came out 2e-4 from
+    # the reference on the K5 fixture where the reference's own fp32 run is 4e-6 from its fp64 run, and every other K5 tensor 2-3x
+    # further out than the reference's fp32 run.  kz^2 itself is protected by fgs_kz2 (opaque values: hipcc's __fmul_rn do NOT stop
+    # contraction, and `#pragma clang fp contract(off)` does nothing under the global setting); the flag makes the rest of the field
+    # chain independent of the compiler's fusion choices as well (profiles/r04_dlambda_probe.txt, r04_referee_table.txt).  The two
+    # VALU-bound loops have their FMAs WRITTEN OUT (k_asm_splat's pass, fgs_colfft.h's butterflies), so the flag costs nothing:
+    # config 5 at 8 images 1.845 ms contracted / 1.958 with the flag alone (splat kernels +10 %) / 1.852 with the explicit FMAs;
+    # 0.437 / 0.462 / 0.438 at one image (profiles/r04_ab_config5_contract_off.txt).
     "fgs_asm.hip": NO_SLP + ["-ffp-contract=off"],
     "fgs_gather.hip": [],
     "fgs_fft.hip": NO_SLP,

@@ -887,9 +887,7 @@ __global__ __launch_bounds__(256) void k_asm_max(size_t HW, float inv_hw, const 
     const int b = blockIdx.y;
     float mx = 0.0f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < 3 * HW; i += (size_t)gridDim.x * 256) {
-        const float2 u = total[(size_t)b * 3 * HW + i];
-        const float ur = u.x * inv_hw, ui = u.y * inv_hw;
-        mx = fmaxf(mx, sqrtf(ur * ur + ui * ui + 1e-8f));
+        mx = fmaxf(mx, fgs_asm_amplitude(fgs_asm_intensity(total[(size_t)b * 3 * HW + i], inv_hw)));
     }
     mx = block_max_256(mx);
     if (threadIdx.x == 0) pmax[(size_t)b * RED_BLOCKS + blockIdx.x] = mx;
@@ -905,9 +903,8 @@ __device__ __forceinline__ void pixel_forward(const float2 u[3], float inv_hw, f
     o.asum = 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float ur = u[c].x * inv_hw, ui = u[c].y * inv_hw;
-        const float I = ur * ur + ui * ui;
-        o.r[c] = sqrtf(I + 1e-8f);
+        const float I = fgs_asm_intensity(u[c], inv_hw);
+        o.r[c] = fgs_asm_amplitude(I);  // (compared for equality with the image's maximum in the backward: fgs_internal.h)
         o.a[c] = sqrtf(I);  // |U| of the complex field, DR:1327
         o.asum += o.a[c];
         const float q = o.r[c] / o.M;
@@ -1352,11 +1349,16 @@ int fgs_asm_forward(const FgsAsmDims *dims, const float *cameras, const float *p
                            total);
         FGS_LAUNCH_CHECK("k_asm_accumulate");
     }
-    if ((rc = fgs_fft2_exec(H, W, B * 3, total, HIPFFT_BACKWARD, sc + p.c_fftwork, st))) return rc;
     const float inv_hw = 1.0f / (float)HW;
     float *pmax = reinterpret_cast<float *>(sc + p.c_part);
-    hipLaunchKernelGGL(k_asm_max, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, inv_hw, total, pmax);
-    FGS_LAUNCH_CHECK("k_asm_max");
+    // the inverse transform's column pass leaves the per-image amplitude maxima as block partials (power-of-two heights whose
+    // column tiles fit the RED_BLOCKS slots); otherwise k_asm_max reduces them in a launch of its own
+    bool max_fused = false;
+    if ((rc = fgs_fft2_inverse_with_max(H, W, B, total, sc + p.c_fftwork, pmax, RED_BLOCKS, inv_hw, &max_fused, st))) return rc;
+    if (!max_fused) {
+        hipLaunchKernelGGL(k_asm_max, dim3(RED_BLOCKS, B), dim3(256), 0, st, HW, inv_hw, total, pmax);
+        FGS_LAUNCH_CHECK("k_asm_max");
+    }
     hipLaunchKernelGGL(k_asm_output, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, HW, inv_hw,
                        a.background[0], a.background[1], a.background[2], total, pmax, scal, out_rgb, seg_off_d,
                        (uint32_t)P * (uint32_t)p.base.tiles);

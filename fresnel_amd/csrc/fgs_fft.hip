@@ -92,8 +92,13 @@ int fgs_fft_rows_work_bytes(int W, int rows, size_t *bytes) { return fgs_fft_wor
 // columns (fgs_colfft.h), one read and one write of the data.  Other heights: rocFFT's 2-D plan.  Unnormalised both ways.
 namespace {
 
-template <int LOGN, int TC, bool INV>
-__global__ __launch_bounds__((1 << LOGN) * TC / 8) void k_colfft_plain(int W, float2 *__restrict__ data) {
+// AMAX (inverse only): the block also leaves the maximum of sqrt(|u / (H W)|^2 + 1e-8) over its tile in
+// amax[(field / 3) * slots + (field % 3) * gridDim.x + blockIdx.x] -- the per-image maximum of the ASM renderer's amplitude
+// (DR:1316-1322) as block partials, for free in the pass that produces the values (k_asm_max was a launch of its own: 10 us at one
+// config-5 image); the value is fgs_asm_amplitude's, as everywhere.  Slots the tiles do not fill are zeroed by block (0, 3 b).
+template <int LOGN, int TC, bool INV, bool AMAX = false>
+__global__ __launch_bounds__((1 << LOGN) * TC / 8) void k_colfft_plain(int W, float2 *__restrict__ data, float *__restrict__ amax = nullptr,
+                                                                       int slots = 0, float inv_hw = 0.0f) {
     constexpr int N = 1 << LOGN, PER = 8, NT = N * TC / PER, E1 = N / 8;
     constexpr bool INNER = lds_fft_inner_in_registers<LOGN>();
     __shared__ float2 x[N][TC];
@@ -142,6 +147,29 @@ __global__ __launch_bounds__((1 << LOGN) * TC / 8) void k_colfft_plain(int W, fl
 #pragma unroll
             for (int e = 0; e < PER; ++e) f[(size_t)(q + e * E1) * W] = v[e];
         }
+        if constexpr (AMAX) {
+            float mx = 0.0f;
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < PER; ++e) {
+                    mx = fmaxf(mx, fgs_asm_amplitude(fgs_asm_intensity(v[e], inv_hw)));  // (the value the backward compares with)
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            __shared__ float wmx[NT / 64 > 0 ? NT / 64 : 1];
+            if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
+            __syncthreads();
+            const int field = blockIdx.y, img = field / 3, ch = field - 3 * img;
+            float *dst = amax + (size_t)img * slots;
+            if (threadIdx.x == 0) {
+                float m = wmx[0];
+                for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, wmx[w]);
+                dst[ch * gridDim.x + blockIdx.x] = m;
+            }
+            if (ch == 0 && blockIdx.x == 0)
+                for (int i = 3 * (int)gridDim.x + threadIdx.x; i < slots; i += NT) dst[i] = 0.0f;
+        }
     }
 }
 
@@ -151,11 +179,12 @@ int colfft_logn(int H) {
     return 0;
 }
 
-template <bool INV>
-int launch_colfft_plain(int lg, int W, int batch, float2 *data, hipStream_t st) {
+template <bool INV, bool AMAX = false>
+int launch_colfft_plain(int lg, int W, int batch, float2 *data, hipStream_t st, float *amax = nullptr, int slots = 0,
+                        float inv_hw = 0.0f) {
 #define FGS_CP(LG, TCV)                                                                                              \
-    hipLaunchKernelGGL((k_colfft_plain<LG, TCV, INV>), dim3((unsigned)((W + TCV - 1) / TCV), (unsigned)batch),         \
-                       dim3((1 << LG) * TCV / 8), 0, st, W, data)
+    hipLaunchKernelGGL((k_colfft_plain<LG, TCV, INV, AMAX>), dim3((unsigned)((W + TCV - 1) / TCV), (unsigned)batch),   \
+                       dim3((1 << LG) * TCV / 8), 0, st, W, data, amax, slots, inv_hw)
     switch (lg) {
         case 6: FGS_CP(6, 16); break;
         case 7: FGS_CP(7, 16); break;
@@ -182,4 +211,18 @@ int fgs_fft2_exec(int H, int W, int batch, float2 *data, int dir, void *work, hi
     if (rc) return rc;
     return dir == HIPFFT_FORWARD ? launch_colfft_plain<false>(lg, W, batch, data, st)
                                  : launch_colfft_plain<true>(lg, W, batch, data, st);
+}
+
+// Inverse 2-D transform of `images` x 3 fields that also leaves every image's amplitude maximum as `slots` block partials in
+// amax[image][slots] (see k_colfft_plain<..., AMAX>).  *fused = false (nothing written to amax) when the frame takes rocFFT's
+// 2-D plan or its column tiles do not fit the slots: the caller then runs its own reduction.
+int fgs_fft2_inverse_with_max(int H, int W, int images, float2 *data, void *work, float *amax, int slots, float inv_hw,
+                              bool *fused, hipStream_t st) {
+    const int lg = colfft_logn(H);
+    const int tiles = (W + (lg == 10 ? 8 : 16) - 1) / (lg == 10 ? 8 : 16);
+    *fused = lg != 0 && 3 * tiles <= slots;
+    if (!*fused) return fgs_fft2_exec(H, W, images * 3, data, HIPFFT_BACKWARD, work, st);
+    const int rc = fgs_fft_rows_exec(W, images * 3 * H, data, HIPFFT_BACKWARD, work, st);
+    if (rc) return rc;
+    return launch_colfft_plain<true, true>(lg, W, images * 3, data, st, amax, slots, inv_hw);
 }

@@ -66,6 +66,9 @@ int fgs_fft_rows_work_bytes(int W, int rows, size_t *bytes);
 // 2-D transform, rocFFT rows + our own column pass for power-of-two heights 64 ... 1024 (else rocFFT's 2-D plan)
 int fgs_fft2_work_bytes(int H, int W, int batch, size_t *bytes);
 int fgs_fft2_exec(int H, int W, int batch, float2 *data, int dir, void *work, hipStream_t st);
+// inverse transform of images x 3 fields + per-image block maxima of sqrt(|u inv_hw|^2 + 1e-8) (fgs_fft.hip); *fused tells whether amax was written
+int fgs_fft2_inverse_with_max(int H, int W, int images, float2 *data, void *work, float *amax, int slots, float inv_hw,
+                              bool *fused, hipStream_t st);
 int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, float *out_rgb,
                              float *out_depth, hipStream_t st);
 int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *saved, char *scratch,
@@ -93,12 +96,32 @@ __device__ __forceinline__ uint32_t fgs_float_key(float f) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// A product or sum the compiler must not fuse into a neighbouring operation: the value passes through an empty asm, which makes
+// it opaque.  (hipcc's __fmul_rn / __fadd_rn are plain operators -- they do NOT stop FMA contraction -- and a
+// `#pragma clang fp contract(off)` does not either in a unit compiled with the default -ffp-contract=fast: the AMDGPU backend
+// fuses under the global setting.  Found in round 4: a "separately rounded" expression written with the intrinsics came out
+// as v_mul + v_fmac in fgs_fft.hip.)
+__device__ __forceinline__ float fgs_rounded(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // kz^2 = (1/l)^2 - FX^2 - FY^2 exactly as the reference's fp32 expression evaluates it (DR:993): every product and every
 // difference rounded on its own, whatever the translation unit's contraction setting.  Near the evanescent boundary the
 // difference cancels to a few ulps of 1/l^2 and dkz/dlambda = -1 / (l^3 kz) weights exactly those frequencies most, so the
 // forward table, the recurrence factor D, both dL/dlambda kernels and the standalone propagator (fgs_spectral.hip) take kz^2
-// from this ONE function: forward and adjoint agree on kz to the bit.  (fgs_asm.hip as a whole is compiled with
-// -ffp-contract=off since round 4 -- build.py has the measurement that decided it.)
+// from this ONE function: forward and adjoint agree on kz to the bit.
 __device__ __forceinline__ float fgs_kz2(float il, float fx, float fy) {
-    return __fsub_rn(__fsub_rn(__fmul_rn(il, il), __fmul_rn(fx, fx)), __fmul_rn(fy, fy));
+    const float a = fgs_rounded(il * il), b = fgs_rounded(fx * fx), c = fgs_rounded(fy * fy);
+    return fgs_rounded(fgs_rounded(a - b) - c);
 }
+
+// |U|^2 of one complex sample of the ASM renderer's total field and sqrt(|U|^2 + 1e-8) (DR:1316-1319), every operation rounded on
+// its own.  The per-image maximum of the latter is found in one translation unit (the inverse column FFT's epilogue, fgs_fft.hip)
+// and COMPARED FOR EQUALITY with recomputed values in another (k_asm_output_bwd*, torch.max's gradient goes to the pixels that
+// equal the maximum): producer and consumers take the value from here, so they agree to the bit whatever their units' flags.
+__device__ __forceinline__ float fgs_asm_intensity(float2 u, float inv_hw) {
+    const float ur = fgs_rounded(u.x * inv_hw), ui = fgs_rounded(u.y * inv_hw);
+    return fgs_rounded(fgs_rounded(ur * ur) + fgs_rounded(ui * ui));
+}
+__device__ __forceinline__ float fgs_asm_amplitude(float intensity) { return sqrtf(fgs_rounded(intensity + 1e-8f)); }
