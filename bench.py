@@ -53,6 +53,7 @@ WORKLOADS = {
     "config2": (8192, 256, 16),
     "config4": (8192, 256, 16),    # config-2 shapes + 8 depth zones + scalar phases, phase blending
     "config5": (8192, 512, 1),     # ASMWaveFieldRenderer, per-channel wavelengths, hipFFT
+    "config1": (256, 128, 32),     # configs[0]'s shape (the reference's CPU plumbing case) on the GPU: the launch-bound end
 }
 
 # ALGORITHMIC work per stage.  P = composited Gaussian-pixels, D = tile
@@ -411,6 +412,10 @@ def main(argv=None):
                     help="synthetic Gaussian distribution (SURVEY 8d): create_dummy_saag or the ~3x heavier decoder-like grid")
     ap.add_argument("--images-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-image-loop", action="store_true",
+                    help="the LITERAL drop-in call pattern of the reference's train_epoch (TGD:1209-1226): B sequential (N,.) calls "
+                         "of the module from a Python loop, torch.stack of the results, one backward through the stack -- what "
+                         "INTEGRATION.md route A (swap the class, keep the loop) costs; the default is the batched (B,N,.) call")
     ap.add_argument("--saturation-skip", action="store_true",
                     help="NOT the default and not the headline: FgsDims.saturation_skip=1 (stop compositing sub-tiles whose "
                          "accumulated alpha reached 1.0f); value still counts the reference's pairs, see DESIGN.md")
@@ -484,6 +489,8 @@ def main(argv=None):
     if args.images_per_gpu:
         per_gpu = args.images_per_gpu
     cfg_id = int(args.workload[-1])
+    if args.workload == "config1":
+        args.no_cpu_baseline = True  # (its CPU figure is BASELINE.md's reference timing; the bounded-sample leg is sized for configs 2-3)
     # image-wise shard: rank r owns images [r*per_gpu, (r+1)*per_gpu)
     pos, scale, quat, col, opa = synth_batch(per_gpu, N, 1000 * cfg_id + rank * per_gpu, device, args.distribution)
     N = pos.shape[1]  # decoder_like: floor(sqrt(N))^2
@@ -515,8 +522,31 @@ def main(argv=None):
     bucket = torch.zeros(DECODER_GRAD_FLOATS, device=device) if dist is not None else None
     grad_leaves = leaves + ([phases] if phases is not None else []) + ([wl] if is_asm else [])
 
+    def step_loop():
+        # reference call pattern, TGD:1209-1226: `for b in range(B): rendered, depth = renderer(out['positions'][b], ...,
+        # camera, return_depth=True)`; `torch.stack(rendered_images)`; the loss backward runs through the stack
+        for t in grad_leaves:
+            t.grad = None
+        imgs, deps = [], []
+        for b in range(per_gpu):
+            if is_asm:
+                imgs.append(ren(pos[b], scale[b], quat[b], col[b], opa[b], cam, phases=phases[b], wavelengths_rgb=wl))
+            else:
+                im, dp_ = ren(pos[b], scale[b], quat[b], col[b], opa[b], cam, return_depth=True,
+                              phases=None if phases is None else phases[b])
+                imgs.append(im)
+                deps.append(dp_)
+        if is_asm:
+            torch.autograd.backward([torch.stack(imgs)], [gI])
+        else:
+            torch.autograd.backward([torch.stack(imgs), torch.stack(deps)], [gI, gD])
+        if bucket is not None:
+            dist.all_reduce(bucket)
+
     def step():
         # the nn.Module call the training harness makes (fresnel_amd/train.py train_step): batched tensors, one Camera
+        if args.per_image_loop:
+            return step_loop()
         for t in grad_leaves:  # (every leaf: a gradient left in place makes autograd launch an accumulation kernel per step)
             t.grad = None
         if is_asm:
@@ -554,6 +584,27 @@ def main(argv=None):
     elapsed, elapsed_cold, pairs_all, rank_ms = reduce_over_ranks(dist, device, elapsed, elapsed_cold, pairs_local, args.steps)
     ms_per_step = elapsed / args.steps * 1e3
     value = pairs_all / (elapsed / args.steps)
+
+    # ---- after the measurement: what the host and the collective cost by themselves (not part of `value`) ----
+    # host_enqueue_us: wall time of the Python side of one step (module call(s), ctypes, autograd, allocator) with the GPU
+    # running behind -- no synchronisation inside; where it exceeds ms_per_step the step is host-bound.
+    torch.cuda.synchronize()
+    t_host = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        step()
+        t_host.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+    host_enqueue_us = sorted(t_host)[len(t_host) // 2] * 1e6
+    allreduce_us = None
+    if dist is not None:  # the step's one collective alone: K back-to-back all-reduces of the bucket, barrier + sync around them
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(bucket)
+        torch.cuda.synchronize()
+        allreduce_us = (time.perf_counter() - t0) / 50 * 1e6
 
     if rank == 0:
         # ---- roofline (rank 0's launches, hipEvent-timed in the library on the stream the kernels run on) ----
@@ -645,6 +696,12 @@ def main(argv=None):
             "higher_is_better": True,
             "rccl_ranks": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None,
             "ms_per_step_rank_min": rank_ms[0], "ms_per_step_rank_max": rank_ms[1],
+            # rank 0's own figures, measured after the timed region: the decoder-gradient all-reduce alone (50 back to back), and
+            # the wall time of the Python side of one step with no synchronisation inside (host-bound where it exceeds ms_per_step)
+            "allreduce_us": None if allreduce_us is None else round(allreduce_us, 1),
+            "host_enqueue_us_per_step": round(host_enqueue_us, 1),
+            "call_pattern": ("per-image loop: %d sequential (N,.) module calls + torch.stack, as TGD:1209-1226" % per_gpu)
+                            if args.per_image_loop else "batched (B,N,.) module call",
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE {args.workload}: {N} Gaussians, {S}x{S}, {per_gpu} images/GPU "
                                    f"({per_gpu * world} global), {dist_name}, rasterizer fwd+bwd through the nn.Module call"

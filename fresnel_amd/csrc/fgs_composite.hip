@@ -444,6 +444,9 @@ __global__ __launch_bounds__(64 * NP * (1 + WIDE)) __attribute__((amdgpu_waves_p
 #ifndef FGS_BWD_WIDE_WAVES
 #define FGS_BWD_WIDE_WAVES 5  /* waves per SIMD of k_composite_bwd<4>; re-measured in round 3 under the clause scheduler: see DESIGN_LOG.md 10.3 */
 #endif
+#ifndef FGS_BWD_DYN_LDS
+#define FGS_BWD_DYN_LDS 0  /* experiment builds: unused dynamic LDS per block, to cap the waves per SIMD below what the registers allow */
+#endif
 template <int NSX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6 : FGS_BWD_WIDE_WAVES, NSX == 2 ? 6 : FGS_BWD_WIDE_WAVES))) void k_composite_bwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, uint32_t dcap,
@@ -1036,7 +1039,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
     }
     const uint32_t ugrid = (uint32_t)p.L.seg_capacity;  // surplus blocks exit at once (measured: free)
 #define FGS_BWD_LAUNCH(NSXV)                                                                                  \
-    hipLaunchKernelGGL(k_composite_bwd<NSXV>, dim3(ugrid), dim3(64), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x, \
+    hipLaunchKernelGGL(k_composite_bwd<NSXV>, dim3(ugrid), dim3(64), FGS_BWD_DYN_LDS, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x, \
                        (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0], p.d.background[1], \
                        p.d.background[2], (uint32_t)p.L.dup_capacity, \
                        reinterpret_cast<const uint32_t *>(saved + p.L.counters), \

@@ -17,6 +17,8 @@ class DPContext:
         self.device = device
         self.enabled = self.world > 1
         self._bucket = None
+        self._views = None
+        self.collectives = 0  # gradient-bucket all-reduces issued (tests assert one per step)
         if self.enabled and not dist.is_initialized():
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -51,38 +53,65 @@ class DPContext:
             for p in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(p.data, src=0)
 
+    # ---- the gradient bucket ------------------------------------------------------------------------------------------
+    # Round 5: the parameters' .grad tensors ARE slices of one flat fp32 bucket (`adopt`), so autograd accumulates straight
+    # into it and the step's exchange is: [extra scalars -> tail of the bucket] + ONE all-reduce + ONE in-place divide.  Until
+    # round 4 every parameter's gradient was copied into and out of the bucket one tensor at a time -- two small launches per
+    # parameter (~40 for the decoder) around a latency-bound 2.7 MB all-reduce inside a 1.8 ms step.
+    def _layout(self, params, n_extra):
+        n = sum(p.numel() for p in params) + n_extra
+        dev = params[0].device
+        if self._bucket is None or self._bucket.numel() != n or self._bucket.device != dev:
+            self._bucket = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._views = None
+        if self._views is None or len(self._views) != len(params) or any(v.shape != p.shape for v, p in zip(self._views, params)):
+            self._views, off = [], 0
+            for p in params:
+                self._views.append(self._bucket[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        return n - n_extra
+
+    def adopt(self, params, n_extra=2):
+        """Point every parameter's .grad at its slice of the flat bucket and zero the bucket (ONE launch): the replacement of
+        `optimizer.zero_grad()` in a data-parallel step.  Gradients then accumulate in place (autograd keeps an existing
+        .grad tensor), and `allreduce_gradients` finds nothing to pack.  No-op layout-wise when already adopted."""
+        params = [p for p in params if p.requires_grad]
+        self._layout(params, n_extra)
+        self._bucket.zero_()
+        for p, v in zip(params, self._views):
+            if p.grad is not v:
+                p.grad = v
+
     def allreduce_gradients(self, params, extra: torch.Tensor = None):
         """Average gradients over ranks through ONE flat fp32 bucket (one collective per step).  `extra`: a small 1-D
         tensor of per-rank scalars (the NaN/Inf flag, the loss) that rides at the end of the same bucket and comes
-        back SUMMED over the ranks -- so the step needs no second collective and no host round trip for them."""
+        back SUMMED over the ranks -- so the step needs no second collective and no host round trip for them.
+        Parameters whose .grad is not (any more) the bucket slice handed out by `adopt` -- a caller that used
+        `zero_grad(set_to_none=True)`, a parameter that received no gradient -- are packed with one fused foreach copy and
+        re-pointed; the adopted ones cost nothing."""
         if not self.enabled:
             return extra
         params = [p for p in params if p.requires_grad]
         ne = 0 if extra is None else extra.numel()
-        n = sum(p.numel() for p in params) + ne
-        if self._bucket is None or self._bucket.numel() != n or self._bucket.device != params[0].device:
-            self._bucket = torch.zeros(n, dtype=torch.float32, device=params[0].device)
-        off = 0
-        for p in params:
-            k = p.numel()
+        off = self._layout(params, ne)
+        stray_dst, stray_src = [], []
+        for p, v in zip(params, self._views):
             if p.grad is None:
-                self._bucket[off:off + k].zero_()
-            else:
-                self._bucket[off:off + k].copy_(p.grad.reshape(-1))
-            off += k
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr() or p.grad.dtype != torch.float32:
+                stray_dst.append(v)
+                stray_src.append(p.grad.reshape(v.shape))
+        if stray_dst:
+            torch._foreach_copy_(stray_dst, stray_src)
         if ne:
-            self._bucket[off:].copy_(extra.reshape(-1).float())
+            self._bucket[off:].copy_(extra.reshape(-1))
         dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
+        self.collectives += 1
         out_extra = self._bucket[off:].clone() if ne else None
-        grads = self._bucket[:off]
-        grads.div_(self.world)
-        off = 0
-        for p in params:
-            k = p.numel()
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-            p.grad.copy_(grads[off:off + k].view_as(p))
-            off += k
+        self._bucket[:off].div_(self.world)
+        for p, v in zip(params, self._views):
+            if p.grad is not v:
+                p.grad = v
         return out_extra
 
     def any_true(self, flag: bool, device) -> bool:

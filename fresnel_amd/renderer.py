@@ -150,6 +150,52 @@ class _Cfg:
         self.phase_amplitude = float(phase_amplitude)
 
 
+# ---- host-side cost of one call (round 5: the per-image drop-in route, INTEGRATION.md route A, makes B small calls per step) ----
+# FgsDims and the two workspace sizes are pure functions of the call's shape and configuration: built once per distinct key.
+_DIMS_CACHE: dict = {}
+
+
+def _dims_for(Bn, N, cfg, use_phase, num_cameras):
+    tuning = getattr(cfg, "tuning", None)
+    key = (Bn, N, cfg.width, cfg.height, cfg.max_radius, cfg.background, use_phase, cfg.phase_amplitude, num_cameras,
+           getattr(cfg, "saturation_skip", False), tuple(sorted(tuning.items())) if tuning else None)
+    hit = _DIMS_CACHE.get(key)
+    if hit is None:
+        dims = B.make_dims(Bn, N, cfg.width, cfg.height, cfg.max_radius, cfg.background, use_phase=use_phase,
+                           phase_amplitude=cfg.phase_amplitude, num_cameras=num_cameras,
+                           saturation_skip=getattr(cfg, "saturation_skip", False), tuning=tuning)
+        if len(_DIMS_CACHE) > 256:
+            _DIMS_CACHE.clear()
+        hit = _DIMS_CACHE[key] = (dims,) + tuple(B.workspace_bytes(dims))
+    return hit
+
+
+# `scratch` lives only for the duration of one fgs_forward / fgs_backward call, and calls on one stream run in order: ONE
+# buffer per (device, stream), grown to the largest request, serves them all.  (`saved` goes from a forward to its backward and
+# several forwards may be pending -- the per-image loop -- so it stays a fresh tensor from torch's caching allocator.)
+_SCRATCH: dict = {}
+
+
+def _scratch_for(dev, nbytes):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return buf
+
+
+def release_scratch():
+    """Drop the cached scratch buffers (their memory goes back to torch's caching allocator)."""
+    _SCRATCH.clear()
+
+
+def _f32c(t):
+    """float32, contiguous, detached -- without a dispatcher call when the tensor already is (the usual case)."""
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t.detach() if t.requires_grad else t
+    return t.detach().contiguous().float()
+
+
 def forward_raw(positions, scales, rotations, colors, opacities, phases, cam_tensor, cfg):
     """fgs_forward without autograd: returns (out_rgb, out_depth, saved, dims, input tensors)."""
     if not positions.is_cuda:
@@ -158,24 +204,15 @@ def forward_raw(positions, scales, rotations, colors, opacities, phases, cam_ten
     lib = B.load()
     Bn, N = positions.shape[0], positions.shape[1]
     dev = positions.device
-    f32 = dict(dtype=torch.float32, device=dev)
-    pos = positions.detach().contiguous().float()
-    scl = scales.detach().contiguous().float()
-    rot = rotations.detach().contiguous().float()
-    col = colors.detach().contiguous().float()
-    opa = opacities.detach().contiguous().float()
-    ph = phases.detach().contiguous().float() if (cfg.use_phase and phases is not None) else None
-    cam_tensor = cam_tensor.contiguous().float()
-    dims = B.make_dims(Bn, N, cfg.width, cfg.height, cfg.max_radius, cfg.background,
-                       use_phase=ph is not None, phase_amplitude=cfg.phase_amplitude,
-                       num_cameras=cam_tensor.shape[0], saturation_skip=getattr(cfg, "saturation_skip", False),
-                       tuning=getattr(cfg, "tuning", None))
-    saved_bytes, scratch_bytes = B.workspace_bytes(dims)
+    pos, scl, rot, col, opa = _f32c(positions), _f32c(scales), _f32c(rotations), _f32c(colors), _f32c(opacities)
+    ph = _f32c(phases) if (cfg.use_phase and phases is not None) else None
+    cam_tensor = _f32c(cam_tensor)
+    dims, saved_bytes, scratch_bytes = _dims_for(Bn, N, cfg, ph is not None, cam_tensor.shape[0])
     with torch.cuda.device(dev):
         saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
-        scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
-        out_rgb = torch.empty(Bn, 3, cfg.height, cfg.width, **f32)
-        out_depth = torch.empty(Bn, cfg.height, cfg.width, **f32)
+        scratch = _scratch_for(dev, scratch_bytes)
+        out_rgb = torch.empty((Bn, 3, cfg.height, cfg.width), dtype=torch.float32, device=dev)
+        out_depth = torch.empty((Bn, cfg.height, cfg.width), dtype=torch.float32, device=dev)
         B.check(lib.fgs_forward(ctypes.byref(dims), _ptr(cam_tensor), _ptr(pos), _ptr(scl), _ptr(rot),
                                 _ptr(col), _ptr(opa), _ptr(ph), _ptr(out_rgb), _ptr(out_depth),
                                 _ptr(saved), _ptr(scratch), _stream_handle()), "fgs_forward")
@@ -204,6 +241,7 @@ class GaussianRenderer(torch.autograd.Function):
                 cfg.pair_counter[1:2] += saved[L.counters:L.counters + 4].view(torch.int32).to(torch.int64)
                 cfg.pair_counter[2:3] += int(dims.batch) * int(dims.num_gaussians)
         ctx.dims = dims
+        ctx.scratch_bytes = _dims_for(pos.shape[0], pos.shape[1], cfg, ph is not None, cam_tensor.shape[0])[2]
         ctx.has_phase = ph is not None
         ctx.save_for_backward(pos, scl, rot, col, opa, ph if ph is not None else pos.new_empty(0),
                               cam_tensor, saved)
@@ -218,11 +256,9 @@ class GaussianRenderer(torch.autograd.Function):
         ph = ph if ctx.has_phase else None
         g_rgb = (g_rgb if g_rgb is not None else torch.zeros(dims.batch, 3, dims.height, dims.width, device=dev))
         g_depth = (g_depth if g_depth is not None else torch.zeros(dims.batch, dims.height, dims.width, device=dev))
-        g_rgb = g_rgb.contiguous().float()
-        g_depth = g_depth.contiguous().float()
-        _, scratch_bytes = B.workspace_bytes(dims)
+        g_rgb, g_depth = _f32c(g_rgb), _f32c(g_depth)
         with torch.cuda.device(dev):
-            scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+            scratch = _scratch_for(dev, ctx.scratch_bytes)
             g_pos, g_scl, g_rot = torch.empty_like(pos), torch.empty_like(scl), torch.empty_like(rot)
             g_col, g_opa = torch.empty_like(col), torch.empty_like(opa)
             g_ph = torch.empty_like(ph) if ph is not None else None

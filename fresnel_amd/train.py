@@ -421,7 +421,10 @@ def train_step(model, renderer, camera, batch, optimizer, cfg: TrainingConfig, d
     # NaN/Inf batch skip (TGD:1255-1258), decided on the device and by ALL ranks together: the flag and the loss ride
     # behind the gradients in the one all-reduce of the step
     bad = (~torch.isfinite(loss.detach())).float()
-    optimizer.zero_grad(set_to_none=True)
+    if dp.enabled:
+        dp.adopt(list(model.parameters()))  # .grad = slices of the flat bucket, zeroed in one launch: nothing to pack later
+    else:
+        optimizer.zero_grad(set_to_none=True)
     loss.backward()
     extra = torch.stack([bad, torch.nan_to_num(loss.detach().float(), nan=0.0, posinf=0.0, neginf=0.0)])
     extra = dp.allreduce_gradients(list(model.parameters()), extra=extra)

@@ -13,6 +13,42 @@ import torch
 from . import fgs_oracle as orc
 
 
+def _prec(f64):
+    import contextlib
+    return orc.fp64() if f64 else contextlib.nullcontext()
+
+
+def _zero_visible(N, H, W, bg, phases, proj, need, wavelengths, depth=False):
+    """The reference's zero-visible return (DR:801-808 / DR:1207-1212): `background.view(3,1,1).expand(3,H,W) + grad_anchor`."""
+    out = dict(image=np.broadcast_to(np.asarray(bg, np.float32).reshape(3, 1, 1), (3, H, W)).copy(), proj=proj)
+    if depth:
+        out["depth"] = np.zeros((H, W), np.float32)
+    if need:
+        z = lambda *sh: np.zeros(sh, np.float32)
+        out.update(grad_positions=z(N, 3), grad_scales=z(N, 3), grad_rotations=z(N, 4), grad_colors=z(N, 3),
+                   grad_opacities=z(N), grad_phases=np.zeros(np.asarray(phases).shape, np.float32))
+        if wavelengths:
+            out["grad_wavelengths"] = z(3)
+    return out
+
+
+def _project_bwd(pos, scale, quat, cam, proj, mean, conic, dep, f64):
+    """Chain dL/d(mean2d, conic, depth) (autograd of the restatement) through the C oracle's projection adjoint."""
+    import ctypes
+    with _prec(f64):
+        real = orc._REAL
+        N = len(proj["visible"])
+        g = lambda x: np.zeros(tuple(x.shape), real) if (x is None or x.grad is None) else np.ascontiguousarray(x.grad.numpy(), dtype=real)
+        gm, gc = g(mean), g(conic)
+        gd = np.zeros(N, real) if dep is None else g(dep)
+        g_pos, g_scale, g_quat = np.zeros((N, 3), real), np.zeros((N, 3), real), np.zeros((N, 4), real)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        p_, s_, q_ = (np.ascontiguousarray(a, dtype=real) for a in (pos, scale, quat))
+        orc.lib().fgs_or_project_bwd(ctypes.c_int32(N), P(p_), P(s_), P(q_), orc._camref(cam),
+                                     P(proj["visible"]), P(gm), P(gc), P(gd), P(g_pos), P(g_scale), P(g_quat))
+    return g_pos.astype(np.float32), g_scale.astype(np.float32), g_quat.astype(np.float32)
+
+
 def transfer_function(H, W, pixel_pitch, z, wl, dtype=torch.float32):
     """DR:959-961 + DR:989-999."""
     fx = torch.fft.fftfreq(W, d=pixel_pitch).to(dtype)
@@ -32,14 +68,20 @@ def propagate(field, z, wl, pixel_pitch=1.0 / 256.0):
 
 def render(pos, scale, quat, color, opacity, phases, wavelengths, cam, bg=(0.0, 0.0, 0.0), max_radius=64.0,
            num_planes=16, depth_range=(0.1, 2.0), focal_depth=0.5, pixel_pitch=1.0 / 256.0,
-           dtype=torch.float32, grad_out=None):
+           dtype=torch.float32, grad_out=None, project_f64=False):
     """ASM forward for one image; with grad_out (3,H,W) also returns gradients of sum(img*grad_out)
     w.r.t. mean2d/conic/opacity/colour/phase/wavelengths chained through the C oracle's projection
     backward to positions/scales/rotations."""
-    proj = orc.project(pos, scale, quat, cam, max_radius)
+    with _prec(project_f64):  # (project_f64: the projection and its adjoint on the fp64 referee build too -- the sweeps' referee)
+        proj = orc.project(pos, scale, quat, cam, max_radius)
     W, H = cam.width, cam.height
     vis = proj["visible"].astype(bool)
     N = len(vis)
+    if not vis.any():
+        # DR:1207-1212: no visible Gaussian -> the background itself (NOT background + sqrt(1e-8): the intensity floor of DR:1319
+        # is never reached), every gradient zero.  (Missing until round 5: the sweeps' two N = 1 cases with the one Gaussian
+        # culled showed exactly 1.00e-4 between this oracle and the HIP path, which follows the reference.)
+        return _zero_visible(N, H, W, bg, phases, proj, grad_out is not None, wavelengths=True)
     t = lambda a, g=False: torch.tensor(np.asarray(a), dtype=dtype, requires_grad=g)
     need = grad_out is not None
     mean, conic = t(proj["mean2d"], need), t(proj["conic"], need)
@@ -81,32 +123,29 @@ def render(pos, scale, quat, color, opacity, phases, wavelengths, cam, bg=(0.0, 
     img = torch.clamp(rendered.permute(2, 0, 1), 0, 1)
     out = dict(image=img.detach().float().numpy(), plane_idx=plane_idx.numpy(), proj=proj)
     if need:
-        (img * torch.tensor(grad_out, dtype=dtype)).sum().backward()
-        z = lambda x: np.zeros_like(np.asarray(x), dtype=np.float32) if x.grad is None else x.grad.float().numpy()
-        g_pos, g_scale, g_quat = np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32)
-        import ctypes
-        gm, gc = np.ascontiguousarray(z(mean)), np.ascontiguousarray(z(conic))
-        gd = np.zeros(N, np.float32)
-        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
-        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        pos32, sc32, q32 = f32(pos), f32(scale), f32(quat)
-        orc.lib().fgs_or_project_bwd(ctypes.c_int32(N), P(pos32), P(sc32), P(q32), ctypes.byref(cam),
-                                     P(proj["visible"]), P(gm), P(gc), P(gd), P(g_pos), P(g_scale), P(g_quat))
+        loss = (img * torch.tensor(grad_out, dtype=dtype)).sum()
+        if loss.requires_grad:  # (no visible Gaussian: the image is a constant, every gradient is zero)
+            loss.backward()
+        z = lambda x: np.zeros_like(np.asarray(x.detach()), dtype=np.float32) if x.grad is None else x.grad.float().numpy()
+        g_pos, g_scale, g_quat = _project_bwd(pos, scale, quat, cam, proj, mean, conic, None, project_f64)
         out.update(grad_positions=g_pos, grad_scales=g_scale, grad_rotations=g_quat, grad_colors=z(col),
                    grad_opacities=z(opa), grad_phases=z(ph), grad_wavelengths=z(wl))
     return out
 
 
 def render_wave(pos, scale, quat, color, opacity, phases, cam, bg=(0.0, 0.0, 0.0), max_radius=64.0,
-                dtype=torch.float32, grad_out=None, grad_depth=None):
+                dtype=torch.float32, grad_out=None, grad_depth=None, project_f64=False):
     """WaveFieldRenderer (DR:747-926) for one image: order-independent complex accumulation, intensity,
     max normalisation, background, amplitude-weighted depth map.  Gradients by autograd of this
     restatement, chained through the C oracle's projection backward."""
-    proj = orc.project(pos, scale, quat, cam, max_radius)
+    with _prec(project_f64):  # (project_f64: the projection and its adjoint on the fp64 referee build too -- the sweeps' referee)
+        proj = orc.project(pos, scale, quat, cam, max_radius)
     W, H = cam.width, cam.height
     vis = proj["visible"].astype(bool)
     N = len(vis)
     need = grad_out is not None
+    if not vis.any():  # DR:801-808: background, zero depth map, zero gradients
+        return _zero_visible(N, H, W, bg, phases, proj, need, wavelengths=False, depth=True)
     t = lambda a, g=False: torch.tensor(np.asarray(a), dtype=dtype, requires_grad=g)
     mean, conic, dep = t(proj["mean2d"], need), t(proj["conic"], need), t(proj["depth"], need)
     opa, col, ph = t(opacity, need), t(color, need), t(phases, need)
@@ -145,14 +184,7 @@ def render_wave(pos, scale, quat, color, opacity, phases, cam, bg=(0.0, 0.0, 0.0
         if loss.requires_grad:  # (no visible Gaussian: the image is a constant, every gradient is zero)
             loss.backward()
         z = lambda x: np.zeros_like(np.asarray(x.detach()), dtype=np.float32) if x.grad is None else x.grad.float().numpy()
-        import ctypes
-        g_pos, g_scale, g_quat = np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32)
-        gm, gc, gd = np.ascontiguousarray(z(mean)), np.ascontiguousarray(z(conic)), np.ascontiguousarray(z(dep))
-        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
-        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        pos32, sc32, q32 = f32(pos), f32(scale), f32(quat)
-        orc.lib().fgs_or_project_bwd(ctypes.c_int32(N), P(pos32), P(sc32), P(q32), ctypes.byref(cam),
-                                     P(proj["visible"]), P(gm), P(gc), P(gd), P(g_pos), P(g_scale), P(g_quat))
+        g_pos, g_scale, g_quat = _project_bwd(pos, scale, quat, cam, proj, mean, conic, dep, project_f64)
         out.update(grad_positions=g_pos, grad_scales=g_scale, grad_rotations=g_quat, grad_colors=z(col),
                    grad_opacities=z(opa), grad_phases=z(ph))
     return out

@@ -14,6 +14,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libfgs_oracle.so")
+_SO64 = os.path.join(_HERE, "_build", "libfgs_oracle_f64.so")
+# Precision of the restatement in use: float32 (the oracle; canonical fp32) or -- inside `with fp64():` -- the sed-widened fp64
+# REFEREE build (oracle/Makefile): what the reference computes with torch's default dtype switched to float64.
+_REAL = np.float32
+_CREAL = ctypes.c_float
 
 
 class OrCamera(ctypes.Structure):
@@ -22,24 +27,59 @@ class OrCamera(ctypes.Structure):
                 ("height", ctypes.c_int32), ("near_", ctypes.c_float), ("far_", ctypes.c_float)]
 
 
+class OrCamera64(ctypes.Structure):
+    _fields_ = [("view", ctypes.c_double * 16), ("fx", ctypes.c_double), ("fy", ctypes.c_double),
+                ("cx", ctypes.c_double), ("cy", ctypes.c_double), ("width", ctypes.c_int32),
+                ("height", ctypes.c_int32), ("near_", ctypes.c_double), ("far_", ctypes.c_double)]
+
+
 def build(force=False):
     src = os.path.join(_HERE, "fgs_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) for so in (_SO, _SO64)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
 
 _lib = None
+_lib64 = None
+
+
+def _load(path):
+    l = ctypes.CDLL(path)
+    l.fgs_or_count_pairs.restype = ctypes.c_int64
+    l.fgs_or_tile_lists.restype = ctypes.c_int64
+    l.fgs_or_render_fwd_bwd.restype = ctypes.c_int64
+    return l
 
 
 def lib():
-    global _lib
+    global _lib, _lib64
+    if _REAL is np.float64:
+        if _lib64 is None:
+            build()
+            _lib64 = _load(_SO64)
+        return _lib64
     if _lib is None:
-        _lib = ctypes.CDLL(build())
-        _lib.fgs_or_count_pairs.restype = ctypes.c_int64
-        _lib.fgs_or_tile_lists.restype = ctypes.c_int64
-        _lib.fgs_or_render_fwd_bwd.restype = ctypes.c_int64
+        _lib = _load(build())
     return _lib
+
+
+class fp64:
+    """`with fgs_oracle.fp64(): r = render(...); g = render_backward(r, gI, gD)` -- the same calls on the fp64 referee build
+    (arrays come back as float64; cameras made by make_camera carry their unrounded doubles)."""
+
+    def __enter__(self):
+        global _REAL, _CREAL
+        self._old = (_REAL, _CREAL)
+        _REAL, _CREAL = np.float64, ctypes.c_double
+
+    def __exit__(self, *a):
+        global _REAL, _CREAL
+        _REAL, _CREAL = self._old
+
+
+def _camref(cam):
+    return ctypes.byref(cam._f64 if _REAL is np.float64 else cam)
 
 
 def _p(a):
@@ -47,7 +87,8 @@ def _p(a):
 
 
 def _f32(a):
-    return np.ascontiguousarray(a, dtype=np.float32)
+    """contiguous array in the precision in use (float32 unless inside `with fp64()`)."""
+    return np.ascontiguousarray(a, dtype=_REAL)
 
 
 def make_camera(view, fx, fy, cx, cy, width, height, near=0.01, far=100.0):
@@ -58,18 +99,26 @@ def make_camera(view, fx, fy, cx, cy, width, height, near=0.01, far=100.0):
     cam.fx, cam.fy, cam.cx, cam.cy = float(fx), float(fy), float(cx), float(cy)
     cam.width, cam.height = int(width), int(height)
     cam.near_, cam.far_ = float(near), float(far)
+    c64 = OrCamera64()
+    v64 = np.asarray(view, dtype=np.float64).reshape(16)
+    for i in range(16):
+        c64.view[i] = float(v64[i])
+    c64.fx, c64.fy, c64.cx, c64.cy = float(fx), float(fy), float(cx), float(cy)
+    c64.width, c64.height = int(width), int(height)
+    c64.near_, c64.far_ = float(near), float(far)
+    cam._f64 = c64
     return cam
 
 
 def project(pos, scale, quat, cam, max_radius=64.0):
     pos, scale, quat = _f32(pos), _f32(scale), _f32(quat)
     N = pos.shape[0]
-    out = dict(cov2d=np.zeros((N, 4), np.float32), mean2d=np.zeros((N, 2), np.float32),
-               depth=np.zeros(N, np.float32), radius=np.zeros(N, np.float32),
+    out = dict(cov2d=np.zeros((N, 4), _REAL), mean2d=np.zeros((N, 2), _REAL),
+               depth=np.zeros(N, _REAL), radius=np.zeros(N, _REAL),
                visible=np.zeros(N, np.uint8), bbox=np.zeros((N, 4), np.int32),
-               conic=np.zeros((N, 3), np.float32))
-    lib().fgs_or_project(ctypes.c_int32(N), _p(pos), _p(scale), _p(quat), ctypes.byref(cam),
-                         ctypes.c_float(max_radius), _p(out["cov2d"]), _p(out["mean2d"]),
+               conic=np.zeros((N, 3), _REAL))
+    lib().fgs_or_project(ctypes.c_int32(N), _p(pos), _p(scale), _p(quat), _camref(cam),
+                         _CREAL(max_radius), _p(out["cov2d"]), _p(out["mean2d"]),
                          _p(out["depth"]), _p(out["radius"]), _p(out["visible"]), _p(out["bbox"]),
                          _p(out["conic"]))
     return out
@@ -124,15 +173,15 @@ def render(pos, scale, quat, color, opacity, cam, bg=(0.0, 0.0, 0.0), max_radius
     r.proj = project(r.pos, r.scale, r.quat, cam, max_radius)
     r.order, r.vis_sorted = depth_order(r.proj["depth"], r.proj["visible"])
     r.P = count_pairs(r.vis_sorted, r.proj["bbox"])
-    r.image = np.zeros((3, H, W), np.float32)
-    r.depth = np.zeros((H, W), np.float32)
-    r.state = np.zeros((5, H, W), np.float32)
-    r.pair_T = np.zeros(max(r.P, 1), np.float32) if keep_pairs else None
-    r.pair_phi = np.zeros(max(r.P, 1), np.float32) if (keep_pairs and phases is not None) else None
+    r.image = np.zeros((3, H, W), _REAL)
+    r.depth = np.zeros((H, W), _REAL)
+    r.state = np.zeros((5, H, W), _REAL)
+    r.pair_T = np.zeros(max(r.P, 1), _REAL) if keep_pairs else None
+    r.pair_phi = np.zeros(max(r.P, 1), _REAL) if (keep_pairs and phases is not None) else None
     lib().fgs_or_composite_fwd(
         ctypes.c_int32(len(r.vis_sorted)), _p(r.vis_sorted), _p(r.proj["mean2d"]), _p(r.proj["conic"]),
         _p(r.color), _p(r.opacity), _p(r.proj["depth"]), _p(r.proj["bbox"]), _p(r.phases),
-        ctypes.c_float(r.phase_amp), ctypes.c_int32(W), ctypes.c_int32(H), _p(r.bg), _p(r.image),
+        _CREAL(r.phase_amp), ctypes.c_int32(W), ctypes.c_int32(H), _p(r.bg), _p(r.image),
         _p(r.depth), _p(r.state), _p(r.pair_T), _p(r.pair_phi))
     return r
 
@@ -142,22 +191,22 @@ def render_backward(r, gI, gD):
     gI, gD = _f32(gI), _f32(gD)
     N = r.pos.shape[0]
     W, H = r.cam.width, r.cam.height
-    g_mean = np.zeros((N, 2), np.float32)
-    g_conic = np.zeros((N, 3), np.float32)
-    g_color = np.zeros((N, 3), np.float32)
-    g_op = np.zeros(N, np.float32)
-    g_dep = np.zeros(N, np.float32)
-    g_ph = np.zeros(N, np.float32) if r.phases is not None else None
+    g_mean = np.zeros((N, 2), _REAL)
+    g_conic = np.zeros((N, 3), _REAL)
+    g_color = np.zeros((N, 3), _REAL)
+    g_op = np.zeros(N, _REAL)
+    g_dep = np.zeros(N, _REAL)
+    g_ph = np.zeros(N, _REAL) if r.phases is not None else None
     lib().fgs_or_composite_bwd(
         ctypes.c_int32(len(r.vis_sorted)), _p(r.vis_sorted), _p(r.proj["mean2d"]), _p(r.proj["conic"]),
         _p(r.color), _p(r.opacity), _p(r.proj["depth"]), _p(r.proj["bbox"]), _p(r.phases),
-        ctypes.c_float(r.phase_amp), ctypes.c_int32(W), ctypes.c_int32(H), _p(r.bg), _p(r.state),
+        _CREAL(r.phase_amp), ctypes.c_int32(W), ctypes.c_int32(H), _p(r.bg), _p(r.state),
         _p(r.pair_T), _p(r.pair_phi), _p(gI), _p(gD), _p(g_mean), _p(g_conic), _p(g_color), _p(g_op),
         _p(g_dep), _p(g_ph))
-    g_pos = np.zeros((N, 3), np.float32)
-    g_scale = np.zeros((N, 3), np.float32)
-    g_quat = np.zeros((N, 4), np.float32)
-    lib().fgs_or_project_bwd(ctypes.c_int32(N), _p(r.pos), _p(r.scale), _p(r.quat), ctypes.byref(r.cam),
+    g_pos = np.zeros((N, 3), _REAL)
+    g_scale = np.zeros((N, 3), _REAL)
+    g_quat = np.zeros((N, 4), _REAL)
+    lib().fgs_or_project_bwd(ctypes.c_int32(N), _p(r.pos), _p(r.scale), _p(r.quat), _camref(r.cam),
                              _p(r.proj["visible"]), _p(g_mean), _p(g_conic), _p(g_dep), _p(g_pos),
                              _p(g_scale), _p(g_quat))
     out = dict(positions=g_pos, scales=g_scale, rotations=g_quat, colors=g_color, opacities=g_op,
@@ -173,11 +222,11 @@ def render_fwd_bwd_timed(pos, scale, quat, color, opacity, cam, gI, gD, bg=(0.0,
     pos, scale, quat, color, opacity = map(_f32, (pos, scale, quat, color, opacity))
     N = pos.shape[0]
     W, H = cam.width, cam.height
-    img = np.zeros((3, H, W), np.float32)
-    dep = np.zeros((H, W), np.float32)
-    gp, gs, gq = np.zeros((N, 3), np.float32), np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32)
-    gc, go = np.zeros((N, 3), np.float32), np.zeros(N, np.float32)
+    img = np.zeros((3, H, W), _REAL)
+    dep = np.zeros((H, W), _REAL)
+    gp, gs, gq = np.zeros((N, 3), _REAL), np.zeros((N, 3), _REAL), np.zeros((N, 4), _REAL)
+    gc, go = np.zeros((N, 3), _REAL), np.zeros(N, _REAL)
     P = lib().fgs_or_render_fwd_bwd(ctypes.c_int32(N), _p(pos), _p(scale), _p(quat), _p(color), _p(opacity),
-                                    ctypes.byref(cam), ctypes.c_float(max_radius), _p(_f32(bg)), _p(_f32(gI)),
+                                    _camref(cam), _CREAL(max_radius), _p(_f32(bg)), _p(_f32(gI)),
                                     _p(_f32(gD)), _p(img), _p(dep), _p(gp), _p(gs), _p(gq), _p(gc), _p(go))
     return int(P), img, dep

@@ -1,0 +1,325 @@
+"""Randomized HIP-vs-oracle sweeps in two halves (round 5; replaces fuzz.py / fuzz_phase.py / fuzz_batch.py / fuzz_asm.py /
+fuzz_asm_batched.py + run_sweeps.sh, whose ASM seeds died at the script's own timeout because the torch oracle ran on the GPU box):
+
+    python scratch/fuzz/sweep.py precompute [family ...]        BUILD CONTAINER, CPU only: the oracle side of every case in fp32
+                                                                AND on the fp64 referee build -> scratch/fuzz/replay/<family>_s<seed>.npz
+    python scratch/fuzz/sweep.py run OUT.txt [--commit HASH] [family ...]
+                                                                GPU BOX: only the HIP side runs; every tensor is ranked with the
+                                                                referee rule of tests/helpers.py (fp32 oracle at 1e-4 where the
+                                                                oracle's own fp32-vs-fp64 spread is <= 5e-5, else the fp64 run
+                                                                referees at <= 2 x spread)
+
+The cases are the seeded draws of tests/fuzz_cases.py (same seeds / iterations as rounds 2-4, so "fuzz_asm seed 0 it 4" is the same
+scene).  The replay files are data (expected outputs only; inputs are re-drawn from the seed); they are git-ignored like built
+libraries and travel to the GPU box with the snapshot.  Every case logs its verdict, its elapsed time and -- on failure or crash -- the
+exception; the run's header carries fgs_version() and the commit.  Not a test, not imported by the product."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REPLAY = os.path.join(ROOT, "scratch", "fuzz", "replay")
+
+import fuzz_cases as FC  # noqa: E402
+from helpers import rel_to_max, referee_tolerance  # noqa: E402
+
+GRADS = ["positions", "scales", "rotations", "colors", "opacities"]
+FAMILIES = {  # family -> (seeds, case generator)
+    "phase": (range(6), lambda s: FC.phase_cases(s)),
+    "blend": (range(4), lambda s: FC.blend_cases(s)),
+    "batch": (range(2), lambda s: FC.batch_cases(s, 2)),
+    "batch_wide": (range(2), lambda s: FC.batch_cases(s, 1)),
+    "asm": (range(6), lambda s: FC.asm_cases(s)),
+    "asm_batched": ([4, 5], lambda s: FC.asm_batched_cases(s)),
+}
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# oracle side (CPU): expected tensors of one case in one precision
+# ----------------------------------------------------------------------------------------------------------------------------
+def _oracle_case(family, c, f64):
+    import contextlib
+    import torch
+    from oracle import asm_oracle, fgs_oracle as orc
+    prec = orc.fp64() if f64 else contextlib.nullcontext()
+    out = {}
+    if family in ("phase", "blend"):
+        W, H = c["W"], c["H"]
+        if family == "phase":
+            cam = orc.make_camera(np.eye(4), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+            kw = dict(bg=c["bg"], phases=c["phases"], phase_amp=c["amp"])
+        else:
+            cam = orc.make_camera(np.eye(4), c["fx"], c["fx"], c["cx"], c["cy"], W, H)
+            kw = dict(bg=c["bg"], max_radius=c["maxr"])
+        with prec:
+            r = orc.render(*c["arrs"], cam, **kw)
+            g = orc.render_backward(r, c["gI"], c["gD"])
+        out["image"], out["depth"] = r.image, r.depth
+        for k in GRADS + (["phases"] if family == "phase" else []):
+            out[k] = g[k]
+    elif family in ("batch", "batch_wide"):
+        from fresnel_amd.renderer import create_camera_from_pose
+        S = c["S"]
+        res = {k: [] for k in ["image", "depth"] + GRADS}
+        for b in range(c["B"]):
+            cc = create_camera_from_pose(c["poses"][b][0], c["poses"][b][1], S, distance=c["poses"][b][2])
+            cam = orc.make_camera(cc.view_matrix.numpy(), cc.fx, cc.fy, cc.cx, cc.cy, S, S)
+            with prec:
+                r = orc.render(*[a[b] for a in c["arrs"]], cam, bg=c["bg"])
+                g = orc.render_backward(r, c["gI"][b], c["gD"][b])
+            res["image"].append(r.image); res["depth"].append(r.depth)
+            for k in GRADS:
+                res[k].append(g[k])
+        out = {k: np.stack(v) for k, v in res.items()}
+    elif family == "asm":
+        W, H = c["W"], c["H"]
+        cam = orc.make_camera(np.eye(4), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+        dt = torch.float64 if f64 else torch.float32
+        if c["kind"] == "asm":
+            kw = c["kw"]
+            r = asm_oracle.render(*c["arrs"], c["phases"], c["wl"], cam, bg=c["bg"], num_planes=c["P"], depth_range=(0.1, 3.2),
+                                  focal_depth=kw["focal_depth"], pixel_pitch=kw["pixel_pitch"], grad_out=c["gI"], dtype=dt, project_f64=f64)
+            out["wavelengths"] = r["grad_wavelengths"]
+        else:
+            r = asm_oracle.render_wave(*c["arrs"], c["phases"], cam, bg=c["bg"], grad_out=c["gI"], grad_depth=c["gD"], dtype=dt, project_f64=f64)
+            out["depth"] = r["depth"]
+        out["image"] = r["image"]
+        for k in GRADS + ["phases"]:
+            out[k] = r["grad_" + k]
+    elif family == "asm_batched":
+        W, H, kw = c["W"], c["H"], c["kw"]
+        cam = orc.make_camera(np.eye(4), c["f"], c["f"], W / 2, H / 2, W, H)
+        dt = torch.float64 if f64 else torch.float32
+        res = {k: [] for k in ["image"] + GRADS + ["phases"]}
+        gw = 0.0
+        for b in range(c["B"]):
+            r = asm_oracle.render(*[a[b] for a in c["arrs"]], c["phases"][b], c["wl"], cam, bg=c["bg"], num_planes=c["P"],
+                                  depth_range=kw["depth_range"], focal_depth=kw["focal_depth"], pixel_pitch=kw["pixel_pitch"],
+                                  grad_out=c["gI"][b], dtype=dt, project_f64=f64)
+            res["image"].append(r["image"])
+            for k in GRADS + ["phases"]:
+                res[k].append(r["grad_" + k])
+            gw = gw + r["grad_wavelengths"].astype(np.float64)
+        out = {k: np.stack(v) for k, v in res.items()}
+        out["wavelengths"] = gw
+    return {k: np.asarray(v, np.float64 if k == "wavelengths" else np.float32) for k, v in out.items()}
+
+
+def _precompute_one(job):
+    family, seed = job
+    import torch
+    torch.set_num_threads(1)
+    t0 = time.time()
+    blob = {}
+    n = 0
+    for c in FAMILIES[family][1](seed):
+        o32, o64 = _oracle_case(family, c, False), _oracle_case(family, c, True)
+        for k, v in o32.items():
+            blob[f"{c['it']}/f32/{k}"] = v
+            # the fp64 run is kept only where it says something (the files travel with every push): where the two runs agree to
+            # 2e-5 of max the fp32 oracle referees anyway (helpers.referee_tolerance: spread <= 5e-5)
+            fin = np.isfinite(v)
+            m = float(np.abs(o64[k]).max()) or 1.0
+            if not fin.all() or float(np.abs(v[fin].astype(np.float64) - o64[k][fin]).max()) / m > 2e-5:
+                blob[f"{c['it']}/f64/{k}"] = o64[k]
+        n += 1
+    os.makedirs(REPLAY, exist_ok=True)
+    path = os.path.join(REPLAY, f"{family}_s{seed}.npz")
+    np.savez_compressed(path, **blob)
+    return f"{family} seed {seed}: {n} cases, {os.path.getsize(path) / 1e6:.1f} MB, {time.time() - t0:.0f} s"
+
+
+def precompute(families):
+    import multiprocessing as mp
+    jobs = [(f, s) for f in families for s in FAMILIES[f][0]]
+    with mp.get_context("spawn").Pool(min(7, len(jobs))) as pool:
+        for line in pool.imap_unordered(_precompute_one, jobs):
+            print(line, flush=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# HIP side (GPU box)
+# ----------------------------------------------------------------------------------------------------------------------------
+def _hip_case(family, c):
+    import torch
+    from fresnel_amd.renderer import (ASMWaveFieldRenderer, Camera, TileBasedRenderer, WaveFieldRenderer,
+                                      create_camera_from_pose)
+    dev = torch.device("cuda:0")
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ts = [up(a).requires_grad_(True) for a in c["arrs"]]
+    out = {}
+    names = list(GRADS)
+    if family in ("phase", "blend", "batch", "batch_wide"):
+        ph = None
+        if family == "phase":
+            W, H = c["W"], c["H"]
+            cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+            ren = TileBasedRenderer(W, H, background=c["bg"], use_phase_blending=True, phase_amplitude=c["amp"])
+            ph = up(c["phases"]).requires_grad_(True)
+            img, dep = ren(*ts, cam, return_depth=True, phases=ph)
+        elif family == "blend":
+            W, H = c["W"], c["H"]
+            cam = Camera(c["fx"], c["fx"], c["cx"], c["cy"], W, H)
+            ren = TileBasedRenderer(W, H, background=c["bg"], max_radius=c["maxr"])
+            ren.tuning = dict(tile_w=c["tile_w"])
+            img, dep = ren(*ts, cam, return_depth=True)
+        else:
+            S = c["S"]
+            cams = [create_camera_from_pose(p[0], p[1], S, distance=p[2]) for p in c["poses"]]
+            img, dep = TileBasedRenderer(S, S, background=c["bg"])(*ts, cams, return_depth=True)
+        ((img * up(c["gI"])).sum() + (dep * up(c["gD"])).sum()).backward()
+        out["image"], out["depth"] = img.detach().cpu().numpy(), dep.detach().cpu().numpy()
+        if ph is not None:
+            out["phases"] = ph.grad.cpu().numpy()
+    elif family == "asm":
+        W, H = c["W"], c["H"]
+        cam = Camera(0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+        ph = up(c["phases"]).requires_grad_(True)
+        if c["kind"] == "asm":
+            ren = ASMWaveFieldRenderer(W, H, background=c["bg"], **c["kw"]).to(dev)
+            wl = up(c["wl"]).requires_grad_(True)
+            img = ren(*ts, cam, phases=ph, wavelengths_rgb=wl)
+            (img * up(c["gI"])).sum().backward()
+            out["wavelengths"] = wl.grad.cpu().numpy()
+        else:
+            ren = WaveFieldRenderer(W, H, background=c["bg"]).to(dev)
+            img, dep = ren(*ts, cam, return_depth=True, phases=ph)
+            ((img * up(c["gI"])).sum() + (dep * up(c["gD"])).sum()).backward()
+            out["depth"] = dep.detach().cpu().numpy()
+        out["image"] = img.detach().cpu().numpy()
+        if c["N"] > 1:  # (a single Gaussian's phase is a global phase: the true gradient is 0, the ratio is noise / noise)
+            out["phases"] = ph.grad.cpu().numpy()
+    elif family == "asm_batched":
+        W, H = c["W"], c["H"]
+        cam = Camera(c["f"], c["f"], W / 2, H / 2, W, H)
+        ph = up(c["phases"]).requires_grad_(True)
+        wl = up(c["wl"]).requires_grad_(True)
+        ren = ASMWaveFieldRenderer(W, H, background=c["bg"], **c["kw"]).to(dev)
+        img = ren(*ts, cam, phases=ph, wavelengths_rgb=wl)
+        (img * up(c["gI"])).sum().backward()
+        out.update(image=img.detach().cpu().numpy(), phases=ph.grad.cpu().numpy(), wavelengths=wl.grad.cpu().numpy())
+    for k, t in zip(names, ts):
+        out[k] = t.grad.cpu().numpy()
+    return out
+
+
+def _describe(family, c):
+    keys = [k for k in ("W", "H", "S", "B", "N", "P", "maxr", "smax", "amp", "tile_w", "kind", "rgbph") if k in c]
+    return " ".join(f"{k}{c[k]}" if not isinstance(c[k], str) else c[k] for k in keys)
+
+
+ABS_KEYS = ("image",)  # images of the ASM / wave renderers live in [0, 1]: absolute error, as in the tests
+
+
+def rank(family, hip, exp):
+    """Per tensor: (error vs the referee, tolerance, spread, which run refereed).  -> (worst tensor line, verdict)."""
+    rows = []
+    for k, x in hip.items():
+        o32, o64 = exp["f32"][k], exp["f64"][k]
+        if family.startswith("asm") and k in ABS_KEYS:
+            spread = float(np.abs(o32.astype(np.float64) - o64).max())
+            use64, tol = referee_tolerance(spread)
+            err = float(np.abs(x - (o64 if use64 else o32)).max())
+            e32 = float(np.abs(x - o32).max())
+        elif k == "wavelengths":
+            fin = np.isfinite(o32)  # torch's fp32 autograd is NaN for a frequency exactly on the evanescent boundary
+            m = float(np.abs(o64).max()) or 1.0
+            spread = float(np.abs(o32[fin] - o64[fin]).max() / m) if fin.any() else 1.0
+            use64, tol = referee_tolerance(spread)
+            if not fin.all():
+                use64 = True
+            ref = o64 if use64 else o32
+            err = float(np.abs(x - ref).max() / m)
+            e32 = float(np.abs(x[fin] - o32[fin]).max() / m) if fin.any() else float("nan")
+        else:
+            spread = rel_to_max(o32, o64)
+            use64, tol = referee_tolerance(spread)
+            err = rel_to_max(x, o64 if use64 else o32)
+            e32 = rel_to_max(x, o32)
+        rows.append((err / tol, k, err, tol, spread, use64, e32))
+    # a tensor passes when it is within 1e-4 of the fp32 oracle (the parity statement itself) OR within the referee rule's tolerance
+    # of the run that referees it; rows are ranked by the smaller of the two ratios
+    rows = [((min(r[0], r[6] / 1e-4) if r[6] == r[6] else r[0]),) + r[1:] for r in rows]
+    rows.sort(reverse=True)
+    worst = rows[0]
+    plain = max(r[6] for r in rows if r[6] == r[6])
+    if worst[0] <= 1.0:
+        verdict = "ok" if plain <= 1e-4 else "ok-referee"
+    else:
+        verdict = "FAIL"
+    return rows, verdict, plain
+
+
+def run(out_path, commit, families):
+    import torch  # noqa: F401
+    from fresnel_amd import _binding
+    lib = _binding.load()
+    ver = _binding.version() if hasattr(_binding, "version") else lib.fgs_version().decode()
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    f = open(out_path, "w")
+
+    def emit(s):
+        print(s, flush=True)
+        f.write(s + "\n"); f.flush()
+
+    emit(f"# randomized sweeps, HIP vs precomputed oracle (fp32) with the fp64 referee build; scratch/fuzz/sweep.py")
+    emit(f"# library: {ver}   commit: {commit}   date: {time.strftime('%Y-%m-%d %H:%M:%S')}")
+    emit("# per case: verdict | worst tensor by (error / tolerance) | error vs the run that referees it | tolerance | the oracle's own fp32-vs-fp64 spread | "
+         "plain max error vs the fp32 oracle over all tensors | seconds")
+    emit("# verdicts: ok = every tensor <= 1e-4 of max against the fp32 oracle; ok-referee = some tensor is > 1e-4 from the fp32 oracle but the oracle's own "
+         "fp32 run is > 5e-5 from its fp64 run there and the HIP result is <= 2 x that spread from the fp64 run (conditioning of the scene, tests/helpers.py); "
+         "FAIL = neither; CRASH = exception")
+    tally = {}
+    for fam in families:
+        seeds, gen = FAMILIES[fam]
+        for seed in seeds:
+            path = os.path.join(REPLAY, f"{fam}_s{seed}.npz")
+            if not os.path.exists(path):
+                emit(f"== {fam} seed {seed}: NO REPLAY FILE ({path}) -- run `sweep.py precompute {fam}` in the build container")
+                tally["MISSING"] = tally.get("MISSING", 0) + 1
+                continue
+            z = np.load(path)
+            emit(f"== {fam} seed {seed}")
+            for c in gen(seed):
+                t0 = time.time()
+                exp = {tag: {k.split("/")[2]: z[k] for k in z.files if k.startswith(f"{c['it']}/{tag}/")} for tag in ("f32", "f64")}
+                for k, v in exp["f32"].items():  # (fp64 run not stored: it agrees with the fp32 run to 2e-5, the fp32 run referees)
+                    exp["f64"].setdefault(k, v)
+                try:
+                    hip = _hip_case(fam, c)
+                    torch.cuda.synchronize()
+                    rows, verdict, plain = rank(fam, hip, exp)
+                    w = rows[0]
+                    line = (f"{verdict:10s} {fam} s{seed} it {c['it']:2d} {_describe(fam, c)} | {w[1]} | {w[2]:.2e} vs {'fp64' if w[5] else 'fp32'} | tol {w[3]:.1e} | "
+                            f"spread {w[4]:.1e} | plain {plain:.2e} | {time.time() - t0:.1f}s")
+                    if verdict != "ok":
+                        os.makedirs(os.path.join(ROOT, "gpurun_out", "sweep_dump"), exist_ok=True)  # the HIP side, for analysis off the box
+                        np.savez_compressed(os.path.join(ROOT, "gpurun_out", "sweep_dump", f"{fam}_s{seed}_it{c['it']}.npz"), **hip)
+                        line += "\n" + "\n".join(f"             {r[1]:12s} err {r[2]:.2e} ({'fp64' if r[5] else 'fp32'} referee) tol {r[3]:.1e} spread {r[4]:.1e} vs-fp32 {r[6]:.2e}"
+                                                 for r in rows if r[6] > 1e-4 or r[0] > 1.0)
+                except Exception as e:  # noqa: BLE001 -- the log must say what died and where
+                    verdict = "CRASH"
+                    line = f"CRASH      {fam} s{seed} it {c['it']:2d} {_describe(fam, c)} | {type(e).__name__}: {e} | {time.time() - t0:.1f}s"
+                tally[verdict] = tally.get(verdict, 0) + 1
+                emit(line)
+    emit("# tally: " + ", ".join(f"{k} {v}" for k, v in sorted(tally.items())))
+    f.close()
+    return 0 if not (tally.get("FAIL") or tally.get("CRASH") or tally.get("MISSING")) else 1
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    if not args or args[0] not in ("precompute", "run"):
+        sys.exit(__doc__)
+    if args[0] == "precompute":
+        precompute(args[1:] or list(FAMILIES))
+    else:
+        commit = "unknown"
+        rest = args[2:]
+        if "--commit" in rest:
+            i = rest.index("--commit"); commit = rest[i + 1]; rest = rest[:i] + rest[i + 2:]
+        sys.exit(run(args[1], commit, rest or list(FAMILIES)))

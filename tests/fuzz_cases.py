@@ -49,3 +49,70 @@ def asm_cases(seed, n_iter=14):
                       pixel_pitch=1.0 / float(rs.choice([128, 256])))
             case.update(kind="asm", P=P, wl=wl, kw=kw)
         yield case
+
+
+def blend_cases(seed, n_iter=40):
+    """Blend path (TileBasedRenderer): odd frame sizes, N = 1 ... 2500, radius caps 8 ... 150, off-centre principal points, random
+    backgrounds, 16- and 32-wide tiles (the draws of round 2-4's scratch/fuzz/fuzz.py, in its order)."""
+    rs = np.random.RandomState(seed)
+    for it in range(n_iter):
+        W, H = int(rs.randint(5, 200)), int(rs.randint(5, 150))
+        N = int(rs.choice([1, 3, 17, 63, 64, 65, 200, 900, 2500]))
+        maxr = float(rs.choice([8, 20, 64, 150]))
+        smax = float(rs.choice([0.02, 0.1, 0.4]))
+        arrs = list(synth_aniso(N, int(rs.randint(1 << 30)), opacity_max=float(rs.choice([0.5, 1.0, 1.3])), smax=smax))
+        bg = tuple(float(x) for x in rs.rand(3))
+        fx = float(rs.uniform(0.5, 1.5) * W)
+        cx = W / 2 + rs.uniform(-3, 3)
+        cy = H / 2 + rs.uniform(-3, 3)
+        gI = rs.standard_normal((3, H, W)).astype(np.float32)
+        gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
+        tile_w = int(rs.choice([16, 32]))
+        yield dict(it=it, W=W, H=H, N=N, maxr=maxr, smax=smax, arrs=arrs, bg=bg, fx=fx, cx=float(cx), cy=float(cy), gI=gI, gD=gD,
+                   tile_w=tile_w)
+
+
+BATCH_SCALE_RANGES = [(0.003, 1.5), (0.01, 0.3), (0.02, 0.15)]
+
+
+def batch_cases(seed, scale_range=2, n_iter=16):
+    """Batched renders with one orbit camera per image, points around the origin (some behind the camera / huge / tiny); the
+    camera of image b is create_camera_from_pose(el[b], az[b], S, distance=dist[b])."""
+    rs = np.random.RandomState(seed)
+    for it in range(n_iter):
+        S = int(rs.choice([32, 64, 100, 144])); Bn = int(rs.choice([1, 2, 5])); N = int(rs.choice([40, 300, 1500]))
+        pos = (rs.standard_normal((Bn, N, 3)) * float(rs.choice([0.3, 1.0, 2.5]))).astype(np.float32)
+        smin, smax = BATCH_SCALE_RANGES[scale_range]
+        scale = np.exp(rs.uniform(np.log(smin), np.log(smax), (Bn, N, 3))).astype(np.float32)
+        quat = rs.standard_normal((Bn, N, 4)).astype(np.float32)
+        col = rs.rand(Bn, N, 3).astype(np.float32); opa = rs.uniform(0.0, 1.1, (Bn, N)).astype(np.float32)
+        poses = [(float(rs.uniform(-1.2, 1.2)), float(rs.uniform(0, 6.28)), float(rs.uniform(1.0, 4.0))) for _ in range(Bn)]
+        bg = tuple(float(x) for x in rs.rand(3))
+        gI = rs.standard_normal((Bn, 3, S, S)).astype(np.float32); gD = (rs.standard_normal((Bn, S, S)) * 0.1).astype(np.float32)
+        yield dict(it=it, S=S, B=Bn, N=N, arrs=[pos, scale, quat, col, opa], poses=poses, bg=bg, gI=gI, gD=gD)
+
+
+def asm_batched_cases(seed, n_iter=24):
+    """Batched angular-spectrum renderer on column-kernel shapes (power-of-two heights, whole column tiles), depth bands that
+    leave planes empty (the draws of round 3's scratch/fuzz/fuzz_asm_batched.py, in its order)."""
+    rs = np.random.RandomState(1000 + seed)
+    for it in range(n_iter):
+        H = int(rs.choice([64, 64, 128, 256])); W = 16 * int(rs.randint(4, 26)); P = int(rs.choice([2, 5, 6, 9, 16])); Bn = int(rs.choice([1, 2, 3, 5]))
+        N = int(rs.choice([40, 150, 300]))
+        near, far = 0.3, float(rs.uniform(1.5, 3.0))
+        bg = tuple(float(x) for x in rs.rand(3) * 0.3)
+        per = []
+        for b in range(Bn):
+            a = list(synth_aniso(N, int(rs.randint(1 << 30)), opacity_max=0.9, smin=0.03, smax=float(rs.choice([0.06, 0.12]))))
+            if H > W: a[0][:, 1] *= H / W * 0.6
+            lo = float(rs.uniform(near, far - 0.2)); hi = float(rs.uniform(lo + 0.1, far))
+            a[0][:, 2] = -rs.uniform(lo, hi, N).astype(np.float32)
+            per.append(a)
+        arrs = [np.stack([p[i] for p in per]) for i in range(5)]
+        phases = (rs.random_sample((Bn, N, 3)) * 2 * np.pi).astype(np.float32)
+        wl = np.array([0.07, 0.052, 0.043], np.float32) * float(rs.uniform(0.8, 1.3))
+        gI = rs.standard_normal((Bn, 3, H, W)).astype(np.float32)
+        f = 0.8 * min(W, H)
+        kw = dict(num_depth_planes=P, depth_range=(near, far), focal_depth=float(rs.uniform(0.5, 1.5)),
+                  pixel_pitch=1.0 / float(rs.choice([128, 200, 256])))
+        yield dict(it=it, W=W, H=H, P=P, B=Bn, N=N, arrs=arrs, phases=phases, wl=wl, bg=bg, gI=gI, f=f, kw=kw)

@@ -64,6 +64,33 @@ def _worker(rank, world, port, outdir, mode):
             p.grad = torch.full_like(p, float(rank + 1))
         dp.allreduce_gradients(list(lin.parameters()))
         torch.save([p.grad.clone() for p in lin.parameters()], os.path.join(outdir, f"g{rank}.pt"))
+        # (round 5) the adopted path: .grad tensors ARE slices of the flat bucket, autograd accumulates in place, the exchange
+        # is one all-reduce with nothing to pack -- same numbers as the packing path above, the loss / flag riding behind
+        lin2 = torch.nn.Linear(3, 2)
+        with torch.no_grad():
+            for p in lin2.parameters():
+                p.fill_(0.5)
+        ps = list(lin2.parameters())
+        n0 = dp.collectives
+        for step in range(3):
+            dp.adopt(ps)
+            views = [p.grad for p in ps]
+            (lin2(torch.full((4, 3), float(rank + 1))).sum() * (step + 1)).backward()
+            assert all(p.grad is v for p, v in zip(ps, views)), "autograd replaced an adopted .grad"
+            lo, hi = dp._bucket.data_ptr(), dp._bucket.data_ptr() + 4 * dp._bucket.numel()
+            assert all(lo <= p.grad.data_ptr() < hi for p in ps)
+            extra = dp.allreduce_gradients(ps, extra=torch.tensor([float(rank), 10.0 * (rank + 1)]))
+            assert torch.equal(extra, torch.tensor([1.0, 30.0]))
+            # d/dW sum(W x + b) = sum over the 4 rows of x = 4 (rank + 1) per entry, averaged over the ranks: 6; bias: 4
+            assert torch.allclose(ps[0].grad, torch.full_like(ps[0], 6.0 * (step + 1)))
+            assert torch.allclose(ps[1].grad, torch.full_like(ps[1], 4.0 * (step + 1)))
+        assert dp.collectives - n0 == 3, "one gradient all-reduce per step"
+        # a caller that dropped the gradients (zero_grad(set_to_none=True)) is packed by one foreach copy and re-adopted
+        for p in ps:
+            p.grad = None
+        lin2(torch.full((4, 3), float(rank + 1))).sum().backward()
+        dp.allreduce_gradients(ps)
+        assert torch.allclose(ps[0].grad, torch.full_like(ps[0], 6.0)) and ps[0].grad.data_ptr() == dp._views[0].data_ptr()
         torch.save(dp.shard(8), os.path.join(outdir, f"s{rank}.pt"))
         for bad in (7, 1):  # uneven shards / fewer images than ranks: refused, never an empty shard
             try:
@@ -81,7 +108,7 @@ def _worker(rank, world, port, outdir, mode):
         poison = 1 if mode == "nan" else None
         factory = lambda c, dev: (StubRenderer(c.image_size, poison), None)
         model, hist = run_training(cfg, dp, renderer_factory=factory, log=lambda *a: None)
-        torch.save({"sd": model.state_dict(), "hist": hist}, os.path.join(outdir, f"m{rank}.pt"))
+        torch.save({"sd": model.state_dict(), "hist": hist, "collectives": dp.collectives}, os.path.join(outdir, f"m{rank}.pt"))
     dp.shutdown()
 
 
@@ -104,6 +131,8 @@ def test_two_rank_training_matches_single_rank():
     m0, m1 = torch.load(os.path.join(d2, "m0.pt")), torch.load(os.path.join(d2, "m1.pt"))
     for k in m0["sd"]:
         assert torch.equal(m0["sd"][k], m1["sd"][k]), f"ranks diverged on {k}"
+    # ONE gradient-bucket all-reduce per optimizer step (2 epochs x 2 steps), nothing per parameter
+    assert m0["collectives"] == 4 and m1["collectives"] == 4
     d1 = _spawn("train", world=1)
     s = torch.load(os.path.join(d1, "m0.pt"))
     # mean-of-shard-means == global mean for equal shards, and the depth loss is normalised with GLOBAL-batch

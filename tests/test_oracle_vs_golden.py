@@ -234,3 +234,23 @@ def test_wave_renderer_g10(tag):
     assert rel_to_max(r["depth"], g["depth"]) <= 1e-5
     for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"]:
         assert rel_to_max(r["grad_" + k], g["grad_" + k]) <= 1e-4, k
+
+
+def test_wave_oracles_zero_visible_is_the_plain_background():
+    """DR:801-808 / DR:1207-1212: with no visible Gaussian both wave renderers return the background itself -- not the
+    intensity floor sqrt(1e-8) on top of it -- and zero gradients.  (The torch oracle lacked the branch until round 5: two
+    N = 1 cases of the randomized sweeps, the one Gaussian culled, sat exactly 1.00e-4 from the HIP path.)"""
+    from oracle import asm_oracle, fgs_oracle as orc
+    W, H, bg = 24, 16, (0.2, 0.1, 0.3)
+    cam = orc.make_camera(np.eye(4, dtype=np.float32), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
+    pos = np.array([[0.0, 0.0, 3.0], [0.1, 0.0, 2.0]], np.float32)  # behind the camera (it looks down -z)
+    scale = np.full((2, 3), 0.05, np.float32); quat = np.tile(np.array([[1, 0, 0, 0]], np.float32), (2, 1))
+    col = np.full((2, 3), 0.5, np.float32); opa = np.full(2, 0.8, np.float32); ph = np.array([0.3, 1.0], np.float32)
+    gI = np.ones((3, H, W), np.float32)
+    want = np.broadcast_to(np.asarray(bg, np.float32).reshape(3, 1, 1), (3, H, W))
+    r = asm_oracle.render(pos, scale, quat, col, opa, ph, np.array([0.06, 0.05, 0.04], np.float32), cam, bg=bg, grad_out=gI)
+    w = asm_oracle.render_wave(pos, scale, quat, col, opa, ph, cam, bg=bg, grad_out=gI, grad_depth=np.ones((H, W), np.float32))
+    for out in (r, w):
+        assert np.array_equal(out["image"], want)
+        assert all(not np.any(out["grad_" + k]) for k in ["positions", "scales", "rotations", "colors", "opacities", "phases"])
+    assert not np.any(w["depth"]) and not np.any(r["grad_wavelengths"])
