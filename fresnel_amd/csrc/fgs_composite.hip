@@ -856,14 +856,22 @@ __global__ __launch_bounds__(256) void k_phase_bwd(
             float Af = ck[wave * 64], Pf = ck[(4 + wave) * 64];
             // ---- forward re-run of the group: park (A_{i-1}, Phi_{i-1}) ----
             float sA[PCK], sP[PCK];
-#if FGS_PHASE_PARK
+#if FGS_PHASE_PARK == 1
             float sG[PCK], sI[PCK];
+#elif FGS_PHASE_PARK == 2
+            float sG[PCK];
+#elif FGS_PHASE_PARK == 3
+            float sI[PCK];
 #endif
 #pragma unroll
             for (int k = 0; k < PCK; ++k) {
                 sA[k] = 0.0f; sP[k] = 0.0f;
-#if FGS_PHASE_PARK
+#if FGS_PHASE_PARK == 1
                 sG[k] = 0.0f; sI[k] = 0.0f;
+#elif FGS_PHASE_PARK == 2
+                sG[k] = 0.0f;
+#elif FGS_PHASE_PARK == 3
+                sI[k] = 0.0f;
 #endif
                 if (k >= (int)m) continue;  // wave-uniform
                 const float4 q0 = st.a[j0 + k], q1 = st.b[j0 + k], q2 = st.c[j0 + k];
@@ -877,7 +885,12 @@ __global__ __launch_bounds__(256) void k_phase_bwd(
                 float pd = fabsf(q2.z - Pf);
                 pd = fminf(pd, 1.0f - pd);
                 const float Ik = base_amp + amp * phase_cos(pd * PHASE_KAPPA);
-                sG[k] = Gk; sI[k] = Ik;
+#if FGS_PHASE_PARK != 3
+                sG[k] = Gk;
+#endif
+#if FGS_PHASE_PARK != 2
+                sI[k] = Ik;
+#endif
                 const float alpha = __builtin_amdgcn_fmed3f((Gk * q1.y) * Ik, 0.0f, ALPHA_MAX);
 #else
                 float alpha = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E) * q1.y;
@@ -907,11 +920,15 @@ __global__ __launch_bounds__(256) void k_phase_bwd(
                 const float pd0 = fabsf(dphi);
                 const float pd = fminf(pd0, 1.0f - pd0);
                 // G zeroed outside the bbox: raw, alpha, w, pc and every gradient term of this pixel then vanish by themselves
-#if FGS_PHASE_PARK
-                const float G = sG[k], inter = sI[k];
+#if FGS_PHASE_PARK == 1 || FGS_PHASE_PARK == 2
+                const float G = sG[k];
 #else
                 const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
                 const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E)) & mk);
+#endif
+#if FGS_PHASE_PARK == 1 || FGS_PHASE_PARK == 3
+                const float inter = sI[k];
+#else
                 const float inter = base_amp + amp * phase_cos(pd * PHASE_KAPPA);
 #endif
                 // (parking G and `inter` of the re-run instead of recomputing them costs 14 VGPRs = one wave per SIMD and

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void k_project(
             o3[0] = (wv[0][0] | wv[1][0]) | (wv[2][0] | wv[3][0]);
             o3[1] = (wv[0][1] & wv[1][1]) & (wv[2][1] & wv[3][1]);
             o3[2] = (wv[0][2] | wv[1][2]) | (wv[2][2] | wv[3][2]);
+            o3[3] = 0u;  // (the record's fourth word: nobody reads it, but `saved` holds no uninitialised words)
         }
     }
 }
@@ -270,10 +271,13 @@ __global__ __launch_bounds__(256) void k_row_sum(int32_t total, int32_t N, uint3
 // contiguous 48-byte gradient rows in a fixed order (deterministic), then chains
 // (dL/dmean2d, dL/dconic, dL/ddepth) to (dL/dpos, dL/dscale, dL/dquat), recomputing the forward
 // intermediates from the inputs (cheaper than saving ~60 floats per Gaussian).
-// ASM = true: rows come from the angular-spectrum splat backward and hold
-//   (dL/du, dL/dv, dL/dconic[3], dL/dopacity, dL/d(c cos phi)[3], dL/d(c sin phi)[3]);
-// colour and phase gradients are formed here and no gradient flows through depth (the depth
-// only selects the plane, DR:1147-1148).
+// MODE 1 (ASM): rows come from the angular-spectrum splat backward (k_asm_splat<BWD>, fgs_asm.hip) and hold the MOMENTS of
+//   t = dL/da G about the Gaussian's mean (round 4): slots 0-1 the first moments (sum t dx, sum t dy), 2-4 the second moments
+//   (sum t dx^2, sum t dx dy, sum t dy^2), 5 the zeroth (sum t = dL/dopacity before the chain), 6-8 dL/d(c cos phi)[3],
+//   9-11 dL/d(c sin phi)[3].  The chain through a = G opacity and m is applied HERE, once per Gaussian, in double:
+//   dL/dconic = -1/2 opacity (second moments), dL/d(u, v) = 1/2 opacity conic_sym (first moments).  This row format is a
+//   contract between the two translation units.  Colour and phase gradients are formed here and no gradient flows through
+//   depth (the depth only selects the plane, DR:1147-1148).
 // MODE 2 (WaveFieldRenderer): ASM rows widened to 16 floats, slot 12 = dL/ddepth (amplitude-weighted depth map)
 // PRESUM: the rows were already summed by k_row_sum (blend path): ONE thread per Gaussian reads its ten totals from
 // `grad_rows` (= the per-Gaussian sums, [input index][12] floats) -- all 64 lanes of a wave run the double-precision adjoint

@@ -146,6 +146,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_upsweep(
 }
 
 // One wave per (segment, digit): exclusive scan along the block axis, digit total to dtot.
+// (Key compression never comes here: it requires bps <= 64, the fused scan.  Were it to, the rows of segments whose upsweep
+// blocks left early -- pass >= live -- would be unwritten; harmless only because their downsweep blocks leave early too.)
 __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *__restrict__ hist, uint32_t *__restrict__ dtot,
                                                     uint32_t bps, uint32_t num_rows) {
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);  // seg*256 + digit
@@ -392,8 +394,11 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
         kin = kout; kout = next_out;
         vin = vdst;
     }
-    *keys_sorted = const_cast<uint32_t *>(kin);
-    *vals_sorted = vin;
+    // Key compression: a segment stops after its own number of live passes, so NO buffer holds every segment's sorted keys
+    // (the pass-4 buffer has stale data for segments that needed fewer) and the payload is in vals_final: hand back no key
+    // pointer rather than one that looks valid (the depth sort's caller reads `order` only).
+    *keys_sorted = compressed ? nullptr : const_cast<uint32_t *>(kin);
+    *vals_sorted = compressed ? vals_final : vin;
     return FGS_OK;
 }
 

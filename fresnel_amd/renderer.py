@@ -73,7 +73,7 @@ class Camera:
         camera is enough."""
         vm = self.view_matrix
         key = (str(device), float(self.fx), float(self.fy), float(self.cx), float(self.cy), float(self.near),
-               float(self.far), vm._version)
+               float(self.far), _tensor_version(vm))
         # the cache entry holds the matrix OBJECT it was built from (compared with `is`: an id() alone can be reused
         # by a later tensor once this one is freed) and a copy of its 16 values (catches edits through .data, which
         # leave _version unchanged; view matrices live on the host, so this costs no device sync)
@@ -116,6 +116,16 @@ def pack_cameras(cameras: Union[Camera, Sequence[Camera]], device) -> torch.Tens
     return torch.tensor([c.packed() for c in cameras], dtype=torch.float32, device=device)
 
 
+def _tensor_version(t):
+    """Version counter of a tensor, or None for an inference tensor (created under torch.inference_mode(): it tracks no
+    version -- reading `_version` raises -- and cannot be edited in place outside inference mode; callers treat None as
+    "cannot tell": the cache is then keyed by object identity and value, or refreshed).  ADVICE r4."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def _phase_channels(ph: torch.Tensor) -> int:
     """Phases are (B,N) -- one per Gaussian -- or (B,N,3) per colour channel (DR:772-776, DR:1170-1176); the kernels
     read exactly that many floats per Gaussian, so anything else is refused here (a (B,N,1) tensor is NOT three
@@ -131,8 +141,35 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_handle():
+    """hipStream_t of the current device's current stream.  (torch.cuda.current_stream().cuda_stream builds a Stream object
+    per call: ~7 us, twice per image on the per-image route; the raw getter is ~0.3 us.)"""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` without its cost when `dev` is current already (the usual case: ~11 us per image saved
+    on the per-image route, profiles/r05_host_profile_config1.txt)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev):
+        self.idx = dev.index
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.idx is not None and self.idx != self.prev:
+            torch.cuda.set_device(self.idx)
+        else:
+            self.prev = None
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
 
 
 class _Cfg:
@@ -177,7 +214,8 @@ _SCRATCH: dict = {}
 
 
 def _scratch_for(dev, nbytes):
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device()) if _raw_stream is not None
+           else torch.cuda.current_stream(dev).cuda_stream)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -208,7 +246,7 @@ def forward_raw(positions, scales, rotations, colors, opacities, phases, cam_ten
     ph = _f32c(phases) if (cfg.use_phase and phases is not None) else None
     cam_tensor = _f32c(cam_tensor)
     dims, saved_bytes, scratch_bytes = _dims_for(Bn, N, cfg, ph is not None, cam_tensor.shape[0])
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
         scratch = _scratch_for(dev, scratch_bytes)
         out_rgb = torch.empty((Bn, 3, cfg.height, cfg.width), dtype=torch.float32, device=dev)
@@ -257,7 +295,7 @@ class GaussianRenderer(torch.autograd.Function):
         g_rgb = (g_rgb if g_rgb is not None else torch.zeros(dims.batch, 3, dims.height, dims.width, device=dev))
         g_depth = (g_depth if g_depth is not None else torch.zeros(dims.batch, dims.height, dims.width, device=dev))
         g_rgb, g_depth = _f32c(g_rgb), _f32c(g_depth)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             scratch = _scratch_for(dev, ctx.scratch_bytes)
             g_pos, g_scl, g_rot = torch.empty_like(pos), torch.empty_like(scl), torch.empty_like(rot)
             g_col, g_opa = torch.empty_like(col), torch.empty_like(opa)
@@ -399,7 +437,7 @@ class AsmRenderer(torch.autograd.Function):
         d.num_cameras = cam_tensor.shape[0]
         d.bin_mode = int(cfg.get("bin_mode", 0))  # FgsAsmDims.bin_mode: list-building override for A/B runs and tests
         sb, cb = ctypes.c_size_t(0), ctypes.c_size_t(0)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             B.check(lib.fgs_asm_workspace_bytes(ctypes.byref(d), ctypes.byref(sb), ctypes.byref(cb)),
                     "fgs_asm_workspace_bytes")
             saved = torch.empty(sb.value, dtype=torch.uint8, device=dev)
@@ -426,7 +464,7 @@ class AsmRenderer(torch.autograd.Function):
         d = ctx.dims
         dev = pos.device
         g_out = g_out.contiguous().float()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             scratch = torch.empty(ctx.scratch_bytes, dtype=torch.uint8, device=dev)
             g_pos, g_scl, g_rot = torch.empty_like(pos), torch.empty_like(scl), torch.empty_like(rot)
             g_col, g_opa, g_ph = torch.empty_like(col), torch.empty_like(opa), torch.empty_like(ph)
@@ -452,7 +490,7 @@ class _AsmPropagate(torch.autograd.Function):
         zt = z.detach().reshape(1).float().contiguous().to(dev)
         wl = wavelengths.detach().reshape(C).float().contiguous().to(dev)
         cb = ctypes.c_size_t(0)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             B.check(lib.fgs_asm_propagate_workspace_bytes(H, W, C, ctypes.byref(cb)), "fgs_asm_propagate_workspace_bytes")
             scratch = torch.empty(cb.value, dtype=torch.uint8, device=dev)
             out = torch.empty_like(f)
@@ -472,7 +510,7 @@ class _AsmPropagate(torch.autograd.Function):
         H, W, C, pitch, bl, cbytes = ctx.cfg
         dev = spec.device
         g = torch.view_as_real(g_out.detach().to(torch.complex64).contiguous())
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             scratch = torch.empty(cbytes, dtype=torch.uint8, device=dev)
             g_field = torch.empty_like(g)
             g_z = torch.empty(1, dtype=torch.float32, device=dev)
@@ -543,10 +581,16 @@ class _HostBackground:
         self._bg_mark()
 
     def _bg_mark(self):
-        object.__setattr__(self, "_bg_src", (self.background, self.background._version))
+        object.__setattr__(self, "_bg_src", (self.background, _tensor_version(self.background)))
+
+    def _bg_fresh(self, b):
+        """The host copy still describes `b`: same object, same version.  An inference tensor has no version counter
+        (_tensor_version -> None): it counts as stale -- one read-back per call instead of an exception."""
+        v = _tensor_version(b)
+        return b is self._bg_src[0] and v is not None and v == self._bg_src[1]
 
     def _apply(self, fn, *a, **k):
-        stale = not (self.background is self._bg_src[0] and self.background._version == self._bg_src[1])
+        stale = not self._bg_fresh(self.background)
         out = super()._apply(fn, *a, **k)
         if not stale:
             self._bg_mark()
@@ -554,7 +598,7 @@ class _HostBackground:
 
     def _background_host(self):
         b = self.background
-        if not (b is self._bg_src[0] and b._version == self._bg_src[1]):
+        if not self._bg_fresh(b):
             self._bg = [float(v) for v in b.detach().cpu().tolist()]
             self._bg_mark()
         return self._bg
@@ -634,7 +678,7 @@ class WaveRenderer(torch.autograd.Function):
         d.phase_channels = _phase_channels(ph)
         d.num_cameras = cam_tensor.shape[0]
         sb, cb = ctypes.c_size_t(0), ctypes.c_size_t(0)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             B.check(lib.fgs_wave_workspace_bytes(ctypes.byref(d), ctypes.byref(sb), ctypes.byref(cb)),
                     "fgs_wave_workspace_bytes")
             saved = torch.empty(sb.value, dtype=torch.uint8, device=dev)
@@ -656,7 +700,7 @@ class WaveRenderer(torch.autograd.Function):
         dev = pos.device
         g_out = (g_out if g_out is not None else torch.zeros(d.batch, 3, d.height, d.width, device=dev)).contiguous().float()
         g_dep = (g_dep if g_dep is not None else torch.zeros(d.batch, d.height, d.width, device=dev)).contiguous().float()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             scratch = torch.empty(ctx.scratch_bytes, dtype=torch.uint8, device=dev)
             g_pos, g_scl, g_rot = torch.empty_like(pos), torch.empty_like(scl), torch.empty_like(rot)
             g_col, g_opa, g_ph = torch.empty_like(col), torch.empty_like(opa), torch.empty_like(ph)

@@ -305,7 +305,8 @@ def default_renderer_factory(cfg: TrainingConfig, device, res: Optional[int] = N
         if cfg.use_fresnel_zones:
             # the decoder snaps depths to `num_fresnel_zones` values (GDM:834-841): the zone-key depth sort then needs one
             # radix pass instead of four (FgsDims.sort_mode, fgs_sort.hip); a work-split choice, the order is the same
-            renderer.tuning = dict(sort_mode=1)
+            renderer.tuning = dict(renderer.tuning or {})
+            renderer.tuning.setdefault("sort_mode", 1)  # (merged: an existing tuning, or an explicit sort_mode=0, is kept -- ADVICE r4)
     camera = Camera(fx=res * 0.8, fy=res * 0.8, cx=res / 2, cy=res / 2, width=res, height=res)
     return renderer, camera
 
