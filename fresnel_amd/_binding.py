@@ -96,6 +96,9 @@ def load():
     vp, cp = ctypes.c_void_p, ctypes.POINTER
     lib.fgs_last_error.restype = ctypes.c_char_p
     lib.fgs_version.restype = ctypes.c_char_p
+    if b"EXPERIMENT" in lib.fgs_version():  # an A/B build selected through FGS_LIB: say so, once, where nobody can miss it
+        import sys
+        sys.stderr.write(f"fresnel_amd: loaded {LIB_PATH}: {lib.fgs_version().decode()}\n")
     lib.fgs_workspace_bytes.argtypes = [cp(FgsDims), cp(ctypes.c_size_t), cp(ctypes.c_size_t)]
     lib.fgs_saved_layout.argtypes = [cp(FgsDims), cp(FgsSavedLayout)]
     lib.fgs_forward.argtypes = [cp(FgsDims)] + [vp] * 12
@@ -138,6 +141,11 @@ def load():
         fn.restype = ctypes.c_int
     _lib = lib
     return lib
+
+
+def version():
+    """fgs_version() of the loaded library (experiment builds list their defines there)."""
+    return load().fgs_version().decode()
 
 
 def check(rc, what):

@@ -84,7 +84,14 @@ def build(force=False, verbose=False, defines=(), suffix=""):
         # experiment builds: FGS_BUILD_EXTRA_<FILE STEM> = extra compiler flags for one file (e.g. scheduler options)
         more = os.environ.get("FGS_BUILD_EXTRA_" + name.split(".")[0].upper(), "").split()
         common = COMMON if name.endswith(".hip") else [c for c in COMMON if "offload" not in c and "gpu-rdc" not in c]
-        cmd = [hipcc] + common + extra + more + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
+        # experiment builds: every unit sees FGS_EXPERIMENT_BUILD (timing-only switches #error without it), and fgs_version() lists
+        # the defines (fgs_api.hip), so a library selected through FGS_LIB says what it is
+        exp = []
+        if defines or more:
+            exp = ["-DFGS_EXPERIMENT_BUILD=1"]
+            if name == "fgs_api.hip":
+                exp.append('-DFGS_BUILD_DEFINES="' + " ".join(list(defines) + more).replace('"', "'") + '"')
+        cmd = [hipcc] + common + extra + more + ["-D" + d for d in defines] + exp + ["-c", src, "-o", obj]
         # an object is stale when its source or a header is newer OR when it was compiled with another command line (the
         # flags live in this file: editing them must rebuild)
         stamp = obj + ".cmd"

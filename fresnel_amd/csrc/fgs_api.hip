@@ -80,7 +80,18 @@ int fgs_stage_timing_read(float *ms, int32_t *count) {
     g_recs.clear();
     return FGS_OK;
 }
-const char *fgs_version(void) { return "fgs-hip 0.1 (gfx950)"; }
+// Experiment builds (python -m fresnel_amd.build --define X=1 --suffix _x, selected through FGS_LIB for same-box A/B runs) say so
+// here: build.py hands every unit FGS_EXPERIMENT_BUILD and this one the list of the defines, the Python binding prints the string to
+// stderr when it loads such a library, and the records of the sweeps / benches carry fgs_version() -- a library built with a
+// timing-only switch can not pass for the product unnoticed.
+#ifdef FGS_EXPERIMENT_BUILD
+#ifndef FGS_BUILD_DEFINES
+#define FGS_BUILD_DEFINES "(defines not recorded)"
+#endif
+const char *fgs_version(void) { return "fgs-hip 0.2 (gfx950) EXPERIMENT BUILD, NOT THE PRODUCT: " FGS_BUILD_DEFINES; }
+#else
+const char *fgs_version(void) { return "fgs-hip 0.2 (gfx950)"; }
+#endif
 
 int fgs_workspace_bytes(const FgsDims *dims, size_t *saved_bytes, size_t *scratch_bytes) {
     FgsPlan p;

@@ -957,7 +957,7 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
             while ((1u << pbits) < (uint32_t)p.layers) ++pbits;
             uint32_t *vs2;
             if ((rc = fgs_launch_radix_sort(keys0, vals0, keys1, vals1, order, &plane_keys, &vs2, N, nullptr, N, N, B, pbits, hist, st,
-                                            reinterpret_cast<const uint32_t *>(saved + p.s_layer), N)))
+                                            reinterpret_cast<const uint32_t *>(saved + p.s_layer), N, nullptr, 0, p.d.sort_mode >> 1)))
                 return rc;
         } else {
             hipLaunchKernelGGL(k_index_order, dim3(nblk), dim3(256), 0, st, total, N, order);
@@ -965,8 +965,8 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         }
     } else if ((rc = fgs_launch_radix_sort(keys0, vals0, keys1, vals1, layered_direct ? nullptr : order, &ks, &vs, N, nullptr, N, N,
                                            B, 32, hist, st, depth_key, N,
-                                           (layered_direct || p.d.sort_mode != 1) ? nullptr : reinterpret_cast<const uint32_t *>(saved + p.s_keybits),
-                                           (N + 255u) / 256u))) {
+                                           (layered_direct || !(p.d.sort_mode & 1)) ? nullptr : reinterpret_cast<const uint32_t *>(saved + p.s_keybits),
+                                           (N + 255u) / 256u, p.d.sort_mode >> 1))) {
         return rc;
     }
     if (p.depth_ordered && layered_direct) {
@@ -979,7 +979,8 @@ int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t
         uint32_t pbits = 0;
         while ((1u << pbits) < (uint32_t)p.layers) ++pbits;
         uint32_t *ks2, *vs2;
-        if ((rc = fgs_launch_radix_sort(kfree, vs, ks, vfree, order, &ks2, &vs2, N, nullptr, N, N, B, pbits, hist, st)))
+        if ((rc = fgs_launch_radix_sort(kfree, vs, ks, vfree, order, &ks2, &vs2, N, nullptr, N, N, B, pbits, hist, st, nullptr, 0,
+                                        nullptr, 0, p.d.sort_mode >> 1)))
             return rc;
         plane_keys = ks2;
     }

@@ -20,6 +20,10 @@
 #include "fgs_internal.h"
 #include "fgs_wave.h"
 
+#if (defined(FGS_BWD_DYN_LDS) || defined(FGS_BWD_WIDE_WAVES) || defined(FGS_PHASE_PARK) || defined(FGS_PHASE_SCAN) || defined(FGS_CKPT_NT)) && !defined(FGS_EXPERIMENT_BUILD)
+#error "work-split / timing switches of this unit are for experiment builds: python -m fresnel_amd.build --define ... (sets FGS_EXPERIMENT_BUILD; fgs_version() then says so)"
+#endif
+
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -643,11 +647,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6
             // into this duplicate's gradient row: no atomics, fixed order, bitwise reproducible ----
             {
                 const float vals[10] = {v_mx, v_my, v_ca, v_cbc, v_cd, v_op, v_r, v_g, v_b, v_d};
-#ifdef FGS_WHATIF_HALF_REDUCTIONS
-                // TIMING EXPERIMENT ONLY (wrong gradients): what a reduction shared by two list entries could save AT MOST --
-                // every second entry's reduction and row store cost nothing (profiles/r04_ab_whatif_half_reductions.txt)
-                if (j & 1u) { asm volatile("" :: "v"(vals[0]), "v"(vals[1]), "v"(vals[2]), "v"(vals[3]), "v"(vals[4]), "v"(vals[5]), "v"(vals[6]), "v"(vals[7]), "v"(vals[8]), "v"(vals[9])); continue; }
-#endif
                 const float tot = wave_sum10_addtid(red, vals, lane);
                 const uint32_t kk = lane >> 2, e = she[j];
                 // (16-float rows: all sixteen quads' last lanes store, lanes >= 40 a zero -- one whole 64-byte line)

@@ -52,7 +52,9 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
                           uint32_t index_payload_mod = 0,
                           const uint32_t *key_stats = nullptr /* depth sort: k_project's per-block OR / AND of the visible keys:
                                                                  sort by the bits that vary, skip the passes nobody needs */,
-                          uint32_t key_recs = 0 /* records per segment */);
+                          uint32_t key_recs = 0 /* records per segment */,
+                          int pass_mode = 0 /* 0 = automatic (fused single-launch passes for segments of <= 4096 keys) | 1 = fused
+                                               passes, 11-bit digits, up to 64 K keys | 2 = fused passes, 8-bit digits (fgs_sort.hip) */);
 
 int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t st);
 

@@ -319,6 +319,224 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
     }
 }
 
+// ---- FUSED PASS (round 5): one launch per radix pass, no histogram hand-off between blocks -------------------------------------
+// The depth sort's launches sit at the launch floor (8 launches of ~4.9 us for 16 x 8192 keys that move 1 MB): what a pass costs is
+// its launch boundaries, not its bytes.  Here every block of a segment forms the segment's digit histogram BY ITSELF -- the digits
+// in front of its own key range (`pre`) and from its range on (`rest`) -- by reading ALL keys of the segment (<= 64 K keys = 256 KB
+// from L2, ONE LDS atomic per key; a wave whose 64 keys share a digit -- quantised depths -- adds once), so the upsweep launch and
+// its histogram round trip disappear without any inter-block communication (no flags, no spinning, nothing that can hang: the
+// redundant reads are the price, ~1 us per pass at 8 192 keys per segment, ~3 us at 32 768).  Digits are BITS = 11 wide: three
+// passes over 32-bit keys instead of four (2048 bins: `pre`, `rest` / running offsets and the four waves' rank counters = 48 KB of
+// LDS).  Ranking and scatter are k_radix_downsweep's (wave64 ballots, stable, no atomics in the scatter).
+// Depth sort: 8 launches -> 3; with key compression a dead pass is one launch of blocks that read ~100 words and leave.
+template <int BITS>
+struct KeyPlanW {
+    uint32_t live;        // passes this segment needs (>= 1)
+    uint32_t sh[BITS];    // source bit of digit bit i of the current pass
+    uint32_t vmask;       // digit bits that exist in this pass
+    uint32_t cull;        // digit of a culled key in this pass
+    uint32_t plain;       // != 0: the compressed key would need more passes than the plain one has: the key's own bits then
+};
+
+template <int BITS>
+__device__ __forceinline__ KeyPlanW<BITS> key_plan_w(const uint32_t *__restrict__ bits, uint32_t nrec, uint32_t seg, uint32_t pass,
+                                                     uint32_t *kb /* 12 + BITS + 3 words */) {
+    constexpr uint32_t MAXP = (32u + BITS - 1u) / BITS;
+    uint32_t vor = 0u, vand = 0xFFFFFFFFu, fl = 0u;
+    for (uint32_t i = threadIdx.x; i < nrec; i += RS_THREADS) {
+        const uint4 r = reinterpret_cast<const uint4 *>(bits)[(size_t)seg * nrec + i];
+        vor |= r.x; vand &= r.y; fl |= r.z;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vor |= __shfl_xor(vor, o, 64); vand &= __shfl_xor(vand, o, 64); fl |= __shfl_xor(fl, o, 64); }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) { kb[3 * wave] = vor; kb[3 * wave + 1] = vand; kb[3 * wave + 2] = fl; }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)BITS) {
+        uint32_t o = 0u, a = 0xFFFFFFFFu, f = 0u;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) { o |= kb[3 * w]; a &= kb[3 * w + 1]; f |= kb[3 * w + 2]; }
+        const uint32_t m = (f & 2u) ? (o ^ a) : 0u;  // no visible key: nothing varies
+        const uint32_t nbits = (uint32_t)__popc(m), cull = f & 1u;
+        const uint32_t idx = (uint32_t)BITS * pass + threadIdx.x;
+        uint32_t mm = m;
+        for (uint32_t j = 0; j < idx && mm; ++j) mm &= mm - 1u;
+        kb[12 + threadIdx.x] = (idx < nbits) ? (uint32_t)__ffs((int)mm) - 1u : 32u;
+        if (threadIdx.x == 0) {
+            const uint32_t need = (nbits + cull + BITS - 1u) / BITS;
+            kb[12 + BITS] = need < 1u ? 1u : (need > MAXP ? MAXP : need);
+            kb[13 + BITS] = (cull && nbits >= BITS * pass && nbits < BITS * pass + BITS) ? 1u << (nbits - BITS * pass) : 0u;
+            kb[14 + BITS] = need > MAXP ? 1u : 0u;  // (8-bit digits: 33 bits -- every key bit varies and some keys are culled)
+        }
+    }
+    __syncthreads();
+    KeyPlanW<BITS> kp;
+    kp.live = kb[12 + BITS];
+    kp.cull = kb[13 + BITS];
+    kp.plain = kb[14 + BITS];
+    kp.vmask = 0u;
+#pragma unroll
+    for (int i = 0; i < BITS; ++i) {
+        const uint32_t p = kb[12 + i];
+        kp.sh[i] = p & 31u;
+        kp.vmask |= (p < 32u ? 1u : 0u) << i;
+    }
+    return kp;
+}
+
+template <int BITS>
+__device__ __forceinline__ uint32_t key_digit_w(const KeyPlanW<BITS> &kp, uint32_t key, uint32_t pass) {
+    if (kp.plain) return (key >> (BITS * pass)) & ((1u << BITS) - 1u);  // block-uniform
+    uint32_t d = 0u;
+#pragma unroll
+    for (int i = 0; i < BITS; ++i) d |= ((key >> kp.sh[i]) & 1u) << i;
+    return key == 0xFFFFFFFFu ? kp.cull : (d & kp.vmask);
+}
+
+template <int BITS, bool COMPRESSED>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_fused(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, uint32_t seg_len, uint32_t seg_stride, uint32_t shift, uint32_t dmask, uint32_t idx_mod,
+    const uint32_t *__restrict__ key_bits, uint32_t key_recs, uint32_t pass, uint32_t *__restrict__ vals_final) {
+    constexpr uint32_t NB = 1u << BITS, DPT = NB / RS_THREADS;  // bins; bins per thread
+    __shared__ uint32_t pre[NB];               // digits of the segment's keys in front of this block's range
+    __shared__ uint32_t rest[NB];              // ... from this block's range on; then the running output offset per digit
+    __shared__ uint32_t wcnt[RS_WAVES][NB];    // the four waves' running digit counters of a round
+    __shared__ uint32_t wtot[RS_WAVES];
+    __shared__ uint32_t kb[12 + BITS + 3];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    KeyPlanW<BITS> kp;
+    if (COMPRESSED) {
+        kp = key_plan_w<BITS>(key_bits, key_recs, blockIdx.y, pass, kb);
+        if (pass >= kp.live) return;                        // this segment is sorted already
+        if (pass + 1u == kp.live) vals_out = vals_final;    // its last live pass: the payload goes to its final place
+    }
+    auto digit_of = [&](uint32_t key) -> uint32_t {
+        if constexpr (COMPRESSED) return key_digit_w<BITS>(kp, key, pass);
+        else return (key >> shift) & dmask;
+    };
+    const SegInfo r = block_range(seg_len, nullptr, seg_len, seg_stride);
+    const uint32_t seg0 = blockIdx.y * seg_stride, seg_end = seg0 + seg_len;
+    constexpr uint32_t ROUND = RS_THREADS * 4;
+    uint32_t key[4], val[4];
+    bool valid[4];
+    auto load_round = [&](uint32_t base) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t i = base + wave * 256u + it * 64u + lane;
+            valid[it] = i < r.end;
+            key[it] = valid[it] ? keys_in[i] : 0u;
+            val[it] = valid[it] ? (vals_in ? vals_in[i] : i % idx_mod) : 0u;
+        }
+    };
+#pragma unroll
+    for (uint32_t k = 0; k < DPT; ++k) {
+        pre[tid + k * RS_THREADS] = 0u; rest[tid + k * RS_THREADS] = 0u;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) wcnt[w][tid + k * RS_THREADS] = 0u;
+    }
+    __syncthreads();
+    // ---- the segment's digit histogram, split at this block's first key (r.begin is a multiple of 1024: a wave instruction's
+    // 64 consecutive keys lie on one side) ----
+    for (uint32_t i0 = seg0 + tid; i0 - tid < seg_end; i0 += ROUND) {
+        uint32_t k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k4[u] = i0 + u * RS_THREADS < seg_end ? keys_in[i0 + u * RS_THREADS] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * RS_THREADS;
+            const bool v = i < seg_end;
+            const uint32_t d = digit_of(k4[u]);
+            const unsigned long long act = __ballot(v);
+            if (act == 0ull) continue;  // wave-uniform
+            uint32_t *h = (__builtin_amdgcn_readfirstlane(i) < r.begin) ? pre : rest;
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);  // (lane 0 of the wave: valid whenever any lane is)
+            if (__ballot(v && d == d0) == act) {
+                if (lane == 0) atomicAdd(&h[d0], (uint32_t)__popcll(act));  // the wave's 64 keys share one digit (quantised depths)
+            } else if (v) {
+                atomicAdd(&h[d], 1u);
+            }
+        }
+    }
+    load_round(r.begin);  // (this block's first keys travel under the scan below)
+    __syncthreads();
+    // ---- exclusive scan over the NB digit totals; running output offset of every digit for THIS block ----
+    {
+        uint32_t t[DPT], p[DPT], loc = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < DPT; ++k) { p[k] = pre[tid * DPT + k]; t[k] = p[k] + rest[tid * DPT + k]; loc += t[k]; }
+        uint32_t sc = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(sc, o, 64);
+            if ((int)lane >= o) sc += v;
+        }
+        if (lane == 63) wtot[wave] = sc;
+        __syncthreads();  // (every thread has read its bins of `rest`)
+        uint32_t run = seg0 + (sc - loc);
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) run += (w < (int)wave) ? wtot[w] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < DPT; ++k) { rest[tid * DPT + k] = run + p[k]; run += t[k]; }
+    }
+    __syncthreads();
+    uint32_t *run_off = rest;
+    for (uint32_t base = r.begin; base < r.end; base += ROUND) {
+        uint32_t lrank[4], dig[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t digit = digit_of(key[it]);
+            dig[it] = digit;
+            unsigned long long m = __ballot(valid[it]);
+#pragma unroll
+            for (int bit = 0; bit < BITS; ++bit) {
+                const bool bset = (digit >> bit) & 1u;
+                const unsigned long long bm = __ballot(valid[it] && bset);
+                m &= bset ? bm : ~bm;
+            }
+            const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t prev = valid[it] ? wcnt[wave][digit] : 0u;
+            lrank[it] = prev + rank;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (valid[it] && rank == 0) wcnt[wave][digit] = prev + (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            if (valid[it]) {
+                const uint32_t digit = dig[it];
+                uint32_t pr = 0;
+#pragma unroll
+                for (int w = 0; w < RS_WAVES; ++w) pr += (w < (int)wave) ? wcnt[w][digit] : 0u;
+                const uint32_t dst = run_off[digit] + pr + lrank[it];
+                keys_out[dst] = key[it];
+                vals_out[dst] = val[it];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < DPT; ++k) {
+            const uint32_t d = tid + k * RS_THREADS;
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) { tot += wcnt[w][d]; wcnt[w][d] = 0; }
+            run_off[d] += tot;
+        }
+        if (base + ROUND < r.end) load_round(base + ROUND);
+        __syncthreads();
+    }
+}
+
+// blocks per segment of the fused pass: ~2048 keys of its own per block (ranking costs ~6x the histogram per key), <= 16 (every
+// block reads the whole segment), <= 4096 blocks per launch
+uint32_t fused_blocks_per_seg(uint32_t seg_len, uint32_t num_segs) {
+    uint32_t bps = (seg_len + 2047u) / 2048u;
+    if (bps > 16u) bps = 16u;
+    while (bps > 1u && (size_t)bps * num_segs > 4096u) bps >>= 1;
+    return bps < 1u ? 1u : bps;
+}
+
 uint32_t dmask_of(uint32_t p, uint32_t width, uint32_t key_bits) {
     const uint32_t left = key_bits - p * width;
     return (1u << (left < width ? left : width)) - 1u;
@@ -331,7 +549,47 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
                           uint32_t seg_len, const uint32_t *seg_len_dev, uint32_t seg_capacity,
                           uint32_t seg_stride, uint32_t num_segs, uint32_t key_bits, uint32_t *hist,
                           hipStream_t st, const uint32_t *keys_first, uint32_t index_payload_mod,
-                          const uint32_t *key_stats, uint32_t key_recs) {
+                          const uint32_t *key_stats, uint32_t key_recs, int pass_mode) {
+    // pass_mode (FgsDims.sort_mode >> 1): 0 = automatic -- the fused pass (one launch per pass, 11-bit digits) for segments of at most
+    // 4096 keys (one or two blocks per segment: little or nothing is read twice, and 8 launches become 3 where launches are all there
+    // is), the two-launch 8-bit passes of rounds 1-4 otherwise | 1 = the fused pass with 11-bit digits for any host-known segment
+    // length up to 64 K keys | 2 = the same with 8-bit digits (A/B runs, agreement tests).  Measured (profiles/r05_ab_sort_passes.txt):
+    // at 16 x 8 192 keys the fused passes take 45.6 us (11-bit) / 55.5 (8-bit) against 42.0 for the two-launch passes, at 8 x 32 768
+    // keys 100.9 / 127.8 against 53.8 -- every block counting the WHOLE segment's digits with LDS atomics costs more than the launch
+    // boundary it saves (~2.8 us); a pass is two memory round trips whichever way it is launched.
+    const bool fused = !seg_len_dev && seg_len == seg_capacity && key_bits >= 1u &&
+                       (pass_mode == 0 ? seg_len <= 4096u : seg_len <= 65536u);
+    if (fused) {
+        const bool compressed = key_stats != nullptr;
+        if (compressed && !(keys_first && index_payload_mod && vals_final && key_recs && key_bits == 32u)) {
+            fgs_set_error("radix sort: key compression needs 32-bit keys in keys_first, an index payload and vals_final");
+            return FGS_EINVAL;
+        }
+        const uint32_t bits = (pass_mode == 2 || key_bits <= 8u) ? 8u : 11u;  // (plane ids, <= 5 bits: the small histogram)
+        const uint32_t passes = (key_bits + bits - 1u) / bits, width = (key_bits + passes - 1u) / passes;
+        const dim3 grid(fused_blocks_per_seg(seg_len, num_segs), num_segs);
+        const uint32_t *kin = keys_first ? keys_first : keys_in;
+        uint32_t *vin = vals_in, *kout = keys_first ? keys_in : keys_alt, *kspare = keys_alt;
+        for (uint32_t p = 0; p < passes; ++p) {
+            uint32_t *vdst = (p == passes - 1 && vals_final) ? vals_final : (vin == vals_in ? vals_alt : vals_in);
+            if (p == 0 && index_payload_mod && !(passes == 1 && vals_final)) vdst = vals_in;  // vals_in is free: nothing to read
+            const uint32_t *vsrc = (p == 0 && index_payload_mod) ? nullptr : vin;
+            const uint32_t shift = p * width, dmask = dmask_of(p, width, key_bits), imod = index_payload_mod ? index_payload_mod : 1u;
+#define FGS_FUSED_LAUNCH(B_, C_)                                                                                             \
+    hipLaunchKernelGGL((k_radix_fused<B_, C_>), grid, dim3(RS_THREADS), 0, st, kin, vsrc, kout, vdst, seg_len, seg_stride, shift, \
+                       dmask, imod, key_stats, key_recs, p, vals_final)
+            if (bits == 8u) { if (compressed) FGS_FUSED_LAUNCH(8, true); else FGS_FUSED_LAUNCH(8, false); }
+            else            { if (compressed) FGS_FUSED_LAUNCH(11, true); else FGS_FUSED_LAUNCH(11, false); }
+#undef FGS_FUSED_LAUNCH
+            FGS_LAUNCH_CHECK("k_radix_fused");
+            uint32_t *next_out = (p == 0 && keys_first) ? kspare : const_cast<uint32_t *>(kin);
+            kin = kout; kout = next_out;
+            vin = vdst;
+        }
+        *keys_sorted = compressed ? nullptr : const_cast<uint32_t *>(kin);  // (compressed: see the end of this function)
+        *vals_sorted = compressed ? vals_final : vin;
+        return FGS_OK;
+    }
     const uint32_t bps = fgs_radix_blocks_per_seg(seg_capacity, num_segs);
     // key compression (depth sort): full 32-bit keys read from keys_first, the index as payload, a final place for the payload
     const bool compressed = key_stats != nullptr;

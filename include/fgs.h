@@ -68,11 +68,15 @@ typedef struct FgsDims {
     int32_t tile_w;         /* tile width in pixels: 0 | 16 | 32 (tiles are always 16 rows high).  0 = automatic:
                                32 on the blend path with the depth-split forward for frames >= 512 pixels wide
                                in calls of >= 3072 16 x 16 tiles, 16 elsewhere (FgsSavedLayout.tile_w tells)    */
-    int32_t sort_mode;      /* depth sort: 0 = four 8-bit radix passes over the 32 key bits | 1 = "zone keys" (BASELINE config 4,
+    int32_t sort_mode;      /* depth sort.  Bit 0: 0 = radix passes over the 32 key bits | 1 = "zone keys" (BASELINE config 4,
                                --use_fresnel_zones: depths snapped to a few values): the keys are compressed to the bits that
                                vary over an image's visible Gaussians and only the passes those need do any work -- the same
-                               order for ANY depths, faster when they vary in <= 24 bits, ~20 % slower otherwise.  NOT chosen
-                               automatically: what the depths look like is known on the device only (fgs_sort.hip)      */
+                               order for ANY depths, faster when they vary in few bits.  NOT chosen automatically: what the
+                               depths look like is known on the device only (fgs_sort.hip).
+                               Bits 1-2 (work split, never the result): 0 = automatic -- ONE launch per pass with 11-bit digits
+                               (three passes; round 5) for images of <= 4096 Gaussians, the two-launch 8-bit passes of
+                               rounds 1-4 above | 2 = one launch per pass, 11-bit digits, for any image of <= 65 536 Gaussians
+                               | 4 = the same with 8-bit digits.  Valid values: 0 ... 5.                                   */
 } FgsDims;
 
 /* Camera record on the DEVICE: FGS_CAMERA_FLOATS floats per camera (Camera, DR:27-52):

@@ -145,3 +145,17 @@ def test_new_entries_validate_arguments_without_a_gpu(lib):
     assert lib.fgs_asm_propagate_workspace_bytes(0, 8, 1, None) == -1
     lib.fgs_reduction_scratch_bytes.restype = ctypes.c_size_t
     assert lib.fgs_reduction_scratch_bytes() >= 8192
+
+
+def test_product_library_is_not_an_experiment_build(lib):
+    """fgs_version() names experiment builds (python -m fresnel_amd.build --define ...: FGS_EXPERIMENT_BUILD + the list of defines,
+    fgs_api.hip): the library the tests, the bench and the sweeps load must be the product.  The timing-only switches of the
+    compositing unit refuse to compile without that marker, and the wrong-results switch of round 4
+    (FGS_WHATIF_HALF_REDUCTIONS) is gone from the source."""
+    lib.fgs_version.restype = ctypes.c_char_p
+    v = lib.fgs_version().decode()
+    assert v.startswith("fgs-hip") and "EXPERIMENT" not in v, v
+    src = open(os.path.join(ROOT, "fresnel_amd", "csrc", "fgs_composite.hip")).read()
+    assert "FGS_WHATIF" not in src and "#error" in src and "FGS_EXPERIMENT_BUILD" in src
+    import fresnel_amd.build as fb
+    assert "FGS_EXPERIMENT_BUILD" in open(fb.__file__).read()
