@@ -60,6 +60,17 @@ WORKLOADS = {
 # duplicates, N = Gaussians, B = images, HW = pixels per image, U = depth-segment units beyond each tile's first.
 FLOPS_PER_PAIR = {"composite_fwd": 23.0, "composite_bwd": 60.0,   # SURVEY §8d "Which roofline"
                   "splat_fwd": 12.0, "splat_bwd": 36.0}            # 6 MACs per pair; adjoint 3x
+# Phase path (config 4), round 5: its OWN per-pair count (until round 4 it was scored with the blend path's 23 / 60).
+# Counted from the recurrence DR:629-667 and its adjoint, FMA = 2, every exp / cos / sin / divide = 1:
+#   forward 38 = dx, dy (2) + quadratic form (8) + exp, x opacity (2) + |phi - Phi|, min(pd, 1 - pd) (3) + 2 pi pd, cos, (1 - amp) + amp cos,
+#                x alpha (5) + clamp (1) + w = alpha (1 - A) (2) + C, D, A += (9) + pc = w / max(A, 1e-6) (2) + Phi update (4);
+#   backward 71 = the same per-pair quantities recomputed (dx, dy, quadratic form, exp, phase difference, cos, raw alpha: 23) + the adjoint
+#                sweep (w-bar incl. gI.c + gD d: 11, colour / depth sums 4, A-bar / Phi-bar updates 9, clamp / min / sign selects 0, sin and
+#                the phase chain 8, dL/dopacity 1, moments of dL/dm 9, pc-bar chain 6).  The re-run of the forward between checkpoints
+#                (~45 flop per pair) is the implementation's price for not storing (A, Phi) per pair and is NOT credited.
+FLOPS_PER_PAIR_PHASE = {"composite_fwd": 38.0, "composite_bwd": 71.0}
+PHASE_CKPT_BYTES_PER_DUP = 115  # (A, Phi) of 64 lanes = 512 B per group of <= 8 touched entries of a sub-tile wave: ~3.6 groups per 64-entry
+                                # scan block and wave at config 4 (~40 % of a tile's entries touch a given sub-tile) x 4 waves / 64 entries
 ASM_BYTES_PER_IMAGE = 0.36e9  # SURVEY §8d "ASM": 51 FFTs of 512^2 with the linearity trick, per direction
 
 
@@ -617,8 +628,10 @@ def main(argv=None):
             "project": per_gpu * N * (56 + 48 + 8),
             "depth_sort": per_gpu * N * 8 * (1 + 2 * 4),
             "list_building": per_gpu * N * 8 + 4 * D_local,  # dup_emit + tile_ranges + tile_sort stages together
-            "composite_fwd": per_gpu * ((40 if args.workload == "config4" else 36) * HW) + 52 * D_local + ckpt_bytes * extra_units,  # state planes + rgb + depth out
-            "composite_bwd": per_gpu * (36 * HW) + (52 + row_bytes) * D_local + ckpt_bytes * extra_units,
+            "composite_fwd": per_gpu * ((40 if args.workload == "config4" else 36) * HW) + 52 * D_local + ckpt_bytes * extra_units  # state planes + rgb + depth out
+                             + (PHASE_CKPT_BYTES_PER_DUP * D_local if args.workload == "config4" else 0),  # phase path: (A, Phi) checkpoints written ...
+            "composite_bwd": per_gpu * (36 * HW) + (52 + row_bytes) * D_local + ckpt_bytes * extra_units
+                             + (PHASE_CKPT_BYTES_PER_DUP * D_local if args.workload == "config4" else 0),  # ... and read back
             "project_bwd": row_bytes * D_local + per_gpu * N * 2 * 56,
             "field_fwd": ASM_BYTES_PER_IMAGE * per_gpu, "field_bwd": ASM_BYTES_PER_IMAGE * per_gpu,
         }
@@ -634,10 +647,11 @@ def main(argv=None):
             if dur <= 0:
                 return None
             if name in FLOPS_PER_PAIR:  # per-pair blend / splat arithmetic on the vector ALU (no MFMA: gather/blend)
-                tfl = FLOPS_PER_PAIR[name] * pairs_local / dur / 1e12
+                fpp = FLOPS_PER_PAIR_PHASE.get(name, FLOPS_PER_PAIR[name]) if args.workload == "config4" else FLOPS_PER_PAIR[name]
+                tfl = fpp * pairs_local / dur / 1e12
                 return {"bound": "valu", "achieved": round(tfl, 3), "peak": FP32_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(tfl / FP32_VECTOR_PEAK_TF, 5), "avg_launch_ms": round(avg_ms[name], 4),
-                        "algorithmic_flops_per_launch": int(FLOPS_PER_PAIR[name] * pairs_local),
+                        "algorithmic_flops_per_launch": int(fpp * pairs_local), "flops_per_pair": fpp,
                         "algorithmic_bytes_per_launch": int(alg_bytes[name]) if name in alg_bytes else None}
             gbs = alg_bytes[name] / dur / 1e9
             return {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -664,8 +678,9 @@ def main(argv=None):
             roofline["traffic_source"] = (f"profiles/r04_pmc_summary.json run {run_key}: 2*FETCH_SIZE + WRITE_SIZE summed over all "
                                           "kernels of field_fwd AND field_bwd per step; algorithmic counterpart = "
                                           f"{int(2 * ASM_BYTES_PER_IMAGE * per_gpu)} bytes")
-        roofline["flop_model"] = ("SURVEY 8d: 23 flop per Gaussian-pixel forward, 60 backward (phase path: same count, its extra "
-                                  "cos/sin/divide work is not credited); splat 12 / 36; peak = fp32 vector peak (plain, "
+        roofline["flop_model"] = ("SURVEY 8d: 23 flop per Gaussian-pixel forward, 60 backward; phase path (config 4): its own count, 38 / 71 "
+                                  "(recurrence DR:629-667 and its adjoint, FMA = 2, exp / cos / sin / divide = 1; the checkpoint re-run is not "
+                                  "credited; bytes include the (A, Phi) checkpoint stream); splat 12 / 36; peak = fp32 vector peak (plain, "
                                   "non-packed VALU code tops out at about half of it, DESIGN.md section 4)")
         stages = {}
         for name in ("project", "depth_sort", "list_building", "composite_fwd", "composite_bwd", "splat_fwd", "field_fwd",

@@ -20,7 +20,7 @@
 #include "fgs_internal.h"
 #include "fgs_wave.h"
 
-#if (defined(FGS_BWD_DYN_LDS) || defined(FGS_BWD_WIDE_WAVES) || defined(FGS_PHASE_PARK) || defined(FGS_PHASE_SCAN) || defined(FGS_CKPT_NT)) && !defined(FGS_EXPERIMENT_BUILD)
+#if (defined(FGS_BWD_DYN_LDS) || defined(FGS_BWD_WIDE_WAVES) || defined(FGS_PHASE_PARK) || defined(FGS_PHASE_SCAN) || defined(FGS_CKPT_NT) || defined(FGS_PHASE_WAVE_BLOCKS)) && !defined(FGS_EXPERIMENT_BUILD)
 #error "work-split / timing switches of this unit are for experiment builds: python -m fresnel_amd.build --define ... (sets FGS_EXPERIMENT_BUILD; fgs_version() then says so)"
 #endif
 
@@ -679,6 +679,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6
 #define FGS_PHASE_PARK 0   /* 1: the backward's re-run also parks G and the interference factor of every entry (registers) */
 #endif
 static_assert(FGS_PHASE_SCAN <= 64 && FGS_PHASE_SCAN % FGS_PHASE_CKPT == 0, "scan block");
+#ifndef FGS_PHASE_WAVE_BLOCKS
+#define FGS_PHASE_WAVE_BLOCKS 0  /* 1 (experiment): every sub-tile wave is a workgroup of its own -- see phase_wave_block */
+#endif
+// FGS_PHASE_WAVE_BLOCKS: grid = 4 x (tiles rounded up to 8) single-wave blocks.  Blocks are dealt round-robin over the 8 XCDs;
+// block L serves launch slot (L / 32) * 8 + L % 8 as sub-tile wave (L / 8) % 4, so the four waves of a tile land on ONE XCD
+// (they share the tile's list through its L2) and consecutive slots of the heavy-first order spread over all eight.
+__device__ __forceinline__ bool phase_wave_block(uint32_t total_slots, uint32_t &slot, uint32_t &wave) {
+    const uint32_t L = blockIdx.x;
+    slot = (L >> 5) * 8u + (L & 7u);
+    wave = (L >> 3) & 3u;
+    return slot < total_slots;
+}
 struct PhaseRec {                 // one compacted list entry in wave-private LDS
     float4 a[FGS_PHASE_SCAN];     // u, v, conic a, conic b + c
     float4 b[FGS_PHASE_SCAN];     // conic d, opacity, colour r, g
@@ -720,17 +732,25 @@ __device__ __forceinline__ unsigned long long phase_scan(PhaseRec &st, uint32_t 
     return touched;
 }
 
-__global__ __launch_bounds__(256) void k_phase_fwd(
+__global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_fwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
     const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ dup_ids,
     const float *__restrict__ rec, const float *__restrict__ phase, float *__restrict__ pix_state,
-    float *__restrict__ phase_ckpt, float *__restrict__ out_rgb, float *__restrict__ out_depth) {
+    float *__restrict__ phase_ckpt, float *__restrict__ out_rgb, float *__restrict__ out_depth, uint32_t total_slots) {
     constexpr int PCK = FGS_PHASE_CKPT;
-    __shared__ PhaseRec st4[4];
+    __shared__ PhaseRec st4[FGS_PHASE_WAVE_BLOCKS ? 1 : 4];
+#if FGS_PHASE_WAVE_BLOCKS
+    uint32_t pslot, wave;
+    if (!phase_wave_block(total_slots, pslot, wave)) return;
+    const TileCtx c = tile_ctx_of(tile_order[pslot], tiles, tiles_x, ranges);
+    const uint32_t lane = threadIdx.x & 63u;
+    PhaseRec &st = st4[0];
+#else
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     PhaseRec &st = st4[wave];
+#endif
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t sx = c.X0 + 8u * (wave & 1u), sy = c.Y0 + 8u * (wave >> 1);
     float fpx = (float)(sx + lx), fpy = (float)(sy + ly);
@@ -794,23 +814,34 @@ __global__ __launch_bounds__(256) void k_phase_fwd(
 // sweeps the group back-to-front with the per-pixel adjoints Abar (init -gI.bg) and Phibar.  Every touched (entry, sub-tile)
 // gets its OWN gradient row (row 4 e + w; k_project_bwd repeats the integer test and never reads the rows of untouched
 // sub-tiles): no cross-wave reduction.
-__global__ __launch_bounds__(256) void k_phase_bwd(
+__global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
     uint32_t tiles, uint32_t tiles_x, uint32_t W, uint32_t H, float bg0, float bg1, float bg2, float amp,
     uint32_t dcap, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ dup_ids, const float *__restrict__ rec, const float *__restrict__ phase,
     const uint32_t *__restrict__ dup_off, const float *__restrict__ pix_state,
     const float *__restrict__ phase_ckpt, const float *__restrict__ g_rgb, const float *__restrict__ g_depth,
-    float *__restrict__ grad_rows) {
+    float *__restrict__ grad_rows, uint32_t total_slots) {
     constexpr int PCK = FGS_PHASE_CKPT;
-    __shared__ PhaseRec st4[4];
-    __shared__ uint32_t rows4[4][FGS_PHASE_SCAN];
-    __shared__ __attribute__((aligned(16))) float red4[4][11 * FGS_RED_PITCH];  // reduction scratch, one per wave
+    constexpr int NWB = FGS_PHASE_WAVE_BLOCKS ? 1 : 4;
+    __shared__ PhaseRec st4[NWB];
+    __shared__ uint32_t rows4[NWB][FGS_PHASE_SCAN];
+    __shared__ __attribute__((aligned(16))) float red4[NWB][11 * FGS_RED_PITCH];  // reduction scratch, one per wave
+#if FGS_PHASE_WAVE_BLOCKS
+    uint32_t pslot, wave;
+    if (!phase_wave_block(total_slots, pslot, wave)) return;
+    const TileCtx c = tile_ctx_of(tile_order[pslot], tiles, tiles_x, ranges);
+    const uint32_t lane = threadIdx.x & 63u;
+    PhaseRec &st = st4[0];
+    uint32_t *rows = rows4[0];
+    float *red = red4[0];
+#else
     const TileCtx c = tile_ctx(tiles, tiles_x, tile_order, ranges);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     PhaseRec &st = st4[wave];
     uint32_t *rows = rows4[wave];
     float *red = red4[wave];
+#endif
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const size_t HW = (size_t)W * H;
     const uint32_t sx = c.X0 + 8u * (wave & 1u), sy = c.Y0 + 8u * (wave >> 1);
@@ -993,10 +1024,11 @@ int fgs_launch_composite_fwd(const FgsPlan &p, const float *phase, char *saved, 
     const uint32_t *seg_off = reinterpret_cast<const uint32_t *>(saved + p.L.seg_off);
     float *seg_ckpt = reinterpret_cast<float *>(saved + p.L.seg_ckpt);
     if (p.d.use_phase) {  // one wave per 8 x 8 sub-tile, four per block
-        hipLaunchKernelGGL(k_phase_fwd, dim3(grid), dim3(256), 0, st, (uint32_t)p.tiles, (uint32_t)p.L.tiles_x, (uint32_t)p.d.width,
+        hipLaunchKernelGGL(k_phase_fwd, dim3(FGS_PHASE_WAVE_BLOCKS ? (grid + 7u) / 8u * 32u : grid), dim3(FGS_PHASE_WAVE_BLOCKS ? 64 : 256), 0, st,
+                           (uint32_t)p.tiles, (uint32_t)p.L.tiles_x, (uint32_t)p.d.width,
                            (uint32_t)p.d.height, p.d.background[0], p.d.background[1], p.d.background[2], p.d.phase_amplitude,
                            tile_order, ranges, dup_ids, rec, phase, pix, reinterpret_cast<float *>(saved + p.L.phase_ckpt), out_rgb,
-                           out_depth);
+                           out_depth, grid);
         FGS_LAUNCH_CHECK("k_phase_fwd");
         return FGS_OK;
     }
@@ -1039,7 +1071,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
     (void)g_phase;  // dL/dphase travels in the gradient rows and is written by k_project_bwd
     const uint32_t grid = (uint32_t)p.d.batch * p.tiles;
     if (p.d.use_phase) {
-        hipLaunchKernelGGL(k_phase_bwd, dim3(grid), dim3(256), 0, st, (uint32_t)p.tiles,
+        hipLaunchKernelGGL(k_phase_bwd, dim3(FGS_PHASE_WAVE_BLOCKS ? (grid + 7u) / 8u * 32u : grid), dim3(FGS_PHASE_WAVE_BLOCKS ? 64 : 256), 0, st, (uint32_t)p.tiles,
                            (uint32_t)p.L.tiles_x, (uint32_t)p.d.width, (uint32_t)p.d.height, p.d.background[0],
                            p.d.background[1], p.d.background[2], p.d.phase_amplitude, (uint32_t)p.L.dup_capacity,
                            reinterpret_cast<const uint32_t *>(saved + p.L.tile_order),
@@ -1049,7 +1081,7 @@ int fgs_launch_composite_bwd(const FgsPlan &p, const float *phase, const char *s
                            reinterpret_cast<const uint32_t *>(saved + p.L.dup_off),
                            reinterpret_cast<const float *>(saved + p.L.pix_state),
                            reinterpret_cast<const float *>(saved + p.L.phase_ckpt), g_rgb, g_depth,
-                           reinterpret_cast<float *>(scratch + p.s_grows));
+                           reinterpret_cast<float *>(scratch + p.s_grows), grid);
         FGS_LAUNCH_CHECK("k_phase_bwd");
         return FGS_OK;
     }
