@@ -45,7 +45,8 @@ def _import_compute():
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (packed / dual-issue rate)
 DECODER_GRAD_FLOATS = 673_537  # DirectPatchDecoder gradient bucket (measured)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (5, 4)) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r05_pmc_summary.json"))  # this round's counters; the previous round's until they exist
 
 WORKLOADS = {
     # name: (N gaussians, resolution, images per GPU)   -- BASELINE.json configs[1..4]
@@ -117,7 +118,7 @@ def pmc_field_traffic(run_key):
 
 def pmc_traffic(run_key, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r04_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per the gfx950
+    (profiles/r0N_pmc_summary.json of this round: separate FETCH_SIZE / WRITE_SIZE passes, 2*FETCH + WRITE per the gfx950
     correction of MI355X_MICROARCH.md).  None when that run was not profiled."""
     if not os.path.exists(PMC_SUMMARY):
         return None
@@ -668,14 +669,14 @@ def main(argv=None):
         roofline.update(stage_roofline(dom_stage))
         traffic = pmc_traffic(run_key, kernel_names[dom_stage].split("<")[0]) if not args.saturation_skip else None
         roofline["traffic"] = traffic
-        roofline["traffic_source"] = (f"profiles/r04_pmc_summary.json run {run_key}: separate rocprofv3 --pmc FETCH_SIZE / "
+        roofline["traffic_source"] = (f"profiles/" + os.path.basename(PMC_SUMMARY) + " run {run_key}: separate rocprofv3 --pmc FETCH_SIZE / "
                                       "WRITE_SIZE passes of this command, 2*FETCH_SIZE + WRITE_SIZE per launch"
                                       if traffic is not None else None)
         if dom_stage in ("field_fwd", "field_bwd") and pmc_field_traffic(run_key) is not None:
             # a stage of many kernels (rocFFT's + ours): the counters are summed over BOTH field stages of a step, to
             # be compared with the algorithmic bytes of both (2 x 0.36 GB per image)
             roofline["traffic"] = pmc_field_traffic(run_key)
-            roofline["traffic_source"] = (f"profiles/r04_pmc_summary.json run {run_key}: 2*FETCH_SIZE + WRITE_SIZE summed over all "
+            roofline["traffic_source"] = (f"profiles/" + os.path.basename(PMC_SUMMARY) + " run {run_key}: 2*FETCH_SIZE + WRITE_SIZE summed over all "
                                           "kernels of field_fwd AND field_bwd per step; algorithmic counterpart = "
                                           f"{int(2 * ASM_BYTES_PER_IMAGE * per_gpu)} bytes")
         roofline["flop_model"] = ("SURVEY 8d: 23 flop per Gaussian-pixel forward, 60 backward; phase path (config 4): its own count, 38 / 71 "
