@@ -1,9 +1,15 @@
-"""Soak: many steps of every path; memory must stay flat and results finite (not a test)."""
-import sys, torch, numpy as np
+"""Soak: many steps of every path; memory must stay flat and results finite (not a test).
+python scratch/fuzz/soak.py [commit]  -- every run prints its elapsed seconds; the header carries fgs_version() and the commit."""
+import sys, time, torch, numpy as np
 sys.path.insert(0, '.')
 import bench; bench._import_compute()
 from fresnel_amd import renderer as R
 dev = torch.device('cuda:0')
+from fresnel_amd import _binding as _B
+print(f"# soak, library: {_B.version()}   commit: {sys.argv[1] if len(sys.argv) > 1 else 'unknown'}   date: {time.strftime('%Y-%m-%d %H:%M:%S')}", flush=True)
+_T0 = [time.time()]
+def _lap():
+    t = time.time() - _T0[0]; _T0[0] = time.time(); return t
 def run(tag, n_img, N, S, steps, use_phase=False, skip=False):
     pos, scale, quat, col, opa = bench.synth_batch(n_img, N, 77, dev)
     leaves = [t.requires_grad_(True) for t in (pos, scale, quat, col, opa)]
@@ -19,7 +25,7 @@ def run(tag, n_img, N, S, steps, use_phase=False, skip=False):
         if i == 10: torch.cuda.synchronize(); m0 = torch.cuda.memory_allocated()
     torch.cuda.synchronize()
     ok = all(torch.isfinite(t.grad).all().item() for t in leaves) and torch.isfinite(img).all().item()
-    print(tag, 'steps', steps, 'finite', ok, 'mem delta MB', (torch.cuda.memory_allocated() - m0) / 1e6, 'peak GB', torch.cuda.max_memory_allocated() / 1e9, flush=True)
+    print(tag, 'steps', steps, 'finite', ok, 'mem delta MB', (torch.cuda.memory_allocated() - m0) / 1e6, 'peak GB', torch.cuda.max_memory_allocated() / 1e9, 'seconds %.1f' % _lap(), flush=True)
 run('config3', 8, 32768, 512, 300)
 run('config3 skip', 8, 32768, 512, 300, skip=True)
 run('config2', 16, 8192, 256, 300)
@@ -44,7 +50,7 @@ def run_asm(tag, n_img, N, S, steps):
         if i == 10: torch.cuda.synchronize(); m0 = torch.cuda.memory_allocated()
     torch.cuda.synchronize()
     ok = all(torch.isfinite(t.grad).all().item() for t in leaves + [ph, wl]) and torch.isfinite(img).all().item()
-    print(tag, 'steps', steps, 'finite', ok, 'mem delta MB', (torch.cuda.memory_allocated() - m0) / 1e6, 'peak GB', torch.cuda.max_memory_allocated() / 1e9, flush=True)
+    print(tag, 'steps', steps, 'finite', ok, 'mem delta MB', (torch.cuda.memory_allocated() - m0) / 1e6, 'peak GB', torch.cuda.max_memory_allocated() / 1e9, 'seconds %.1f' % _lap(), flush=True)
 
 
 run_asm('config5 b1', 1, 32768, 512, 200)
