@@ -130,3 +130,21 @@ def test_bench_line_on_the_gpu(workload):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
     assert set(rf["stage_avg_ms"]) >= {"project", "project_bwd"} and rf["stage_avg_ms_cold"]
     assert rf["kernel"].startswith({"config3": "k_composite_bwd", "config4": "k_phase_bwd", "config5": ""}[workload])
+
+
+@pytest.mark.gpu
+def test_per_image_loop_line_on_the_gpu():
+    """`--per-image-loop`: the reference's literal call pattern (B sequential (N,.) module calls + torch.stack, TGD:1209-1226) gives
+    the same unit count as the batched call on the same synthetic batch, and the line says which pattern it timed and what the host
+    side of a step costs (round 5)."""
+    out = {}
+    for flag in ([], ["--per-image-loop"]):
+        r = subprocess.run([sys.executable, BENCH, "--workload", "config1", "--steps", "3", "--warmup", "2", "--spinup-ms", "0"] + flag,
+                           capture_output=True, text=True, env=_clean_env(), timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+        assert d["host_enqueue_us_per_step"] > 0 and d["allreduce_us"] is None and d["cpu_baseline"] is None
+        out[bool(flag)] = d
+    assert out[False]["call_pattern"].startswith("batched") and out[True]["call_pattern"].startswith("per-image loop: 32 sequential")
+    assert out[False]["config"]["pairs_per_step"] == out[True]["config"]["pairs_per_step"] > 0
+    assert out[True]["ms_per_step"] > out[False]["ms_per_step"]  # 32 calls against one

@@ -398,3 +398,42 @@ def test_plane_recurrence_identities_of_the_asm_column_kernels():
         for p in range(lo, hi):
             assert np.abs(w - g * np.conj(H[p])).max() <= 1e-9
             w = w * np.conj(D)
+
+
+def test_renderers_tolerate_inference_mode_tensors():
+    """tensors created under torch.inference_mode() have no version counter (`_version` raises).  The wave renderers'
+    host copy of the background buffer and the camera's packed-record cache are keyed by version: constructing / moving the modules
+    or packing a camera inside inference mode must work (the cache then counts as stale: one read-back, never an exception)."""
+    from fresnel_amd.renderer import ASMWaveFieldRenderer, Camera, WaveFieldRenderer, _tensor_version
+    with torch.inference_mode():
+        r = ASMWaveFieldRenderer(32, 32, background=(0.1, 0.2, 0.3)).to("cpu")
+        w = WaveFieldRenderer(16, 16, background=(0.0, 0.5, 1.0))
+        assert _tensor_version(r.background) is None
+        assert r._background_host() == pytest.approx([0.1, 0.2, 0.3]) and w._background_host() == pytest.approx([0.0, 0.5, 1.0])
+        cam = Camera(10.0, 10.0, 8.0, 8.0, 16, 16)
+        cam.set_view(torch.eye(4))
+        assert cam.packed_tensor("cpu").shape == (1, 24)
+    assert r._background_host() == pytest.approx([0.1, 0.2, 0.3])  # ... and outside it afterwards
+    n = WaveFieldRenderer(16, 16, background=(0.2, 0.2, 0.2))       # a normal module still notices an in-place edit
+    n.background.mul_(2.0)
+    assert n._background_host() == pytest.approx([0.4, 0.4, 0.4])
+
+
+def test_call_shape_cache_and_input_normalisation():
+    """Round 5 (the per-image drop-in route makes B small calls per step): FgsDims and both workspace sizes are built once per
+    distinct call shape / configuration; inputs that already are contiguous fp32 pass through without a copy."""
+    from fresnel_amd import renderer as R
+    cfg = R._Cfg(64, 48, (0.1, 0.2, 0.3), 64, False, 0.25)
+    a = R._dims_for(2, 100, cfg, False, 1)
+    assert R._dims_for(2, 100, cfg, False, 1) is a and R._dims_for(3, 100, cfg, False, 1) is not a
+    assert a[0].batch == 2 and a[0].num_gaussians == 100 and a[1] > 0 and a[2] > 0
+    from fresnel_amd import _binding as B
+    assert (a[1], a[2]) == B.workspace_bytes(a[0])
+    cfg2 = R._Cfg(64, 48, (0.1, 0.2, 0.3), 64, False, 0.25, tuning=dict(tile_w=16))
+    assert R._dims_for(2, 100, cfg2, False, 1) is not a and R._dims_for(2, 100, cfg2, False, 1)[0].tile_w == 16
+    t = torch.zeros(4, 3)
+    assert R._f32c(t) is t
+    g = torch.zeros(4, 3, requires_grad=True)
+    assert R._f32c(g).data_ptr() == g.data_ptr() and not R._f32c(g).requires_grad
+    h = torch.zeros(3, 4, dtype=torch.float64).t()
+    assert R._f32c(h).dtype == torch.float32 and R._f32c(h).is_contiguous()
