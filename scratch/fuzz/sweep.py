@@ -29,11 +29,12 @@ from helpers import rel_to_max, referee_tolerance  # noqa: E402
 
 GRADS = ["positions", "scales", "rotations", "colors", "opacities"]
 FAMILIES = {  # family -> (seeds, case generator)
-    "phase": (range(6), lambda s: FC.phase_cases(s)),
-    "blend": (range(4), lambda s: FC.blend_cases(s)),
-    "batch": (range(2), lambda s: FC.batch_cases(s, 2)),
-    "batch_wide": (range(2), lambda s: FC.batch_cases(s, 1)),
-    "asm": (range(6), lambda s: FC.asm_cases(s)),
+    "phase": (range(10), lambda s: FC.phase_cases(s)),
+    "blend": (range(8), lambda s: FC.blend_cases(s)),
+    "blend_big": (range(4), lambda s: FC.blend_big_cases(s)),
+    "batch": (range(3), lambda s: FC.batch_cases(s, 2)),
+    "batch_wide": (range(3), lambda s: FC.batch_cases(s, 1)),
+    "asm": (range(8), lambda s: FC.asm_cases(s)),
     "asm_batched": ([4, 5], lambda s: FC.asm_batched_cases(s)),
 }
 
@@ -47,7 +48,7 @@ def _oracle_case(family, c, f64):
     from oracle import asm_oracle, fgs_oracle as orc
     prec = orc.fp64() if f64 else contextlib.nullcontext()
     out = {}
-    if family in ("phase", "blend"):
+    if family in ("phase", "blend", "blend_big"):
         W, H = c["W"], c["H"]
         if family == "phase":
             cam = orc.make_camera(np.eye(4), 0.8 * W, 0.8 * W, W / 2, H / 2, W, H)
@@ -58,7 +59,8 @@ def _oracle_case(family, c, f64):
         with prec:
             r = orc.render(*c["arrs"], cam, **kw)
             g = orc.render_backward(r, c["gI"], c["gD"])
-        out["image"], out["depth"] = r.image, r.depth
+        rs_ = c.get("row_stride", 1)  # (big frames: every row_stride-th row of the image and depth is kept)
+        out["image"], out["depth"] = r.image[:, ::rs_], r.depth[::rs_]
         for k in GRADS + (["phases"] if family == "phase" else []):
             out[k] = g[k]
     elif family in ("batch", "batch_wide"):
@@ -153,7 +155,7 @@ def _hip_case(family, c):
     ts = [up(a).requires_grad_(True) for a in c["arrs"]]
     out = {}
     names = list(GRADS)
-    if family in ("phase", "blend", "batch", "batch_wide"):
+    if family in ("phase", "blend", "blend_big", "batch", "batch_wide"):
         ph = None
         if family == "phase":
             W, H = c["W"], c["H"]
@@ -161,18 +163,19 @@ def _hip_case(family, c):
             ren = TileBasedRenderer(W, H, background=c["bg"], use_phase_blending=True, phase_amplitude=c["amp"])
             ph = up(c["phases"]).requires_grad_(True)
             img, dep = ren(*ts, cam, return_depth=True, phases=ph)
-        elif family == "blend":
+        elif family in ("blend", "blend_big"):
             W, H = c["W"], c["H"]
             cam = Camera(c["fx"], c["fx"], c["cx"], c["cy"], W, H)
             ren = TileBasedRenderer(W, H, background=c["bg"], max_radius=c["maxr"])
-            ren.tuning = dict(tile_w=c["tile_w"])
+            ren.tuning = c["tuning"] if family == "blend_big" else dict(tile_w=c["tile_w"])
             img, dep = ren(*ts, cam, return_depth=True)
         else:
             S = c["S"]
             cams = [create_camera_from_pose(p[0], p[1], S, distance=p[2]) for p in c["poses"]]
             img, dep = TileBasedRenderer(S, S, background=c["bg"])(*ts, cams, return_depth=True)
         ((img * up(c["gI"])).sum() + (dep * up(c["gD"])).sum()).backward()
-        out["image"], out["depth"] = img.detach().cpu().numpy(), dep.detach().cpu().numpy()
+        rs_ = c.get("row_stride", 1)
+        out["image"], out["depth"] = img.detach().cpu().numpy()[..., ::rs_, :], dep.detach().cpu().numpy()[..., ::rs_, :]
         if ph is not None:
             out["phases"] = ph.grad.cpu().numpy()
     elif family == "asm":
@@ -208,7 +211,7 @@ def _hip_case(family, c):
 
 
 def _describe(family, c):
-    keys = [k for k in ("W", "H", "S", "B", "N", "P", "maxr", "smax", "amp", "tile_w", "kind", "rgbph") if k in c]
+    keys = [k for k in ("W", "H", "S", "B", "N", "P", "maxr", "smax", "amp", "tile_w", "tuning", "kind", "rgbph") if k in c]
     return " ".join(f"{k}{c[k]}" if not isinstance(c[k], str) else c[k] for k in keys)
 
 

@@ -116,3 +116,24 @@ def asm_batched_cases(seed, n_iter=24):
         kw = dict(num_depth_planes=P, depth_range=(near, far), focal_depth=float(rs.uniform(0.5, 1.5)),
                   pixel_pitch=1.0 / float(rs.choice([128, 200, 256])))
         yield dict(it=it, W=W, H=H, P=P, B=Bn, N=N, arrs=arrs, phases=phases, wl=wl, bg=bg, gI=gI, f=f, kw=kw)
+
+
+def blend_big_cases(seed, n_iter=6):
+    """Blend path at sizes where a tile's list spans several depth segments and list parts (round 5): frames of 200 ... 520 pixels,
+    4 000 ... 30 000 Gaussians, automatic / 16- / 32-wide tiles, automatic / 64- / 128-entry segments, a random orbit camera."""
+    rs = np.random.RandomState(7000 + seed)
+    for it in range(n_iter):
+        W, H = int(rs.randint(200, 521)), int(rs.randint(200, 521))
+        N = int(rs.choice([4000, 12000, 30000]))
+        smax = float(rs.choice([0.03, 0.08]))
+        arrs = list(synth_aniso(N, int(rs.randint(1 << 30)), opacity_max=float(rs.choice([0.6, 1.0, 1.3])), smax=smax))
+        bg = tuple(float(x) for x in rs.rand(3))
+        fx = float(rs.uniform(0.6, 1.2) * W)
+        gI = rs.standard_normal((3, H, W)).astype(np.float32)
+        gD = (rs.standard_normal((H, W)) * 0.1).astype(np.float32)
+        tuning = {}
+        tw, sl = int(rs.choice([0, 16, 32])), int(rs.choice([0, 64, 128]))
+        if tw: tuning["tile_w"] = tw
+        if sl: tuning["seg_len"] = sl
+        yield dict(it=it, W=W, H=H, N=N, maxr=64.0, smax=smax, arrs=arrs, bg=bg, fx=fx, cx=W / 2.0, cy=H / 2.0, gI=gI, gD=gD,
+                   tuning=tuning, tile_w=tw, row_stride=4)
