@@ -125,7 +125,11 @@ int fgs_forward(const FgsDims *dims, const float *cameras, const float *pos, con
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char *sv = reinterpret_cast<char *>(saved), *sc = reinterpret_cast<char *>(scratch);
     fgs_stage_begin(ST_PROJECT, st);
-    if ((rc = fgs_launch_project(p, cameras, pos, scale, quat, color, opacity, sv, st))) return rc;
+    // (sort_mode bits 1-2 = 3: the depth sort's blocks hand their histograms to each other through scratch words that must be clear)
+    const bool handoff = (p.d.sort_mode >> 1) == 3;
+    if ((rc = fgs_launch_project(p, cameras, pos, scale, quat, color, opacity, sv, st, 0, 0.0f, 0.0f,
+                                 handoff ? reinterpret_cast<uint32_t *>(sc + p.s_hist) : nullptr,
+                                 (uint32_t)(FGS_SORT_HANDOFF_PASSES * (size_t)p.d.batch * 16 * 256)))) return rc;
     fgs_stage_end(ST_PROJECT, st);
     if ((rc = fgs_launch_binning(p, sv, sc, st))) return rc;
     fgs_stage_begin(ST_COMPOSITE_FWD, st);

@@ -27,7 +27,8 @@ void fgs_stage_end(int stage, hipStream_t st);
 // (DR:1136-1148) of each Gaussian
 int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                        const float *quat, const float *color, const float *opacity, char *saved,
-                       hipStream_t st, int num_planes = 0, float plane_near = 0.0f, float plane_far = 0.0f);
+                       hipStream_t st, int num_planes = 0, float plane_near = 0.0f, float plane_far = 0.0f,
+                       uint32_t *zero_words = nullptr /* cleared on the side: the depth sort's hand-off words */, uint32_t zero_count = 0);
 int fgs_launch_project_bwd(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                            const float *quat, const char *saved, const float *grad_rows, float *g_pos,
                            float *g_scale, float *g_quat, float *g_color, float *g_opacity, float *g_phase,
@@ -54,7 +55,9 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
                                                                  sort by the bits that vary, skip the passes nobody needs */,
                           uint32_t key_recs = 0 /* records per segment */,
                           int pass_mode = 0 /* 0 = automatic (fused single-launch passes for segments of <= 4096 keys) | 1 = fused
-                                               passes, 11-bit digits, up to 64 K keys | 2 = fused passes, 8-bit digits (fgs_sort.hip) */);
+                                               passes, 11-bit digits, up to 64 K keys | 2 = fused passes, 8-bit digits | 3 = fused
+                                               passes, 8-bit digits, per-block histograms HANDED OFF between the blocks through `hist`
+                                               (which the caller cleared beforehand: fgs_sort.hip) */);
 
 int fgs_launch_binning(const FgsPlan &p, char *saved, char *scratch, hipStream_t st);
 

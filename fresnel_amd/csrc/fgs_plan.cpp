@@ -15,7 +15,11 @@ uint32_t fgs_radix_blocks_per_seg(uint32_t seg_capacity, uint32_t num_segs) {
 
 size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs) {
     const size_t bps = fgs_radix_blocks_per_seg(seg_capacity, num_segs);
-    return ((size_t)num_segs * 256 * bps + (size_t)num_segs * 256) * sizeof(uint32_t);
+    size_t words = (size_t)num_segs * 256 * bps + (size_t)num_segs * 256;
+    // the hand-off form of the fused pass (FgsDims.sort_mode bits 1-2 = 3): four pass regions of [segments][<= 16 blocks][256] words
+    const size_t handoff = (size_t)FGS_SORT_HANDOFF_PASSES * num_segs * 16 * 256;
+    if (handoff > words) words = handoff;
+    return words * sizeof(uint32_t);
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -31,7 +35,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     }
     const int fv = d->fwd_variant, afv = fv < -16 || fv > 16 ? 3 /* invalid; INT_MIN has no negation */ : (fv < 0 ? -fv : fv);
     if (d->seg_len < 0 || d->seg_len > 512 || d->seg_len % 64 != 0 || (afv != 0 && afv != 1 && afv != 2 && afv != 4 && !(fv == 8 || fv == 16)) ||
-        d->bin_mode < 0 || d->bin_mode > 2 || (d->tile_w != 0 && d->tile_w != 16 && d->tile_w != 32) || d->sort_mode < 0 || d->sort_mode > 5) {
+        d->bin_mode < 0 || d->bin_mode > 2 || (d->tile_w != 0 && d->tile_w != 16 && d->tile_w != 32) || d->sort_mode < 0 || d->sort_mode > 7) {
         fgs_set_error("invalid tuning: seg_len=%d fwd_variant=%d bin_mode=%d tile_w=%d sort_mode=%d", d->seg_len, d->fwd_variant,
                       d->bin_mode, d->tile_w, d->sort_mode);
         return FGS_EINVAL;

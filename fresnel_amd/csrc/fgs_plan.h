@@ -65,5 +65,6 @@ void fgs_set_error(const char *fmt, ...);
 #define FGS_MASK_MAX_LINES 512  /* mask binning: tile columns + tile rows per image (LDS of k_mask_build: 16 KB) */
 /* 64-bit rank words per mask line of the mask binning (fgs_bin.hip), padded to a multiple of 8 */
 static inline uint32_t fgs_mask_words(uint32_t n) { return (((n + 63u) / 64u) + 7u) & ~7u; }
+#define FGS_SORT_HANDOFF_PASSES 4
 size_t fgs_radix_hist_bytes(uint32_t seg_capacity, uint32_t num_segs);
 uint32_t fgs_radix_blocks_per_seg(uint32_t seg_capacity, uint32_t num_segs);

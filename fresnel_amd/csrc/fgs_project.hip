@@ -91,7 +91,11 @@ __global__ __launch_bounds__(256) void k_project(
     const float *__restrict__ quat, const float *__restrict__ color, const float *__restrict__ opacity,
     float *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ tile_count,
     uint32_t *__restrict__ layer, int32_t num_planes, float plane_near, float plane_far, int32_t tile_w,
-    uint32_t *__restrict__ key_bits) {
+    uint32_t *__restrict__ key_bits, uint32_t *__restrict__ zero_words, uint32_t zero_count) {
+    // the depth sort's hand-off words (fgs_sort.hip, sort_mode bits 1-2 = 3) must read "not published" when its passes start: this
+    // launch precedes them on the stream, so it clears them on the side (<= 1 store per thread)
+    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x; i < zero_count; i += gridDim.x * gridDim.y * 256u)
+        zero_words[i] = 0u;
     // grid (blocks per image, B): a block never straddles two images, so that its share of the image's key statistics
     // (below) is one record
     const int32_t n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
@@ -557,7 +561,8 @@ __global__ __launch_bounds__(256) void k_project_bwd(
 
 int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, const float *scale,
                        const float *quat, const float *color, const float *opacity, char *saved,
-                       hipStream_t st, int num_planes, float plane_near, float plane_far) {
+                       hipStream_t st, int num_planes, float plane_near, float plane_far, uint32_t *zero_words,
+                       uint32_t zero_count) {
     const dim3 grid((unsigned)((p.d.num_gaussians + 255) / 256), (unsigned)p.d.batch);
     hipLaunchKernelGGL(k_project, grid, dim3(256), 0, st, p.d.num_gaussians, p.d.width,
                        p.d.height, p.d.num_cameras, p.d.max_radius, cams, pos, scale, quat, color, opacity,
@@ -565,7 +570,8 @@ int fgs_launch_project(const FgsPlan &p, const float *cams, const float *pos, co
                        reinterpret_cast<uint32_t *>(saved + p.L.depth_key),
                        reinterpret_cast<uint32_t *>(saved + p.L.tile_count),
                        num_planes > 1 ? reinterpret_cast<uint32_t *>(saved + p.s_layer) : nullptr, num_planes,  // one plane: layer 0
-                       plane_near, plane_far, p.tile_w, reinterpret_cast<uint32_t *>(saved + p.s_keybits));
+                       plane_near, plane_far, p.tile_w, reinterpret_cast<uint32_t *>(saved + p.s_keybits), zero_words,
+                       zero_words ? zero_count : 0u);
     FGS_LAUNCH_CHECK("k_project");
     return FGS_OK;
 }

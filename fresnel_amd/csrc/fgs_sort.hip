@@ -393,11 +393,22 @@ __device__ __forceinline__ uint32_t key_digit_w(const KeyPlanW<BITS> &kp, uint32
     return key == 0xFFFFFFFFu ? kp.cull : (d & kp.vmask);
 }
 
-template <int BITS, bool COMPRESSED>
+// HANDOFF (sort_mode bits 1-2 = 3; VERDICT r4 item 4c, "the look-back pass actually built and timed"): instead of counting the whole
+// segment, a block counts its OWN keys, publishes the NB counts (count + 1 per word, write-through agent-scope stores into this pass's
+// region of `handoff`, which k_project cleared) and collects the other blocks' words by polling them with agent-scope loads.  A word
+// carries its own "published" mark (non-zero), so no flag and no fence are needed (a single dword store is atomic).  The wait is
+// BOUNDED: a block that has not seen a word after FGS_HANDOFF_SPINS polls -- its producer is not resident (a grid larger than the
+// chip, another stream's kernels holding the CUs) -- stops waiting and counts the whole segment itself, the plain fused path: every
+// block terminates whatever the others do.
+#ifndef FGS_HANDOFF_SPINS
+#define FGS_HANDOFF_SPINS 20000u
+#endif
+template <int BITS, bool COMPRESSED, bool HANDOFF = false>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_fused(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, uint32_t seg_len, uint32_t seg_stride, uint32_t shift, uint32_t dmask, uint32_t idx_mod,
-    const uint32_t *__restrict__ key_bits, uint32_t key_recs, uint32_t pass, uint32_t *__restrict__ vals_final) {
+    const uint32_t *__restrict__ key_bits, uint32_t key_recs, uint32_t pass, uint32_t *__restrict__ vals_final,
+    uint32_t *__restrict__ handoff = nullptr /* this pass's region: [segment][block][NB] words */) {
     constexpr uint32_t NB = 1u << BITS, DPT = NB / RS_THREADS;  // bins; bins per thread
     __shared__ uint32_t pre[NB];               // digits of the segment's keys in front of this block's range
     __shared__ uint32_t rest[NB];              // ... from this block's range on; then the running output offset per digit
@@ -436,9 +447,73 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_fused(
         for (int w = 0; w < RS_WAVES; ++w) wcnt[w][tid + k * RS_THREADS] = 0u;
     }
     __syncthreads();
+    bool counted = false;
+    if constexpr (HANDOFF) {
+        __shared__ volatile uint32_t gave_up;
+        if (tid == 0) gave_up = 0u;
+        // (1) this block's own digit counts -> `rest`
+        for (uint32_t i0 = r.begin + tid; i0 - tid < r.end; i0 += ROUND) {
+            uint32_t k4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k4[u] = i0 + u * RS_THREADS < r.end ? keys_in[i0 + u * RS_THREADS] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool v = i0 + u * RS_THREADS < r.end;
+                const uint32_t d = digit_of(k4[u]);
+                const unsigned long long act = __ballot(v);
+                if (act == 0ull) continue;
+                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                if (__ballot(v && d == d0) == act) {
+                    if (lane == 0) atomicAdd(&rest[d0], (uint32_t)__popcll(act));
+                } else if (v) {
+                    atomicAdd(&rest[d], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // (2) publish them, (3) collect the other blocks': every thread owns DPT digits
+        uint32_t *mine = handoff + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NB;
+        uint32_t own[DPT], before[DPT], total[DPT];
+#pragma unroll
+        for (uint32_t k = 0; k < DPT; ++k) {
+            own[k] = rest[tid + k * RS_THREADS];
+            __hip_atomic_store(&mine[tid + k * RS_THREADS], own[k] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            before[k] = 0u; total[k] = own[k];
+        }
+        bool ok = true;
+        for (uint32_t b = 0; b < gridDim.x && ok; ++b) {
+            if (b == blockIdx.x) continue;
+            const uint32_t *theirs = handoff + ((size_t)blockIdx.y * gridDim.x + b) * NB;
+#pragma unroll
+            for (uint32_t k = 0; k < DPT; ++k) {
+                uint32_t w = 0u, spins = 0u;
+                while ((w = __hip_atomic_load(&theirs[tid + k * RS_THREADS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                    if (++spins > FGS_HANDOFF_SPINS || gave_up) { ok = false; break; }  // bounded: see the header
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (!ok) break;
+                total[k] += w - 1u;
+                if (b < blockIdx.x) before[k] += w - 1u;
+            }
+        }
+        if (!ok) gave_up = 1u;
+        __syncthreads();
+        if (!gave_up) {
+#pragma unroll
+            for (uint32_t k = 0; k < DPT; ++k) {
+                pre[tid + k * RS_THREADS] = before[k];
+                rest[tid + k * RS_THREADS] = total[k] - before[k];
+            }
+            counted = true;
+        } else {  // some producer is not running: count the whole segment here (below)
+#pragma unroll
+            for (uint32_t k = 0; k < DPT; ++k) { pre[tid + k * RS_THREADS] = 0u; rest[tid + k * RS_THREADS] = 0u; }
+        }
+        __syncthreads();
+    }
     // ---- the segment's digit histogram, split at this block's first key (r.begin is a multiple of 1024: a wave instruction's
     // 64 consecutive keys lie on one side) ----
-    for (uint32_t i0 = seg0 + tid; i0 - tid < seg_end; i0 += ROUND) {
+    for (uint32_t i0 = seg0 + tid; !counted && i0 - tid < seg_end; i0 += ROUND) {
         uint32_t k4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) k4[u] = i0 + u * RS_THREADS < seg_end ? keys_in[i0 + u * RS_THREADS] : 0u;
@@ -559,13 +634,17 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
     // boundary it saves (~2.8 us); a pass is two memory round trips whichever way it is launched.
     const bool fused = !seg_len_dev && seg_len == seg_capacity && key_bits >= 1u &&
                        (pass_mode == 0 ? seg_len <= 4096u : seg_len <= 65536u);
+    // (pass_mode 3, the hand-off form: a compressed segment that leaves a pass early publishes nothing for it, and nobody of that
+    //  segment waits either -- all its blocks leave together; region p belongs to pass p alone, so no word is ever reused in a call)
     if (fused) {
         const bool compressed = key_stats != nullptr;
         if (compressed && !(keys_first && index_payload_mod && vals_final && key_recs && key_bits == 32u)) {
             fgs_set_error("radix sort: key compression needs 32-bit keys in keys_first, an index payload and vals_final");
             return FGS_EINVAL;
         }
-        const uint32_t bits = (pass_mode == 2 || key_bits <= 8u) ? 8u : 11u;  // (plane ids, <= 5 bits: the small histogram)
+        const uint32_t bits = (pass_mode >= 2 || key_bits <= 8u) ? 8u : 11u;  // (plane ids, <= 5 bits: the small histogram)
+        // hand-off form: the depth sort of a forward whose projection cleared `hist` (fgs_api.hip); needs its four pass regions
+        const bool handoff = pass_mode == 3 && hist != nullptr && key_bits == 32u && keys_first != nullptr;
         const uint32_t passes = (key_bits + bits - 1u) / bits, width = (key_bits + passes - 1u) / passes;
         const dim3 grid(fused_blocks_per_seg(seg_len, num_segs), num_segs);
         const uint32_t *kin = keys_first ? keys_first : keys_in;
@@ -578,7 +657,15 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
 #define FGS_FUSED_LAUNCH(B_, C_)                                                                                             \
     hipLaunchKernelGGL((k_radix_fused<B_, C_>), grid, dim3(RS_THREADS), 0, st, kin, vsrc, kout, vdst, seg_len, seg_stride, shift, \
                        dmask, imod, key_stats, key_recs, p, vals_final)
-            if (bits == 8u) { if (compressed) FGS_FUSED_LAUNCH(8, true); else FGS_FUSED_LAUNCH(8, false); }
+            if (handoff) {
+                uint32_t *region = hist + (size_t)p * num_segs * 16u * 256u;
+                if (compressed)
+                    hipLaunchKernelGGL((k_radix_fused<8, true, true>), grid, dim3(RS_THREADS), 0, st, kin, vsrc, kout, vdst, seg_len, seg_stride,
+                                       shift, dmask, imod, key_stats, key_recs, p, vals_final, region);
+                else
+                    hipLaunchKernelGGL((k_radix_fused<8, false, true>), grid, dim3(RS_THREADS), 0, st, kin, vsrc, kout, vdst, seg_len, seg_stride,
+                                       shift, dmask, imod, key_stats, key_recs, p, vals_final, region);
+            } else if (bits == 8u) { if (compressed) FGS_FUSED_LAUNCH(8, true); else FGS_FUSED_LAUNCH(8, false); }
             else            { if (compressed) FGS_FUSED_LAUNCH(11, true); else FGS_FUSED_LAUNCH(11, false); }
 #undef FGS_FUSED_LAUNCH
             FGS_LAUNCH_CHECK("k_radix_fused");

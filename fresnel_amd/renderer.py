@@ -214,6 +214,10 @@ _SCRATCH: dict = {}
 
 
 def _scratch_for(dev, nbytes):
+    # under stream capture (torch.cuda.graph) the buffer must come from the graph's own memory pool and belong to that graph alone:
+    # a cached buffer would be baked into the graph AND handed to later eager calls on a stream with the same handle
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
     key = (dev.index, _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device()) if _raw_stream is not None
            else torch.cuda.current_stream(dev).cuda_stream)
     buf = _SCRATCH.get(key)

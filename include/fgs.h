@@ -76,7 +76,8 @@ typedef struct FgsDims {
                                Bits 1-2 (work split, never the result): 0 = automatic -- ONE launch per pass with 11-bit digits
                                (three passes; round 5) for images of <= 4096 Gaussians, the two-launch 8-bit passes of
                                rounds 1-4 above | 2 = one launch per pass, 11-bit digits, for any image of <= 65 536 Gaussians
-                               | 4 = the same with 8-bit digits.  Valid values: 0 ... 5.                                   */
+                               | 4 = the same with 8-bit digits | 6 = 8-bit digits, the blocks' digit
+                               counts handed off between them instead of recounted (bounded wait).  Valid values: 0 ... 7.                                   */
 } FgsDims;
 
 /* Camera record on the DEVICE: FGS_CAMERA_FLOATS floats per camera (Camera, DR:27-52):
