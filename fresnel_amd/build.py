@@ -25,7 +25,9 @@ NO_SLP = ["-fno-slp-vectorize"]
 # Machine-scheduler strategy of the compositing unit: "max-memory-clause" orders the list loops so that the LDS record reads
 # sit together ahead of the arithmetic; same-box A/B over 4 x 100 steps at config 3 (round 3): step 1.856-1.864 -> 1.832-1.838 ms
 # (-1.35 %; forward -2 %, backward -1 %), "max-ilp" -0.7 %, wave-priority / metric-bias: nothing.
-SCHED = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
+# (FGS_BUILD_SCHED=<strategy|none>: experiment builds with another strategy; counts as an experiment define)
+_SCHED_ENV = os.environ.get("FGS_BUILD_SCHED", "")
+SCHED = ([] if _SCHED_ENV == "none" else ["-mllvm", "-amdgpu-sched-strategy=" + (_SCHED_ENV or "max-memory-clause")])
 # per-file extra flags.  fgs_project.hip carries the "canonical fp32" contract: no FMA
 # contraction, IEEE divide/sqrt, so integer decisions match the CPU oracle bit for bit.
 SOURCES = {
@@ -87,10 +89,10 @@ def build(force=False, verbose=False, defines=(), suffix=""):
         # experiment builds: every unit sees FGS_EXPERIMENT_BUILD (timing-only switches #error without it), and fgs_version() lists
         # the defines (fgs_api.hip), so a library selected through FGS_LIB says what it is
         exp = []
-        if defines or more:
+        if defines or more or _SCHED_ENV:
             exp = ["-DFGS_EXPERIMENT_BUILD=1"]
             if name == "fgs_api.hip":
-                exp.append('-DFGS_BUILD_DEFINES="' + " ".join(list(defines) + more).replace('"', "'") + '"')
+                exp.append('-DFGS_BUILD_DEFINES="' + " ".join(list(defines) + more + (["sched=" + _SCHED_ENV] if _SCHED_ENV else [])).replace('"', "'") + '"')
         cmd = [hipcc] + common + extra + more + ["-D" + d for d in defines] + exp + ["-c", src, "-o", obj]
         # an object is stale when its source or a header is newer OR when it was compiled with another command line (the
         # flags live in this file: editing them must rebuild)
