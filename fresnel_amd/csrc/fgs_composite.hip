@@ -33,26 +33,26 @@ constexpr float ALPHA_MAX = 0.99f;                          // DR:647
 constexpr float INV_ALPHA_MAX = 1.0f / 0.99f;
 constexpr float PHASE_KAPPA = 2.0f * 3.14159f;              // DR:642 uses the literal 3.14159
 
-// cos / sin of x = kappa * pd, pd in [0, 0.5], i.e. x in [0, pi]: Taylor polynomials around pi/2 (|y| <= pi/2,
-// truncation < 6e-8), all plain FMAs.  The hardware v_cos_f32 / v_sin_f32 (__cosf / __sinf) are only good to
-// ~1e-5 absolute, which showed up as 1e-5 image error and > 1e-4 gradient error at phase_amplitude 0.6.
+// cos / sin of x = kappa * pd, pd in [0, 0.5], i.e. x in [0, pi]: polynomials in y = x - pi/2 (|y| <= pi/2), all plain FMAs.  The
+// hardware v_cos_f32 / v_sin_f32 (__cosf / __sinf) are only good to ~1e-5 absolute, which showed up as 1e-5 image error and > 1e-4
+// gradient error at phase_amplitude 0.6.  Round 5: MINIMAX coefficients (fit on [0, (pi/2)^2] in y^2 with the constant term held at
+// 1; approximation error 4.8e-9 / 2.4e-10, fp32 evaluation error 1.3e-7 / 1.2e-7 over the interval -- that of the Taylor
+// polynomials of degree 11 / 12 they replace) of degree 9 / 10: one FMA less per evaluation, three per list entry of the backward.
 __device__ __forceinline__ float phase_cos(float x) {
-    const float y = x - 1.57079632679489661923f, y2 = y * y;  // cos(x) = -sin(y)
-    float p = -2.50521083854417187751e-8f;                    // -1/11!
-    p = p * y2 + 2.75573192239858906526e-6f;                  //  1/9!
-    p = p * y2 - 1.98412698412698412698e-4f;                  // -1/7!
-    p = p * y2 + 8.33333333333333333333e-3f;                  //  1/5!
-    p = p * y2 - 1.66666666666666666667e-1f;                  // -1/3!
+    const float y = x - 1.57079632679489661923f, y2 = y * y;  // cos(x) = -sin(y),  sin(y) = y (1 + y^2 p(y^2))
+    float p = 2.6089300414764439e-6f;
+    p = p * y2 - 1.9811111665926607e-4f;
+    p = p * y2 + 8.3330881539788702e-3f;
+    p = p * y2 - 1.6666660461917662e-1f;
     return -(y + y * (y2 * p));
 }
 __device__ __forceinline__ float phase_sin(float x) {
-    const float y = x - 1.57079632679489661923f, y2 = y * y;  // sin(x) = cos(y)
-    float p = 2.08767569878680989792e-9f;                     //  1/12!
-    p = p * y2 - 2.75573192239858906526e-7f;                  // -1/10!
-    p = p * y2 + 2.48015873015873015873e-5f;                  //  1/8!
-    p = p * y2 - 1.38888888888888888889e-3f;                  // -1/6!
-    p = p * y2 + 4.16666666666666666667e-2f;                  //  1/4!
-    p = p * y2 - 0.5f;
+    const float y = x - 1.57079632679489661923f, y2 = y * y;  // sin(x) = cos(y) = 1 + y^2 p(y^2)
+    float p = -2.6077082524225105e-7f;
+    p = p * y2 + 2.4761885011562826e-5f;
+    p = p * y2 - 1.3888403485377396e-3f;
+    p = p * y2 + 4.1666640726419513e-2f;
+    p = p * y2 - 4.9999999549521157e-1f;
     return 1.0f + y2 * p;
 }
 constexpr int CH = 64;                                      // records per LDS chunk (one per lane)
@@ -726,7 +726,9 @@ __device__ __forceinline__ unsigned long long phase_scan(PhaseRec &st, uint32_t 
     const unsigned long long touched = __ballot(bits != 0u);
     if (bits) {
         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(touched >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touched, 0u));
-        if (FWD) { q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E; }
+        // conic in exp2 units, forward AND backward (round 5: the backward's re-run and reverse sweep then evaluate G with the forward's
+        // own operation order -- and one multiply less per evaluation)
+        q0.z *= NEG_HALF_LOG2E; q0.w *= NEG_HALF_LOG2E; q1.x *= NEG_HALF_LOG2E;
         st.a[slot] = q0; st.b[slot] = q1;
         st.c[slot] = make_float4(q2.x, q2.y, phase[gid], __uint_as_float(bits));
         if (!FWD) rows[slot] = e;
@@ -864,7 +866,7 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
         gd = g_depth[(size_t)c.b * HW + o];
         Abar = -(gr * bg0 + gg * bg1 + gb * bg2);  // d/dA of (1 - A) * bg
     }
-    const float base_amp = 1.0f - amp;
+    const float base_amp = 1.0f - amp, neg_amp_kappa = -(amp * PHASE_KAPPA);
     const uint32_t total = c.end - c.start;
     constexpr uint32_t SCAN = FGS_PHASE_SCAN;
     const uint32_t nblocks = (total + SCAN - 1u) / SCAN;
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
                         const uint32_t mk = (uint32_t)__builtin_amdgcn_sbfe((int)bits, lx, 1) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, 8u + ly, 1);
                         const float dx = fpx - q0.x, dy = fpy - q0.y;
                         const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
-                        float alpha = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E) * q1.y;
+                        float alpha = __builtin_amdgcn_exp2f(mm) * q1.y;
                         float pd = fabsf(q2.z - P8);
                         pd = fminf(pd, 1.0f - pd);
                         alpha *= base_amp + amp * phase_cos(pd * PHASE_KAPPA);
@@ -952,7 +954,7 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
                 const float dx = fpx - q0.x, dy = fpy - q0.y;
                 const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
 #if FGS_PHASE_PARK
-                const float Gk = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E)) & mk);
+                const float Gk = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm)) & mk);
                 float pd = fabsf(q2.z - Pf);
                 pd = fminf(pd, 1.0f - pd);
                 const float Ik = base_amp + amp * phase_cos(pd * PHASE_KAPPA);
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
 #endif
                 const float alpha = __builtin_amdgcn_fmed3f((Gk * q1.y) * Ik, 0.0f, ALPHA_MAX);
 #else
-                float alpha = __builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E) * q1.y;
+                float alpha = __builtin_amdgcn_exp2f(mm) * q1.y;  // (conic staged in exp2 units)
                 float pd = fabsf(q2.z - Pf);
                 pd = fminf(pd, 1.0f - pd);
                 alpha *= base_amp + amp * phase_cos(pd * PHASE_KAPPA);
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
                 const float G = sG[k];
 #else
                 const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
-                const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm * NEG_HALF_LOG2E)) & mk);
+                const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm)) & mk);
 #endif
 #if FGS_PHASE_PARK == 1 || FGS_PHASE_PARK == 3
                 const float inter = sI[k];
@@ -1020,27 +1022,29 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
                 // (below the 1e-6 clamp of A_i, pc = w / 1e-6: d pc/d w = 1 / 1e-6 = rA and no dependence on A_{i-1}; selected per lane
                 // -- a divergent branch cost a save / restore of the exec mask per entry)
                 const float rA2 = rA * rA;
-                const bool big = Ai >= 1e-6f;
-                const float dpc_dw = big ? Aprev * rA2 : rA, dpc_dA = big ? w * rA2 : 0.0f;
+                float dpc_dw, dpc_dA;
+                select2_ge(Ai, 1e-6f, Aprev * rA2, w * rA2, rA, dpc_dw, dpc_dA);  // (one compare, both selects adjacent: issue costs)
                 const float wbar = Abar + (gr * q1.z + gg * q1.w + gb * q2.x + gd * q2.y) + pcbar * dpc_dw;
                 const float v_r = w * gr, v_g = w * gg, v_b = w * gb, v_d = w * gd;
                 const float abar = wbar * T;
                 Abar = (Abar - pcbar * dpc_dA) - wbar * alpha;  // (outside the bbox: w = alpha = pcbar = 0, Abar unchanged)
-                const float rbar = (raw >= 0.0f && raw <= ALPHA_MAX) ? abar : 0.0f;  // clamp passes the gradient on the closed interval
+                // clamp passes the gradient on the closed interval [0, 0.99]: exactly where clamping changed nothing (alpha == raw;
+                // one compare instead of two)
+                const float rbar = select_eq(alpha, raw, abar);
                 const float v_op = rbar * Gint;
-                const float pdbar = -(rbar * Gop) * amp * PHASE_KAPPA * phase_sin(PHASE_KAPPA * pd);
-                const float pd0bar = (pd0 < 1.0f - pd0) ? pdbar : ((pd0 > 1.0f - pd0) ? -pdbar : 0.0f);
-                const float sg = (dphi > 0.0f) ? 1.0f : ((dphi < 0.0f) ? -1.0f : 0.0f);
-                const float t_ph = pd0bar * sg;
+                const float pdbar = (rbar * Gop) * neg_amp_kappa * phase_sin(PHASE_KAPPA * pd);
+                // d pd/d dphi = sign(1/2 - |dphi|) sign(dphi), 0 on either tie: the sign of x = (1/2 - |dphi|) dphi, formed by saturating
+                // x 2^100 to [-1, 1] (exactly +-1 for |x| >= 2^-100, exactly 0 for x = 0; four compares and four selects before round 5).
+                // (pd0 < 1 - pd0 is pd0 < 1/2 for every fp32 pd0 in [0, 1]: 1 - pd0 rounds to >= 1/2 below one half and is exact above.)
+                const float t_ph = pdbar * __builtin_amdgcn_fmed3f(((0.5f - pd0) * dphi) * 1.2676506e30f, -1.0f, 1.0f);
                 v_ph += t_ph;
                 Pbar -= Pb * pc + t_ph;  // = Pb (1 - pc) - pd0bar sg inside the bbox, unchanged outside (Pb = G = 0 there)
-                const float dm = -0.5f * (rbar * raw);
+                const float dm = rbar * raw;  // -2 dL/dm: the -1/2 rides on the per-Gaussian sums (k_project_bwd)
                 const float dmx = dm * dx, dmy = dm * dy;
-                // slots 0 / 1: the FIRST MOMENTS of dL/dm' (m' = K m, the blend path's convention: dm / K = -2 ln2 dm) -- dL/d(u, v) =
-                // -K conic_sym (moments) is formed once per Gaussian, in double, by k_project_bwd (two multiplies here instead of the
-                // conic products; the same chain as the blend backward's rows)
-                const float vals[11] = {dmx * -1.38629436111989061883f, dmy * -1.38629436111989061883f, dmx * dx, dmx * dy, dmy * dy,
-                                        v_op, v_r, v_g, v_b, v_d, v_ph};
+                // slots 0 / 1: the FIRST MOMENTS of dL/dm; k_project_bwd turns their per-Gaussian sums into those of dL/dm' (m' = K m, the
+                // blend path's convention: x 1 / K = -2 ln2, once per Gaussian since round 5) and forms dL/d(u, v) = -K conic_sym (moments)
+                // in double (the same chain as the blend backward's rows)
+                const float vals[11] = {dmx, dmy, dmx * dx, dmx * dy, dmy * dy, v_op, v_r, v_g, v_b, v_d, v_ph};  // (slots 0-4: moments of -2 dL/dm, rescaled in k_project_bwd)
                 const float tot = wave_sum11_addtid(red, vals, lane);
                 if ((lane & 3u) == 3u && lane < 44u && e < dcap)
                     grad_rows[((size_t)e * 4 + wave) * FGS_GROW_FLOATS + (lane >> 2)] = tot;

@@ -340,6 +340,10 @@ __global__ __launch_bounds__(256) void k_project_bwd(
                 acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
                 acc[8] += cq.x; acc[9] += cq.y; acc[10] += cq.z; acc[11] += cq.w;
             }
+            // k_phase_bwd leaves the moments of -2 dL/dm in slots 0-4 (round 5: the constants ride on the per-Gaussian sums, not on every
+            // list entry); the chain below takes the first moments of dL/dm' (m' = K m: x -1/2 x 1/K = ln 2) and dL/dconic (x -1/2)
+            acc[0] *= 0.69314718055994530942f; acc[1] *= 0.69314718055994530942f;
+            acc[2] *= -0.5f; acc[3] *= -0.5f; acc[4] *= -0.5f;
         } else {
             // rows sub, sub + 4, ...: two rows in flight per lane, added in the same order as one at a time
             const uint32_t room = dcap * rows_per_dup, lim = off >= room ? 0u : min(cnt, room - off);

@@ -67,6 +67,18 @@ __device__ __forceinline__ float select_lt(float x, float lim, float v) {
     return o;
 }
 
+// (a == b) ? v : 0, compare and select adjacent (see select_lt)
+__device__ __forceinline__ float select_eq(float a, float b, float v) {
+    float o;
+    asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(o) : "v"(a), "v"(b), "v"(v) : "vcc");
+    return o;
+}
+// x >= lim ? (a, b) : (c, 0): ONE compare, both selects right behind it
+__device__ __forceinline__ void select2_ge(float x, float lim, float a, float b, float c, float &o1, float &o2) {
+    asm("v_cmp_ge_f32 vcc, %2, %3\n\tv_cndmask_b32 %0, %6, %4, vcc\n\tv_cndmask_b32 %1, 0, %5, vcc"
+        : "=&v"(o1), "=&v"(o2) : "v"(x), "v"(lim), "v"(a), "v"(b), "v"(c) : "vcc");
+}
+
 // Quad sum of one value: lanes with (lane & 3) == 3 end up with the sum over their quad.
 __device__ __forceinline__ void quad_sum1(float &a) {
     asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
