@@ -54,10 +54,14 @@ for k in sorted(set(list(acc) + list(stats))):
         row['lds_conflict_share'] = round(row.get('SQ_LDS_BANK_CONFLICT', 0.0) / row['SQ_LDS_IDX_ACTIVE'], 4)
     out['kernels'].append(row)
 if field:
-    # the PMC passes run `--steps 3 --warmup 1`: four steps per pass
-    out["field_stages_hbm_bytes_per_step"] = (2 * field['FETCH_SIZE'] + field['WRITE_SIZE']) * 1024 / 4
+    # steps of a PMC pass = launches of a once-per-step kernel of this path (`--steps 3 --warmup 1` + the five untimed steps of bench.py's
+    # host-enqueue measurement since round 5: nine; a hard-coded four inflated the figure 2.25x in the first r05 summaries)
+    once = calls.get('k_asm_splat<true>', {}).get('FETCH_SIZE') or calls.get('k_colfft_bwd', {}).get('FETCH_SIZE') or ()
+    nsteps = max(len(once), 1) if once else 4
+    out["field_stages_hbm_bytes_per_step"] = (2 * field['FETCH_SIZE'] + field['WRITE_SIZE']) * 1024 / nsteps
     out["field_stages_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) summed over rocFFT's kernels and k_asm_transfer / accumulate[_bwd] / max / "
-                                "output[_bwd] of field_fwd AND field_bwd, per step (4 steps per PMC pass)")
+                                f"output[_bwd] of field_fwd AND field_bwd, per step ({nsteps} steps in the PMC pass, counted from the launches of a "
+                                "once-per-step kernel)")
 json.dump(out, open(root + '/pmc_run.json', 'w'), indent=1)
 for r in out['kernels']:
     print(r['kernel'], {k: (round(v, 1) if isinstance(v, float) else v) for k, v in r.items() if k in
