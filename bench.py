@@ -669,14 +669,14 @@ def main(argv=None):
         roofline.update(stage_roofline(dom_stage))
         traffic = pmc_traffic(run_key, kernel_names[dom_stage].split("<")[0]) if not args.saturation_skip else None
         roofline["traffic"] = traffic
-        roofline["traffic_source"] = (f"profiles/" + os.path.basename(PMC_SUMMARY) + " run {run_key}: separate rocprofv3 --pmc FETCH_SIZE / "
+        roofline["traffic_source"] = (f"profiles/" + os.path.basename(PMC_SUMMARY) + f" run {run_key}: separate rocprofv3 --pmc FETCH_SIZE / "
                                       "WRITE_SIZE passes of this command, 2*FETCH_SIZE + WRITE_SIZE per launch"
                                       if traffic is not None else None)
         if dom_stage in ("field_fwd", "field_bwd") and pmc_field_traffic(run_key) is not None:
             # a stage of many kernels (rocFFT's + ours): the counters are summed over BOTH field stages of a step, to
             # be compared with the algorithmic bytes of both (2 x 0.36 GB per image)
             roofline["traffic"] = pmc_field_traffic(run_key)
-            roofline["traffic_source"] = (f"profiles/" + os.path.basename(PMC_SUMMARY) + " run {run_key}: 2*FETCH_SIZE + WRITE_SIZE summed over all "
+            roofline["traffic_source"] = (f"profiles/" + os.path.basename(PMC_SUMMARY) + f" run {run_key}: 2*FETCH_SIZE + WRITE_SIZE summed over all "
                                           "kernels of field_fwd AND field_bwd per step; algorithmic counterpart = "
                                           f"{int(2 * ASM_BYTES_PER_IMAGE * per_gpu)} bytes")
         roofline["flop_model"] = ("SURVEY 8d: 23 flop per Gaussian-pixel forward, 60 backward; phase path (config 4): its own count, 38 / 71 "

@@ -129,6 +129,7 @@ def test_bench_line_on_the_gpu(workload):
     assert rf["bound"] in ("valu", "hbm") and rf["unit"] in ("TFLOP/s", "GB/s") and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
     assert set(rf["stage_avg_ms"]) >= {"project", "project_bwd"} and rf["stage_avg_ms_cold"]
+    assert "{" not in (rf.get("traffic_source") or "")  # (an unformatted "{run_key}" once sat in the committed lines)
     assert rf["kernel"].startswith({"config3": "k_composite_bwd", "config4": "k_phase_bwd", "config5": ""}[workload])
 
 
