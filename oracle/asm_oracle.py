@@ -51,8 +51,8 @@ def _project_bwd(pos, scale, quat, cam, proj, mean, conic, dep, f64):
 
 def transfer_function(H, W, pixel_pitch, z, wl, dtype=torch.float32):
     """DR:959-961 + DR:989-999."""
-    fx = torch.fft.fftfreq(W, d=pixel_pitch).to(dtype)
-    fy = torch.fft.fftfreq(H, d=pixel_pitch).to(dtype)
+    fx = torch.fft.fftfreq(W, d=pixel_pitch, dtype=dtype)  # (the propagator's buffers take the default dtype of the run, DR:959-961)
+    fy = torch.fft.fftfreq(H, d=pixel_pitch, dtype=dtype)
     FX, FY = torch.meshgrid(fx, fy, indexing="xy")
     kz_sq = torch.clamp((1.0 / wl) ** 2 - FX ** 2 - FY ** 2, min=0)
     return torch.exp(1j * 2 * torch.pi * z * torch.sqrt(kz_sq))
@@ -86,9 +86,12 @@ def render(pos, scale, quat, color, opacity, phases, wavelengths, cam, bg=(0.0, 
     need = grad_out is not None
     mean, conic = t(proj["mean2d"], need), t(proj["conic"], need)
     opa, col, ph, wl = t(opacity, need), t(color, need), t(phases, need), t(wavelengths, need)
-    planes = torch.linspace(depth_range[0], depth_range[1], num_planes)          # DR:1106 (fp32)
-    depth32 = torch.tensor(proj["depth"], dtype=torch.float32)
-    plane_idx = (depth32.unsqueeze(1) - planes.unsqueeze(0)).abs().argmin(dim=1)  # DR:1147-1148
+    # DR:1106: the plane depths are a buffer of the module's default dtype -- fp32 in the reference's fp32 run, fp64 in its fp64 run
+    # (round 5: until then this restatement kept them, and the propagation distances below, in fp32 in BOTH modes, and its "fp64" run
+    # sat 1.7e-5 ... 2e-4 (dL/dlambda) from the reference's own fp64 run on K6: z rounded to fp32 under a phase of ~200 rad)
+    planes = torch.linspace(depth_range[0], depth_range[1], num_planes, dtype=dtype)
+    depth_t = torch.tensor(proj["depth"], dtype=dtype)
+    plane_idx = (depth_t.unsqueeze(1) - planes.unsqueeze(0)).abs().argmin(dim=1)  # DR:1147-1148
     fields = [[torch.zeros(H, W, dtype=dtype), torch.zeros(H, W, dtype=dtype)] for _ in range(num_planes * 3)]
     for i in range(N):  # DR:1238-1283 (order-independent accumulation)
         if not vis[i]:
@@ -108,7 +111,7 @@ def render(pos, scale, quat, color, opacity, phases, wavelengths, cam, bg=(0.0, 
             fields[p * 3 + c][1] = fields[p * 3 + c][1] + torch.nn.functional.pad(amp * col[i, c] * torch.sin(phc), pad)
     total = [torch.zeros(H, W, dtype=torch.complex128 if dtype == torch.float64 else torch.complex64) for _ in range(3)]
     for p in range(num_planes):  # DR:1291-1313
-        z = torch.tensor(focal_depth, dtype=torch.float32) - planes[p]
+        z = torch.tensor(focal_depth, dtype=dtype) - planes[p]                      # DR:1293-1295, in the run's dtype
         fc = [torch.complex(fields[p * 3 + c][0], fields[p * 3 + c][1]) for c in range(3)]
         if max(float(f.detach().abs().max()) for f in fc) < 1e-8:
             continue

@@ -249,7 +249,14 @@ def rank(family, hip, exp):
             use64, tol = referee_tolerance(spread)
             err = rel_to_max(x, o64 if use64 else o32)
             e32 = rel_to_max(x, o32)
-        rows.append((err / tol, k, err, tol, spread, use64, e32))
+        # "within 1e-4 of the oracle" is satisfied by either of its two runs (tests/helpers.assert_with_referee): the fp64 one counts too
+        if k == "wavelengths":
+            e64 = float(np.abs(x - o64).max() / m)
+        elif family.startswith("asm") and k in ABS_KEYS:
+            e64 = float(np.abs(x - o64).max())
+        else:
+            e64 = rel_to_max(x, o64)
+        rows.append((min(err / tol, e64 / 1e-4), k, err, tol, spread, use64, e32))
     # a tensor passes when it is within 1e-4 of the fp32 oracle (the parity statement itself) OR within the referee rule's tolerance
     # of the run that referees it; rows are ranked by the smaller of the two ratios
     rows = [((min(r[0], r[6] / 1e-4) if r[6] == r[6] else r[0]),) + r[1:] for r in rows]
@@ -279,7 +286,7 @@ def run(out_path, commit, families):
     emit(f"# library: {ver}   commit: {commit}   date: {time.strftime('%Y-%m-%d %H:%M:%S')}")
     emit("# per case: verdict | worst tensor by (error / tolerance) | error vs the run that referees it | tolerance | the oracle's own fp32-vs-fp64 spread | "
          "plain max error vs the fp32 oracle over all tensors | seconds")
-    emit("# verdicts: ok = every tensor <= 1e-4 of max against the fp32 oracle; ok-referee = some tensor is > 1e-4 from the fp32 oracle but the oracle's own "
+    emit("# verdicts: ok = every tensor <= 1e-4 of max against the fp32 oracle (or its fp64 run); ok-referee = some tensor is > 1e-4 from the fp32 oracle but the oracle's own "
          "fp32 run is > 5e-5 from its fp64 run there and the HIP result is <= 2 x that spread from the fp64 run (conditioning of the scene, tests/helpers.py); "
          "FAIL = neither; CLASSIFIED = neither, traced to its cause (named on the next line); CRASH = exception")
     tally = {}

@@ -23,7 +23,7 @@ from helpers import (assert_with_referee, load_golden, oracle_camera, referee, r
 NAMES = ["positions", "scales", "rotations", "colors", "opacities"]
 G14 = ["G14_needles_r30_96", "G14_needles_r100_96", "G14_needles_r500_96"]
 K_PHASE = ["K1_phase_kink_s2_it12", "K2_phase_kink_s1_it23"]
-K_ASM = ["K3_asm_kink_s3_it10", "K4_asm_kink_s5_it8", "K5_asm_kink_s8_it0"]
+K_ASM = ["K3_asm_kink_s3_it10", "K4_asm_kink_s5_it8", "K5_asm_kink_s8_it0", "K6_asm_kink_s0_it4"]
 
 
 def _arrs(g):
@@ -158,6 +158,23 @@ def test_asm_oracle_vs_asm_kink_cases(case):
             continue  # one Gaussian: its phase is a global phase, the true gradient is 0 (noise / noise)
         assert_with_referee(r["grad_" + k], g["f32_grad_" + k], g["f64_grad_" + k], k)
     assert_with_referee(r["grad_wavelengths"], g["f32_grad_wavelengths"], g["f64_grad_wavelengths"], "wavelengths")
+
+
+@pytest.mark.parametrize("case", K_ASM)
+def test_asm_oracle_fp64_mode_is_the_references_fp64_run(case):
+    """The fp64 REFEREE of the randomized sweeps (asm_oracle.render(dtype=float64, project_f64=True)) against the reference's own fp64
+    run.  K6 (round 5) showed what had been missing: the plane depths, the propagation distances and the frequency grid stayed fp32
+    in the oracle's "fp64" mode -- 1.7e-5 (positions) ... 2e-4 (dL/dlambda) from the reference's fp64 run; now <= 1e-5."""
+    import torch
+    from oracle import asm_oracle
+    g = load_golden(case)
+    r = asm_oracle.render(*_arrs(g), g["phases"], g["wavelengths"], oracle_camera(g), grad_out=g["gI"], dtype=torch.float64,
+                          project_f64=True, **_asm_kwargs(g))
+    assert np.abs(r["image"] - g["f64_image"]).max() <= 2e-6
+    for k in NAMES + ["phases", "wavelengths"]:
+        if k == "phases" and len(g["positions"]) == 1:
+            continue
+        assert rel_to_max(r["grad_" + k], g["f64_grad_" + k]) <= 2e-5, k
 
 
 # ------------------------------------------------------------------------------------------------------------------
