@@ -216,10 +216,7 @@ def _describe(family, c):
 
 
 # cases outside both rules that have been traced to their cause: (family, seed, it) -> where the classification is written down
-CLASSIFIED = {
-    ("asm", 0, 4): "one Gaussian's quaternion gradient: a moment sum with cancellation ratio 3 900 x fp32 noise of the propagated gradient "
-                   "field; the same scene through the wave renderer (same splat + adjoint) is 1.3e-6 -- profiles/r05_fuzz_asm_s0_it4_classification.txt",
-}
+CLASSIFIED = {}  # (round 5: `asm s0 it 4` stood here until K6 -- the same scene through the reference -- showed it 8.8e-5 from the reference's fp64 run)
 
 ABS_KEYS = ("image",)  # images of the ASM / wave renderers live in [0, 1]: absolute error, as in the tests
 
@@ -256,10 +253,10 @@ def rank(family, hip, exp):
             e64 = float(np.abs(x - o64).max())
         else:
             e64 = rel_to_max(x, o64)
-        rows.append((min(err / tol, e64 / 1e-4), k, err, tol, spread, use64, e32))
+        rows.append((min(err / tol, e64 / 1e-4), k, err, tol, spread, use64, e32, e64))
     # a tensor passes when it is within 1e-4 of the fp32 oracle (the parity statement itself) OR within the referee rule's tolerance
     # of the run that referees it; rows are ranked by the smaller of the two ratios
-    rows = [((min(r[0], r[6] / 1e-4) if r[6] == r[6] else r[0]),) + r[1:] for r in rows]
+    rows = [((min(r[0], r[6] / 1e-4) if r[6] == r[6] else r[0]),) + r[1:] for r in rows]  # (r[0] already counts the fp64 run at 1e-4)
     rows.sort(reverse=True)
     worst = rows[0]
     plain = max(r[6] for r in rows if r[6] == r[6])
@@ -319,7 +316,7 @@ def run(out_path, commit, families):
                     if verdict != "ok":
                         os.makedirs(os.path.join(ROOT, "gpurun_out", "sweep_dump"), exist_ok=True)  # the HIP side, for analysis off the box
                         np.savez_compressed(os.path.join(ROOT, "gpurun_out", "sweep_dump", f"{fam}_s{seed}_it{c['it']}.npz"), **hip)
-                        line += "\n" + "\n".join(f"             {r[1]:12s} err {r[2]:.2e} ({'fp64' if r[5] else 'fp32'} referee) tol {r[3]:.1e} spread {r[4]:.1e} vs-fp32 {r[6]:.2e}"
+                        line += "\n" + "\n".join(f"             {r[1]:12s} err {r[2]:.2e} ({'fp64' if r[5] else 'fp32'} referee) tol {r[3]:.1e} spread {r[4]:.1e} vs-fp32 {r[6]:.2e} vs-fp64 {r[7]:.2e}"
                                                  for r in rows if r[6] > 1e-4 or r[0] > 1.0)
                 except Exception as e:  # noqa: BLE001 -- the log must say what died and where
                     verdict = "CRASH"
