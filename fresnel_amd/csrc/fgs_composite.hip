@@ -20,7 +20,7 @@
 #include "fgs_internal.h"
 #include "fgs_wave.h"
 
-#if (defined(FGS_BWD_DYN_LDS) || defined(FGS_BWD_WIDE_WAVES) || defined(FGS_PHASE_PARK) || defined(FGS_PHASE_SCAN) || defined(FGS_CKPT_NT) || defined(FGS_PHASE_WAVE_BLOCKS) || defined(FGS_PHASE_GROUP16)) && !defined(FGS_EXPERIMENT_BUILD)
+#if (defined(FGS_BWD_DYN_LDS) || defined(FGS_BWD_WIDE_WAVES) || defined(FGS_PHASE_SCAN) || defined(FGS_CKPT_NT) || defined(FGS_PHASE_WAVE_BLOCKS)) && !defined(FGS_EXPERIMENT_BUILD)
 #error "work-split / timing switches of this unit are for experiment builds: python -m fresnel_amd.build --define ... (sets FGS_EXPERIMENT_BUILD; fgs_version() then says so)"
 #endif
 
@@ -675,13 +675,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NSX == 2 ? 6
 #ifndef FGS_PHASE_SCAN
 #define FGS_PHASE_SCAN 64  /* list entries per scan block (a multiple of FGS_PHASE_CKPT, <= 64) */
 #endif
-#ifndef FGS_PHASE_PARK
-#define FGS_PHASE_PARK 0   /* 1: the backward's re-run also parks G and the interference factor of every entry (registers) */
-#endif
 static_assert(FGS_PHASE_SCAN <= 64 && FGS_PHASE_SCAN % FGS_PHASE_CKPT == 0, "scan block");
-#ifndef FGS_PHASE_GROUP16
-#define FGS_PHASE_GROUP16 0  /* 1: (A, Phi) checkpoints every 16 touched entries instead of 8 -- see k_phase_bwd */
-#endif
 #ifndef FGS_PHASE_WAVE_BLOCKS
 #define FGS_PHASE_WAVE_BLOCKS 0  /* 1 (experiment): every sub-tile wave is a workgroup of its own -- see phase_wave_block */
 #endif
@@ -773,7 +767,7 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_fwd(
         for (uint32_t j0 = 0; j0 < nt; j0 += PCK) {
             const size_t slot = (size_t)(c.start / PCK) + (base - c.start + j0) / PCK + c.tile;
             float *ck = phase_ckpt + slot * 512 + lane;
-            if (!FGS_PHASE_GROUP16 || (j0 % 16u) == 0u) { ck[wave * 64] = A; ck[(4 + wave) * 64] = Ph; }
+            ck[wave * 64] = A; ck[(4 + wave) * 64] = Ph;
             const uint32_t m = min((uint32_t)PCK, nt - j0);
 #pragma unroll
             for (int k = 0; k < PCK; ++k) {
@@ -812,6 +806,8 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_fwd(
     }
 }
 
+// (Round 5 measured and removed three experiment switches of this kernel -- parking G / the interference factor in the re-run, checkpoint
+// groups of sixteen, the re-run interleaved with the sweep: profiles/r05_ab_phase_variants.txt; the code of the first two is in commit c134f2a.)
 // Backward of the phase recurrence (the reference cannot backprop this path at all, §0.6 -- the contract is the
 // exact adjoint of the forward recurrence DR:629-667).  The recurrence cannot be inverted back-to-front, so the wave walks
 // its sub-tile's touched entries in REVERSE checkpoint groups: re-runs the forward inside a group from the group's (A, Phi)
@@ -882,43 +878,6 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
         if (bi && lane < SCAN) gid_next = dup_ids[base - SCAN + lane];  // the block in front of this one: always full
         const unsigned long long touched = phase_scan<false>(st, rows, gid, have, sx, sy, c, rec, phase, dup_off);
         const uint32_t nt = (uint32_t)__popcll(touched);
-#if FGS_PHASE_GROUP16
-        // (A, Phi) checkpoints every SIXTEEN touched entries (half the checkpoint bytes): the second half of a group restarts from the
-        // state a plain re-run of its first half provides -- that half is re-run twice, once here without parking and once below
-        const uint32_t ngroups = 2u * ((nt + 15u) / 16u);
-        float A8 = 0.0f, P8 = 0.0f, Ac = 0.0f, Pc = 0.0f;
-        for (uint32_t g = ngroups; g-- > 0;) {
-            const uint32_t j0 = g * PCK;
-            if (j0 >= nt) continue;  // (a last group of <= 8 entries has no second half)
-            const uint32_t m = min((uint32_t)PCK, nt - j0);
-            if ((g & 1u) || j0 + PCK >= nt) {  // first visit of this group of sixteen: its checkpoint, and -- if it has a second half -- the state in front of that
-                const size_t slot = (size_t)(c.start / PCK) + (bi * SCAN + (j0 & ~15u)) / PCK + c.tile;
-                const float *ck = phase_ckpt + slot * 512 + lane;
-                Ac = ck[wave * 64]; Pc = ck[(4 + wave) * 64];
-                if (g & 1u) {
-                    A8 = Ac; P8 = Pc;
-#pragma unroll
-                    for (int k = 0; k < PCK; ++k) {
-                        const float4 q0 = st.a[j0 - PCK + k], q1 = st.b[j0 - PCK + k], q2 = st.c[j0 - PCK + k];
-                        const uint32_t bits = __float_as_uint(q2.w);
-                        const uint32_t mk = (uint32_t)__builtin_amdgcn_sbfe((int)bits, lx, 1) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, 8u + ly, 1);
-                        const float dx = fpx - q0.x, dy = fpy - q0.y;
-                        const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
-                        float alpha = __builtin_amdgcn_exp2f(mm) * q1.y;
-                        float pd = fabsf(q2.z - P8);
-                        pd = fminf(pd, 1.0f - pd);
-                        alpha *= base_amp + amp * phase_cos(pd * PHASE_KAPPA);
-                        alpha = __builtin_amdgcn_fmed3f(alpha, 0.0f, ALPHA_MAX);
-                        alpha = __uint_as_float(__float_as_uint(alpha) & mk);
-                        const float w = alpha * (1.0f - A8);
-                        A8 += w;
-                        const float pc = w / fmaxf(A8, 1e-6f);
-                        P8 = P8 * (1.0f - pc) + q2.z * pc;
-                    }
-                }
-            }
-            float Af = (g & 1u) ? A8 : Ac, Pf = (g & 1u) ? P8 : Pc;
-#else
         const uint32_t ngroups = (nt + PCK - 1) / PCK;
         for (uint32_t g = ngroups; g-- > 0;) {
             const uint32_t j0 = g * PCK;
@@ -926,26 +885,11 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
             const size_t slot = (size_t)(c.start / PCK) + (bi * SCAN + j0) / PCK + c.tile;
             const float *ck = phase_ckpt + slot * 512 + lane;
             float Af = ck[wave * 64], Pf = ck[(4 + wave) * 64];
-#endif
             // ---- forward re-run of the group: park (A_{i-1}, Phi_{i-1}) ----
             float sA[PCK], sP[PCK];
-#if FGS_PHASE_PARK == 1
-            float sG[PCK], sI[PCK];
-#elif FGS_PHASE_PARK == 2
-            float sG[PCK];
-#elif FGS_PHASE_PARK == 3
-            float sI[PCK];
-#endif
 #pragma unroll
             for (int k = 0; k < PCK; ++k) {
                 sA[k] = 0.0f; sP[k] = 0.0f;
-#if FGS_PHASE_PARK == 1
-                sG[k] = 0.0f; sI[k] = 0.0f;
-#elif FGS_PHASE_PARK == 2
-                sG[k] = 0.0f;
-#elif FGS_PHASE_PARK == 3
-                sI[k] = 0.0f;
-#endif
                 if (k >= (int)m) continue;  // wave-uniform
                 const float4 q0 = st.a[j0 + k], q1 = st.b[j0 + k], q2 = st.c[j0 + k];
                 const uint32_t bits = __float_as_uint(q2.w);
@@ -953,26 +897,12 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
                 sA[k] = Af; sP[k] = Pf;
                 const float dx = fpx - q0.x, dy = fpy - q0.y;
                 const float mm = (q0.z * dx) * dx + (q0.w * dx) * dy + (q1.x * dy) * dy;
-#if FGS_PHASE_PARK
-                const float Gk = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm)) & mk);
-                float pd = fabsf(q2.z - Pf);
-                pd = fminf(pd, 1.0f - pd);
-                const float Ik = base_amp + amp * phase_cos(pd * PHASE_KAPPA);
-#if FGS_PHASE_PARK != 3
-                sG[k] = Gk;
-#endif
-#if FGS_PHASE_PARK != 2
-                sI[k] = Ik;
-#endif
-                const float alpha = __builtin_amdgcn_fmed3f((Gk * q1.y) * Ik, 0.0f, ALPHA_MAX);
-#else
                 float alpha = __builtin_amdgcn_exp2f(mm) * q1.y;  // (conic staged in exp2 units)
                 float pd = fabsf(q2.z - Pf);
                 pd = fminf(pd, 1.0f - pd);
                 alpha *= base_amp + amp * phase_cos(pd * PHASE_KAPPA);
                 alpha = __builtin_amdgcn_fmed3f(alpha, 0.0f, ALPHA_MAX);
                 alpha = __uint_as_float(__float_as_uint(alpha) & mk);
-#endif
                 const float w = alpha * (1.0f - Af);
                 Af += w;
                 const float pc = w / fmaxf(Af, 1e-6f);
@@ -993,17 +923,9 @@ __global__ __launch_bounds__(FGS_PHASE_WAVE_BLOCKS ? 64 : 256) void k_phase_bwd(
                 const float pd0 = fabsf(dphi);
                 const float pd = fminf(pd0, 1.0f - pd0);
                 // G zeroed outside the bbox: raw, alpha, w, pc and every gradient term of this pixel then vanish by themselves
-#if FGS_PHASE_PARK == 1 || FGS_PHASE_PARK == 2
-                const float G = sG[k];
-#else
                 const float mm = (ca * dx) * dx + (cbc * dx) * dy + (cd * dy) * dy;
                 const float G = __uint_as_float(__float_as_uint(__builtin_amdgcn_exp2f(mm)) & mk);
-#endif
-#if FGS_PHASE_PARK == 1 || FGS_PHASE_PARK == 3
-                const float inter = sI[k];
-#else
                 const float inter = base_amp + amp * phase_cos(pd * PHASE_KAPPA);
-#endif
                 // (parking G and `inter` of the re-run instead of recomputing them costs 14 VGPRs = one wave per SIMD and
                 // was 7 % slower in round 2: this kernel lives on occupancy)
                 const float Gop = G * op, Gint = G * inter;
