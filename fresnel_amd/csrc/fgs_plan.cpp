@@ -35,7 +35,7 @@ int fgs_make_plan(const FgsDims *d, FgsPlan *p, int layers, bool segment_ckpt) {
     }
     const int fv = d->fwd_variant, afv = fv < -16 || fv > 16 ? 3 /* invalid; INT_MIN has no negation */ : (fv < 0 ? -fv : fv);
     if (d->seg_len < 0 || d->seg_len > 512 || d->seg_len % 64 != 0 || (afv != 0 && afv != 1 && afv != 2 && afv != 4 && !(fv == 8 || fv == 16)) ||
-        d->bin_mode < 0 || d->bin_mode > 2 || (d->tile_w != 0 && d->tile_w != 16 && d->tile_w != 32) || d->sort_mode < 0 || d->sort_mode > 7) {
+        d->bin_mode < 0 || d->bin_mode > 2 || (d->tile_w != 0 && d->tile_w != 16 && d->tile_w != 32) || d->sort_mode < 0 || d->sort_mode > 11) {
         fgs_set_error("invalid tuning: seg_len=%d fwd_variant=%d bin_mode=%d tile_w=%d sort_mode=%d", d->seg_len, d->fwd_variant,
                       d->bin_mode, d->tile_w, d->sort_mode);
         return FGS_EINVAL;

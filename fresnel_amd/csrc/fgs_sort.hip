@@ -57,6 +57,27 @@ __device__ __forceinline__ SegInfo block_range(uint32_t seg_len, const uint32_t 
 }
 
 
+// Stable rank of a lane among the wave's lanes that hold the same BITS-bit digit (valid lanes only): `rank` = how many of them sit in
+// lower lanes, `count` = how many there are.  One ballot per digit bit; the running match mask is kept as two 32-bit halves per lane
+// and narrowed by m &= ~(ballot ^ sext(bit)) -- four VALU instructions per bit (v_bfe_i32, v_cmp, two three-input bit operations).
+// Written as `m &= bset ? bm : ~bm` on a 64-bit mask the compiler spends eleven per bit on it (compare, select, compare again for
+// the ballot, 64-bit select built from a cndmask and a 64-bit add, two xor, two and: 110 instructions per 64 keys), and the
+// ranking is what a pass of the in-LDS sort costs.
+template <int BITS>
+__device__ __forceinline__ void match_rank(uint32_t digit, bool valid, uint32_t &rank, uint32_t &count) {
+    const unsigned long long bv = __ballot(valid);
+    uint32_t mlo = (uint32_t)bv, mhi = (uint32_t)(bv >> 32);
+#pragma unroll
+    for (int bit = 0; bit < BITS; ++bit) {
+        const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)digit, bit, 1);  // all ones where the bit is set
+        const unsigned long long bm = __ballot(sel != 0u);
+        mlo &= ~((uint32_t)bm ^ sel);
+        mhi &= ~((uint32_t)(bm >> 32) ^ sel);
+    }
+    rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+    count = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+}
+
 // ---- key compression (see the header) ------------------------------------------------------------------------------------
 struct KeyPlan {
     uint32_t live;      // passes this segment needs (>= 1)
@@ -280,18 +301,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_downsweep(
         for (int it = 0; it < 4; ++it) {
             const uint32_t digit = COMPRESSED ? key_digit(kp, key[it], pass) : (key[it] >> shift) & dmask;
             dig[it] = digit;
-            unsigned long long m = __ballot(valid[it]);
-#pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const bool bset = (digit >> bit) & 1u;
-                const unsigned long long bm = __ballot(valid[it] && bset);
-                m &= bset ? bm : ~bm;
-            }
-            const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+            uint32_t rank, count;
+            match_rank<8>(digit, valid[it], rank, count);
             const uint32_t prev = valid[it] ? wcnt[wave][digit] : 0u;
             lrank[it] = prev + rank;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (valid[it] && rank == 0) wcnt[wave][digit] = prev + (uint32_t)__popcll(m);
+            if (valid[it] && rank == 0) wcnt[wave][digit] = prev + count;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         __syncthreads();
@@ -562,18 +577,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_fused(
         for (int it = 0; it < 4; ++it) {
             const uint32_t digit = digit_of(key[it]);
             dig[it] = digit;
-            unsigned long long m = __ballot(valid[it]);
-#pragma unroll
-            for (int bit = 0; bit < BITS; ++bit) {
-                const bool bset = (digit >> bit) & 1u;
-                const unsigned long long bm = __ballot(valid[it] && bset);
-                m &= bset ? bm : ~bm;
-            }
-            const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+            uint32_t rank, count;
+            match_rank<BITS>(digit, valid[it], rank, count);
             const uint32_t prev = valid[it] ? wcnt[wave][digit] : 0u;
             lrank[it] = prev + rank;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (valid[it] && rank == 0) wcnt[wave][digit] = prev + (uint32_t)__popcll(m);
+            if (valid[it] && rank == 0) wcnt[wave][digit] = prev + count;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         __syncthreads();
@@ -603,6 +612,139 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_fused(
     }
 }
 
+// ---- WHOLE SEGMENT IN LDS (round 5) ---------------------------------------------------------------------------------------------
+// What the A/B of the fused passes showed (profiles/r05_ab_sort_passes.txt): a depth-sort pass costs its launch boundary and two
+// memory round trips, not its bytes -- 16 x 8192 keys are 1 MB.  A segment of at most 8192 (key, payload) pairs fits the LDS of ONE
+// compute unit twice over (2 x 64 KB of pairs + 16 KB of rank counters), so one 16-wave block per segment runs ALL the passes there:
+// one launch instead of eight, one read of the keys and one write of the order, no histogram in memory.  A pass is
+// k_radix_downsweep's: wave w owns the w-th contiguous slice of the segment (<= 8 chunks of 64 keys, held in registers), ranks its
+// keys chunk by chunk with wave64 ballots against its own row of digit counters (stable, no atomics), 256 threads turn the 16 x 256
+// counters into exclusive prefixes (over the waves, then over the digits), every wave scatters its keys into the other LDS buffer.
+// Three block barriers per pass.  Zone keys (COMPRESSED): the key is compressed ONCE, when it is loaded -- pext(key, varying bits),
+// a culled key 1 << popcount -- and the passes that the compressed keys need run on plain 8-bit digits of it.
+constexpr int SL_THREADS = 1024, SL_WAVES = SL_THREADS / 64, SL_CAP = 8192, SL_CH = SL_CAP / SL_THREADS;
+
+template <bool COMPRESSED>
+__global__ __launch_bounds__(SL_THREADS) void k_sort_segment_lds(
+    const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, uint32_t seg_len, uint32_t seg_stride, uint32_t passes, uint32_t idx_mod,
+    const uint32_t *__restrict__ key_bits, uint32_t key_recs) {
+    __shared__ uint32_t ks[2][SL_CAP], vs[2][SL_CAP];
+    __shared__ uint32_t wcnt[SL_WAVES][256];
+    __shared__ uint32_t run_off[256];
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t kb[3 * SL_WAVES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t seg0 = blockIdx.x * seg_stride;
+    const uint32_t nch = (seg_len + SL_THREADS - 1u) / SL_THREADS;  // chunks per wave (host-checked: <= SL_CH)
+    const uint32_t w0 = wave * nch * 64u;                           // wave w owns the keys [w0, w0 + 64 nch) of the segment
+    uint32_t key[SL_CH], val[SL_CH];
+    bool valid[SL_CH];
+#pragma unroll
+    for (int c = 0; c < SL_CH; ++c) {
+        const uint32_t i = w0 + (uint32_t)c * 64u + lane;
+        valid[c] = (uint32_t)c < nch && i < seg_len;
+        key[c] = valid[c] ? keys[seg0 + i] : 0u;
+        // (the depth sort's payload: the index inside the image -- seg0 is a multiple of idx_mod there, no division)
+        val[c] = valid[c] ? (vals_in ? vals_in[seg0 + i] : (idx_mod == seg_stride ? i : (seg0 + i) % idx_mod)) : 0u;
+    }
+    if (COMPRESSED) {
+        uint32_t vor = 0u, vand = 0xFFFFFFFFu, fl = 0u;
+        for (uint32_t i = tid; i < key_recs; i += SL_THREADS) {
+            const uint4 r = reinterpret_cast<const uint4 *>(key_bits)[(size_t)blockIdx.x * key_recs + i];
+            vor |= r.x; vand &= r.y; fl |= r.z;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { vor |= __shfl_xor(vor, o, 64); vand &= __shfl_xor(vand, o, 64); fl |= __shfl_xor(fl, o, 64); }
+        if (lane == 0) { kb[3 * wave] = vor; kb[3 * wave + 1] = vand; kb[3 * wave + 2] = fl; }
+        __syncthreads();
+        uint32_t o = 0u, a = 0xFFFFFFFFu, f = 0u;
+#pragma unroll
+        for (int w = 0; w < SL_WAVES; ++w) { o |= kb[3 * w]; a &= kb[3 * w + 1]; f |= kb[3 * w + 2]; }
+        const uint32_t m = (f & 2u) ? (o ^ a) : 0u;  // no visible key: nothing varies
+        const uint32_t nbits = (uint32_t)__popc(m), cull = f & 1u;
+        const uint32_t need = (nbits + cull + 7u) / 8u;
+        passes = need < 1u ? 1u : (need > 4u ? 4u : need);
+        if (need <= 4u) {  // (33 bits -- every key bit varies and some keys are culled -- is the key itself, as in key_digit)
+            uint32_t d[SL_CH];
+#pragma unroll
+            for (int c = 0; c < SL_CH; ++c) d[c] = 0u;
+            uint32_t mm = m, i = 0u;
+            while (mm) {  // block-uniform: the varying bits, lowest first
+                const uint32_t pos = (uint32_t)__ffs((int)mm) - 1u;
+#pragma unroll
+                for (int c = 0; c < SL_CH; ++c) d[c] |= ((key[c] >> pos) & 1u) << i;
+                ++i; mm &= mm - 1u;
+            }
+#pragma unroll
+            for (int c = 0; c < SL_CH; ++c) key[c] = key[c] == 0xFFFFFFFFu ? 1u << nbits : d[c];  // culled: behind every visible key
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wcnt[wave][lane + 64u * k] = 0u;  // (the wave's own row: its LDS operations execute in order)
+    for (uint32_t p = 0; p < passes; ++p) {
+        const uint32_t shift = 8u * p;
+        uint32_t lrank[SL_CH], dig[SL_CH];
+        // (ranking all chunks first and walking the counters afterwards -- the LDS chain out of the ballots' way -- is SLOWER: 32 against
+        //  29.5 us at 16 x 8192 keys, profiles/r05_ab_sort_lds.txt: the waves of a SIMD fall into step and wait together)
+#pragma unroll
+        for (int c = 0; c < SL_CH; ++c) {
+            if ((uint32_t)c >= nch) continue;  // block-uniform
+            const uint32_t digit = (key[c] >> shift) & 0xFFu;
+            dig[c] = digit;
+            uint32_t rank, count;
+            match_rank<8>(digit, valid[c], rank, count);
+            const uint32_t prev = valid[c] ? wcnt[wave][digit] : 0u;
+            lrank[c] = prev + rank;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (valid[c] && rank == 0) wcnt[wave][digit] = prev + count;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        __syncthreads();
+        if (tid < 256u) {  // digit `tid`: the waves' counts -> exclusive prefixes over the waves; then over the digits
+            uint32_t cw[SL_WAVES], acc = 0u;
+#pragma unroll
+            for (int w = 0; w < SL_WAVES; ++w) cw[w] = wcnt[w][tid];
+#pragma unroll
+            for (int w = 0; w < SL_WAVES; ++w) { wcnt[w][tid] = acc; acc += cw[w]; }
+            uint32_t sc = acc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(sc, o, 64);
+                if ((int)lane >= o) sc += v;
+            }
+            if (lane == 63u) wtot[wave] = sc;
+            run_off[tid] = sc - acc;
+        }
+        __syncthreads();
+        const bool last = p + 1u == passes;
+        uint32_t *kd = ks[p & 1u], *vd = vs[p & 1u];
+        const uint32_t t0 = wtot[0], t1 = t0 + wtot[1], t2 = t1 + wtot[2];
+#pragma unroll
+        for (int c = 0; c < SL_CH; ++c) {
+            if (valid[c]) {  // (false for c >= nch)
+                const uint32_t d = dig[c];
+                const uint32_t dst = run_off[d] + (d >= 192u ? t2 : (d >= 128u ? t1 : (d >= 64u ? t0 : 0u))) + wcnt[wave][d] + lrank[c];
+                if (last) {
+                    vals_out[seg0 + dst] = val[c];
+                    if (!COMPRESSED && keys_out) keys_out[seg0 + dst] = key[c];
+                } else {
+                    kd[dst] = key[c]; vd[dst] = val[c];
+                }
+            }
+        }
+        if (last) break;
+        __syncthreads();  // the pass's output is in place; the counters are free
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wcnt[wave][lane + 64u * k] = 0u;
+#pragma unroll
+        for (int c = 0; c < SL_CH; ++c) {
+            const uint32_t i = w0 + (uint32_t)c * 64u + lane;
+            if (valid[c]) { key[c] = kd[i]; val[c] = vd[i]; }
+        }
+    }
+}
+
 // blocks per segment of the fused pass: ~2048 keys of its own per block (ranking costs ~6x the histogram per key), <= 16 (every
 // block reads the whole segment), <= 4096 blocks per launch
 uint32_t fused_blocks_per_seg(uint32_t seg_len, uint32_t num_segs) {
@@ -625,15 +767,39 @@ int fgs_launch_radix_sort(uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_a
                           uint32_t seg_stride, uint32_t num_segs, uint32_t key_bits, uint32_t *hist,
                           hipStream_t st, const uint32_t *keys_first, uint32_t index_payload_mod,
                           const uint32_t *key_stats, uint32_t key_recs, int pass_mode) {
-    // pass_mode (FgsDims.sort_mode >> 1): 0 = automatic -- the fused pass (one launch per pass, 11-bit digits) for segments of at most
-    // 4096 keys (one or two blocks per segment: little or nothing is read twice, and 8 launches become 3 where launches are all there
-    // is), the two-launch 8-bit passes of rounds 1-4 otherwise | 1 = the fused pass with 11-bit digits for any host-known segment
-    // length up to 64 K keys | 2 = the same with 8-bit digits (A/B runs, agreement tests).  Measured (profiles/r05_ab_sort_passes.txt):
-    // at 16 x 8 192 keys the fused passes take 45.6 us (11-bit) / 55.5 (8-bit) against 42.0 for the two-launch passes, at 8 x 32 768
-    // keys 100.9 / 127.8 against 53.8 -- every block counting the WHOLE segment's digits with LDS atomics costs more than the launch
-    // boundary it saves (~2.8 us); a pass is two memory round trips whichever way it is launched.
-    const bool fused = !seg_len_dev && seg_len == seg_capacity && key_bits >= 1u &&
-                       (pass_mode == 0 ? seg_len <= 4096u : seg_len <= 65536u);
+    // pass_mode (FgsDims.sort_mode >> 1): 1 = the fused pass (one launch per pass, every block recounting its segment, 11-bit digits)
+    // for any host-known segment length up to 64 K keys | 2 = the same with 8-bit digits | 3 = 8-bit digits with the hand-off (A/B runs,
+    // agreement tests).  Measured (profiles/r05_ab_sort_passes.txt): at 16 x 8 192 keys the fused passes take 45.6 us (11-bit) / 55.5
+    // (8-bit) against 42.0 for the two-launch passes, at 8 x 32 768 keys 100.9 / 127.8 against 53.8 -- every block counting the WHOLE
+    // segment's digits with LDS atomics costs more than the launch boundary it saves (~2.8 us); a pass is two memory round trips
+    // whichever way it is launched.  (Until the LDS sort below, automatic used the 11-bit fused pass for segments of <= 4096 keys.)
+    // Round 5, later: 0 = automatic now means the whole-segment LDS sort (k_sort_segment_lds: ONE launch for all passes) for
+    // host-known segments of at most 8192 keys, the two-launch passes above that | 4 = the two-launch passes for any size | 5 = the LDS
+    // sort where it applies (as automatic).  profiles/r05_ab_sort_lds.txt.
+    const bool host_len = !seg_len_dev && seg_len == seg_capacity && key_bits >= 1u;
+    if (host_len && seg_len <= (uint32_t)SL_CAP && (pass_mode == 0 || pass_mode == 5) && (vals_in || index_payload_mod)) {
+        const bool compressed = key_stats != nullptr;
+        if (compressed && !(keys_first && index_payload_mod && vals_final && key_recs && key_bits == 32u)) {
+            fgs_set_error("radix sort: key compression needs 32-bit keys in keys_first, an index payload and vals_final");
+            return FGS_EINVAL;
+        }
+        const uint32_t *kin = keys_first ? keys_first : keys_in;
+        uint32_t *kdst = compressed ? nullptr : (keys_first ? keys_in : keys_alt);
+        uint32_t *vdst = vals_final ? vals_final : vals_alt;
+        const uint32_t *vsrc = index_payload_mod ? nullptr : vals_in;
+        const uint32_t passes = (key_bits + 7u) / 8u, imod = index_payload_mod ? index_payload_mod : 1u;
+        if (compressed)
+            hipLaunchKernelGGL(k_sort_segment_lds<true>, dim3(num_segs), dim3(SL_THREADS), 0, st, kin, vsrc, kdst, vdst, seg_len, seg_stride,
+                               passes, imod, key_stats, key_recs);
+        else
+            hipLaunchKernelGGL(k_sort_segment_lds<false>, dim3(num_segs), dim3(SL_THREADS), 0, st, kin, vsrc, kdst, vdst, seg_len, seg_stride,
+                               passes, imod, (const uint32_t *)nullptr, 0u);
+        FGS_LAUNCH_CHECK("k_sort_segment_lds");
+        *keys_sorted = kdst;
+        *vals_sorted = vdst;
+        return FGS_OK;
+    }
+    const bool fused = host_len && pass_mode >= 1 && pass_mode <= 3 && seg_len <= 65536u;
     // (pass_mode 3, the hand-off form: a compressed segment that leaves a pass early publishes nothing for it, and nobody of that
     //  segment waits either -- all its blocks leave together; region p belongs to pass p alone, so no word is ever reused in a call)
     if (fused) {

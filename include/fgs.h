@@ -73,11 +73,12 @@ typedef struct FgsDims {
                                vary over an image's visible Gaussians and only the passes those need do any work -- the same
                                order for ANY depths, faster when they vary in few bits.  NOT chosen automatically: what the
                                depths look like is known on the device only (fgs_sort.hip).
-                               Bits 1-2 (work split, never the result): 0 = automatic -- ONE launch per pass with 11-bit digits
-                               (three passes; round 5) for images of <= 4096 Gaussians, the two-launch 8-bit passes of
-                               rounds 1-4 above | 2 = one launch per pass, 11-bit digits, for any image of <= 65 536 Gaussians
-                               | 4 = the same with 8-bit digits | 6 = 8-bit digits, the blocks' digit
-                               counts handed off between them instead of recounted (bounded wait).  Valid values: 0 ... 7.                                   */
+                               Bits 1-3 (work split, never the result): 0 = automatic -- images of <= 8192 Gaussians are sorted by
+                               ONE launch, all passes in the LDS of one compute unit per image (round 5); larger ones by the
+                               two-launch 8-bit passes of rounds 1-4 | 2 = one launch per pass, 11-bit digits, every block
+                               recounting its image (<= 65 536 Gaussians) | 4 = the same with 8-bit digits | 6 = 8-bit digits,
+                               the blocks' digit counts handed off between them instead of recounted (bounded wait) | 8 = the
+                               two-launch passes for any size | 10 = as automatic.  Valid values: 0 ... 11.                 */
 } FgsDims;
 
 /* Camera record on the DEVICE: FGS_CAMERA_FLOATS floats per camera (Camera, DR:27-52):

@@ -671,15 +671,16 @@ def test_forward_variants_agree(use_phase):
             assert rel_to_max(o["grad_" + k], go[k]) <= TOL, (t, k)
 
 
-@pytest.mark.parametrize("sort_mode", [1, 0, 2, 3, 4, 5, 6, 7])
-@pytest.mark.parametrize("N", [1000, 8192, 33000, 70000])
+@pytest.mark.parametrize("sort_mode", [1, 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("N", [1000, 5000, 8192, 33000, 70000])
 def test_depth_sort_key_compression_gives_the_full_key_order(N, sort_mode):
     """Round 4 (BASELINE config 4, "depth-zone sort keys"): with FgsDims.sort_mode bit 0 set the depth sort keeps only the key bits
-    that vary over an image's visible Gaussians and runs as many passes as those need.  Round 5: bits 1-2 select the pass
-    implementation -- 0 = automatic (ONE launch per pass, every block forming the segment's histogram itself, 11-bit digits, for
-    images of <= 4096 Gaussians: N = 1000 here; the two-launch 8-bit passes of rounds 1-4 above), 2 = one launch per pass with
-    11-bit digits up to 65 536 Gaussians (N = 70000 falls back to two launches), 4 = the same with 8-bit digits, 6 = 8-bit digits with the
-    blocks' histograms handed off between them (published words polled with a bounded wait).  Whatever the depths look like, and in EVERY mode, `order` must be the stable argsort of the
+    that vary over an image's visible Gaussians and runs as many passes as those need.  Round 5: bits 1-3 select the pass
+    implementation -- 0 = automatic (images of <= 8192 Gaussians: ONE launch, one block per image, all passes in LDS -- N = 1000, 5000
+    and 8192 here, the last one filling its eight chunks per wave exactly; the two-launch 8-bit passes of rounds 1-4 above), 2 = one
+    launch per pass, every block forming the segment's histogram itself, 11-bit digits, up to 65 536 Gaussians (N = 70000 falls back
+    to two launches), 4 = the same with 8-bit digits, 6 = 8-bit digits with the blocks' histograms handed off between them (published
+    words polled with a bounded wait), 8 = the two-launch passes at every size, 10 = as automatic.  Whatever the depths look like, and in EVERY mode, `order` must be the stable argsort of the
     FULL keys (culled keys = 0xFFFFFFFF last, in index order).  One batch, one image of each kind:
       0  zone-snapped depths (8 values: 3 varying bits, ONE live pass), some Gaussians culled;
       1  ordinary depths (~25 varying bits: all four passes);
@@ -687,7 +688,7 @@ def test_depth_sort_key_compression_gives_the_full_key_order(N, sort_mode):
       3  one single depth, nothing culled (no varying bit, no culled bit);
       4  two depths that differ in ONE low mantissa bit + culled ones (2 bits: one pass);
       5  depths that differ in the exponent byte and the low byte only (16 varying bits in two separate bytes).
-    N = 1000 / 33000: segments that are not whole projection blocks (key statistics) or whole sort rounds."""
+    N = 1000 / 5000 / 33000: segments that are not whole projection blocks (key statistics) or whole sort rounds."""
     from fresnel_amd.renderer import Camera
     S = 128
     rs = np.random.RandomState(N)

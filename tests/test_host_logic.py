@@ -263,7 +263,7 @@ def test_harness_selects_the_zone_key_depth_sort_with_fresnel_zones():
     d = B.make_dims(2, 100, 64, 64, tuning=dict(sort_mode=1))
     assert d.sort_mode == 1 and B.make_dims(2, 100, 64, 64).sort_mode == 0
     with pytest.raises(B.FgsError):
-        B.saved_layout(B.make_dims(2, 100, 64, 64, tuning=dict(sort_mode=8)))
+        B.saved_layout(B.make_dims(2, 100, 64, 64, tuning=dict(sort_mode=12)))
     with pytest.raises(B.FgsError):
         B.saved_layout(B.make_dims(70000, 4, 16, 16))   # images are a grid dimension: <= 65535
 
