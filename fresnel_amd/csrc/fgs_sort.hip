@@ -59,7 +59,7 @@ __device__ __forceinline__ SegInfo block_range(uint32_t seg_len, const uint32_t 
 
 // Stable rank of a lane among the wave's lanes that hold the same BITS-bit digit (valid lanes only): `rank` = how many of them sit in
 // lower lanes, `count` = how many there are.  One ballot per digit bit; the running match mask is kept as two 32-bit halves per lane
-// and narrowed by m &= ~(ballot ^ sext(bit)) -- four VALU instructions per bit (v_bfe_i32, v_cmp, two three-input bit operations).
+// and narrowed by m &= ~(ballot ^ sext(bit)) -- four VALU instructions per bit (v_bfe_i32, v_cmp, two v_bitop3_b32).
 // Written as `m &= bset ? bm : ~bm` on a 64-bit mask the compiler spends eleven per bit on it (compare, select, compare again for
 // the ballot, 64-bit select built from a cndmask and a 64-bit add, two xor, two and: 110 instructions per 64 keys), and the
 // ranking is what a pass of the in-LDS sort costs.
@@ -70,9 +70,11 @@ __device__ __forceinline__ void match_rank(uint32_t digit, bool valid, uint32_t 
 #pragma unroll
     for (int bit = 0; bit < BITS; ++bit) {
         const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)digit, bit, 1);  // all ones where the bit is set
-        const unsigned long long bm = __ballot(sel != 0u);
-        mlo &= ~((uint32_t)bm ^ sel);
-        mhi &= ~((uint32_t)(bm >> 32) ^ sel);
+        const unsigned long long bm = __ballot((int)sel < 0);
+        // m & ~(bm ^ sel) as ONE three-input bit operation per half (truth table 0x90: m set and bm == sel); spelled with & ~ ^ the
+        // compiler collects the mismatches with shifts, xors and or3s instead: six instructions per bit, this is four
+        mlo = __builtin_amdgcn_bitop3_b32(mlo, (uint32_t)bm, sel, 0x90);
+        mhi = __builtin_amdgcn_bitop3_b32(mhi, (uint32_t)(bm >> 32), sel, 0x90);
     }
     rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
     count = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
@@ -619,8 +621,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_fused(
 // one launch instead of eight, one read of the keys and one write of the order, no histogram in memory.  A pass is
 // k_radix_downsweep's: wave w owns the w-th contiguous slice of the segment (<= 8 chunks of 64 keys, held in registers), ranks its
 // keys chunk by chunk with wave64 ballots against its own row of digit counters (stable, no atomics), 256 threads turn the 16 x 256
-// counters into exclusive prefixes (over the waves, then over the digits), every wave scatters its keys into the other LDS buffer.
-// Three block barriers per pass.  Zone keys (COMPRESSED): the key is compressed ONCE, when it is loaded -- pext(key, varying bits),
+// counters into each wave's output base per digit (prefix over the waves + prefix over the digits), every wave scatters its keys into
+// the other LDS buffer.  Four block barriers per pass.  Zone keys (COMPRESSED): the key is compressed ONCE, when it is loaded -- pext(key, varying bits),
 // a culled key 1 << popcount -- and the passes that the compressed keys need run on plain 8-bit digits of it.
 constexpr int SL_THREADS = 1024, SL_WAVES = SL_THREADS / 64, SL_CAP = 8192, SL_CH = SL_CAP / SL_THREADS;
 
@@ -631,7 +633,6 @@ __global__ __launch_bounds__(SL_THREADS) void k_sort_segment_lds(
     const uint32_t *__restrict__ key_bits, uint32_t key_recs) {
     __shared__ uint32_t ks[2][SL_CAP], vs[2][SL_CAP];
     __shared__ uint32_t wcnt[SL_WAVES][256];
-    __shared__ uint32_t run_off[256];
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t kb[3 * SL_WAVES];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -701,30 +702,38 @@ __global__ __launch_bounds__(SL_THREADS) void k_sort_segment_lds(
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         __syncthreads();
-        if (tid < 256u) {  // digit `tid`: the waves' counts -> exclusive prefixes over the waves; then over the digits
-            uint32_t cw[SL_WAVES], acc = 0u;
+        // digit `tid` (threads 0 ... 255): the waves' counts -> their exclusive prefix over the waves + the digit's exclusive prefix over the
+        // digits, written back over the counts: the scatter then reads ONE word per key (its wave's base for its digit)
+        uint32_t cw[SL_WAVES], acc = 0u, sc = 0u;
+        if (tid < 256u) {
 #pragma unroll
             for (int w = 0; w < SL_WAVES; ++w) cw[w] = wcnt[w][tid];
 #pragma unroll
-            for (int w = 0; w < SL_WAVES; ++w) { wcnt[w][tid] = acc; acc += cw[w]; }
-            uint32_t sc = acc;
+            for (int w = 0; w < SL_WAVES; ++w) { const uint32_t x = cw[w]; cw[w] = acc; acc += x; }
+            sc = acc;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t v = __shfl_up(sc, o, 64);
                 if ((int)lane >= o) sc += v;
             }
             if (lane == 63u) wtot[wave] = sc;
-            run_off[tid] = sc - acc;
+        }
+        __syncthreads();
+        if (tid < 256u) {
+            uint32_t base = sc - acc;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) base += (w < (int)wave) ? wtot[w] : 0u;
+#pragma unroll
+            for (int w = 0; w < SL_WAVES; ++w) wcnt[w][tid] = base + cw[w];
         }
         __syncthreads();
         const bool last = p + 1u == passes;
         uint32_t *kd = ks[p & 1u], *vd = vs[p & 1u];
-        const uint32_t t0 = wtot[0], t1 = t0 + wtot[1], t2 = t1 + wtot[2];
 #pragma unroll
         for (int c = 0; c < SL_CH; ++c) {
             if (valid[c]) {  // (false for c >= nch)
                 const uint32_t d = dig[c];
-                const uint32_t dst = run_off[d] + (d >= 192u ? t2 : (d >= 128u ? t1 : (d >= 64u ? t0 : 0u))) + wcnt[wave][d] + lrank[c];
+                const uint32_t dst = wcnt[wave][d] + lrank[c];
                 if (last) {
                     vals_out[seg0 + dst] = val[c];
                     if (!COMPRESSED && keys_out) keys_out[seg0 + dst] = key[c];
